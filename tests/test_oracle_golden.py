@@ -1,0 +1,152 @@
+"""The CPU oracle against the fixtures produced by the reference itself (tools/make_golden.py)."""
+import numpy as np
+import pytest
+import torch
+
+from licv.config import IDEFICS_MID, IDEFICS_TINY
+from licv.synthetic import synth_idefics_weights, weights_checksum
+from oracle import icv_ref as O
+from oracle import idefics_ref as R
+
+T = torch.from_numpy
+
+
+def test_g1_encoder_init_and_alpha(golden):
+    z = golden("g1_encoder")
+    for tag in ("a", "b"):
+        H, L, a0, sig = z[f"{tag}_cfg"]
+        torch.manual_seed(426)
+        icv, alpha = O.encoder_init(int(H), int(L), float(a0))
+        assert torch.equal(icv, T(z[f"{tag}_icv"]))
+        assert torch.equal(alpha, T(z[f"{tag}_alpha_param"]))
+        assert torch.equal(O.encoder_alpha(alpha, bool(sig)), T(z[f"{tag}_alpha_out"]))
+        assert list(z[f"{tag}_state_keys"]) == ["alpha", "icv"]
+
+
+def test_g2_layer_bookkeeping(golden):
+    z = golden("g2_intervention")
+    layers = O.prepare_layers([3, 7, 1], 8)
+    assert O.layer_names(layers, "model.model.layers.<LAYER_NUM>") == list(z["names"])
+    m = O.layer_to_icv_index(layers)
+    assert list(m.keys()) == list(z["map_keys"]) and list(m.values()) == list(z["map_vals"])
+    assert O.layer_names(O.prepare_layers(-1, 5), "blk.<LAYER_NUM>.mlp") == list(z["names_all"])
+    assert O.layer_names(O.prepare_layers(2, 5), "blk.<LAYER_NUM>") == list(z["names_int"])
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_g2_inject_renorm(golden, dt):
+    z = golden("g2_intervention")
+    icv = T(z["icv"])
+    h = T(z[f"h_{dt}"]).to(torch.bfloat16 if dt == "bf16" else torch.float32)
+    m = O.layer_to_icv_index([3, 7, 1])
+    out = O.inject_renorm(h, icv[:, m[7]])
+    assert out.dtype == torch.float32 and bool(z[f"tensor_{dt}_is_f32"])
+    assert torch.equal(out, T(z[f"tensor_{dt}"]))
+    assert torch.equal(O.inject_renorm(h, icv[:, m[1]]), T(z[f"tuple_{dt}"]))
+
+
+def test_inject_renorm_bwd_matches_autograd():
+    g = torch.Generator().manual_seed(0)
+    h = torch.randn(3, 5, 32, generator=g, dtype=torch.float64, requires_grad=True)
+    v = torch.randn(32, generator=g, dtype=torch.float64, requires_grad=True)
+    go = torch.randn(3, 5, 32, generator=g, dtype=torch.float64)
+    O.inject_renorm(h, v).backward(go)
+    gh, gv = O.inject_renorm_bwd(h.detach(), v.detach(), go)
+    assert torch.allclose(gh, h.grad, atol=1e-12) and torch.allclose(gv, v.grad, atol=1e-12)
+
+
+@pytest.mark.parametrize("tag,arch", [("g3_idefics_tiny", IDEFICS_TINY), ("g3_idefics_mid", IDEFICS_MID)])
+@pytest.mark.parametrize("dn,dt", [("f32", torch.float32), ("bf16", torch.bfloat16)])
+def test_g3_idefics_forward(golden, tag, arch, dn, dt):
+    z = golden(tag)
+    sd32 = synth_idefics_weights(arch, seed=int(z["meta"][0]), dtype=torch.float32)
+    assert weights_checksum(sd32) == float(z["weights_checksum"]), "seeded weight generator drifted"
+    sd = {k: v.to(dt) for k, v in sd32.items()}
+    ins = dict(input_ids=T(z["in_input_ids"]), attention_mask=T(z["in_attention_mask"]),
+               pixel_values=T(z["in_pixel_values"]).to(dt), image_attention_mask=T(z["in_image_attention_mask"]))
+    tol = 1e-5 if dn == "f32" else 0.0          # bf16 restatement is bit-for-bit the HF path on CPU
+    with torch.no_grad():
+        cap = {}
+        off = R.forward(sd, arch, **ins, capture=cap)
+        assert (off.float() - T(z[f"{dn}_logits_off"])).abs().max() <= tol
+        assert (cap["image_states"].float().reshape(-1) - T(z[f"{dn}_image_states"]).reshape(-1)).abs().max() <= tol
+        for hs, layers in (("all", list(range(arch.num_layers))), ("sub", [1, 3])):
+            if f"{dn}_{hs}_logits" not in z.files:
+                continue
+            icv = T(z["icv_full"])[:, : len(layers)]
+            cap = {}
+            lg = R.forward(sd, arch, **ins, icv=icv, hook_layers=layers, capture=cap)
+            assert (lg.float() - T(z[f"{dn}_{hs}_logits"])).abs().max() <= tol
+            raw = torch.stack([t.float() for t in cap["raw"]])
+            assert (raw - T(z[f"{dn}_{hs}_raw"])).abs().max() <= tol
+            ed = torch.stack([cap["edited"][i].float() for i in z[f"{dn}_{hs}_edited_idx"]])
+            assert (ed - T(z[f"{dn}_{hs}_edited"])).abs().max() <= tol
+            # fp32 icv promotes the residual stream to fp32 from the first hooked layer on
+            assert cap["edited"][-1].dtype == torch.float32
+
+
+def _g6_setup(golden, dt):
+    z = golden("g6_loss")
+    arch = IDEFICS_TINY
+    sd32 = synth_idefics_weights(arch, seed=31, dtype=torch.float32)
+    assert weights_checksum(sd32) == float(z["weights_checksum"])
+    sd = {k: v.to(dt) for k, v in sd32.items()}
+    def b(n):
+        return dict(input_ids=T(z[f"{n}_input_ids"]), attention_mask=T(z[f"{n}_attention_mask"]),
+                    pixel_values=T(z[f"{n}_pixel_values"]).to(dt), image_attention_mask=T(z[f"{n}_image_attention_mask"]))
+    return z, arch, sd, b("stu"), b("tea")
+
+
+def test_g6_masks(golden):
+    z, arch, sd, stu, tea = _g6_setup(golden, torch.float32)
+    assert torch.equal(O.get_mask(stu["input_ids"], T(z["query_x_length"]), arch.pad_token_id), T(z["stu_mask"]))
+    assert torch.equal(O.get_mask(tea["input_ids"], T(z["in_context_length"]), arch.pad_token_id), T(z["tea_mask"]))
+    assert int(T(z["stu_mask"]).sum()) == int(T(z["tea_mask"]).sum())
+
+
+@pytest.mark.parametrize("dn,dt", [("f32", torch.float32), ("bf16", torch.bfloat16)])
+@pytest.mark.parametrize("temp", [1.0, 2.0])
+def test_g6_kl_loss_and_grads(golden, dn, dt, temp):
+    z, arch, sd, stu, tea = _g6_setup(golden, dt)
+    icv = T(z["enc_icv"]).clone().requires_grad_(True)
+    alpha = T(z["enc_alpha_param"]).clone().requires_grad_(True)
+    icv_eff = O.scale_icv(O.encoder_alpha(alpha, True), icv)
+    layers = list(range(arch.num_layers))
+    s_logits = R.forward(sd, arch, **stu, icv=icv_eff, hook_layers=layers)
+    with torch.no_grad():
+        t_logits = R.forward(sd, arch, **tea)
+    sm, tm = T(z["stu_mask"]), T(z["tea_mask"])
+    kl = O.kl_divergence(s_logits[sm].view(-1, s_logits.shape[-1]), t_logits[tm].view(-1, t_logits.shape[-1]), temp)
+    kl.backward()
+    key = f"{dn}_T{int(temp)}"
+    tol = 1e-6 if dn == "f32" else 0.0
+    assert abs(float(kl) - float(z[f"{key}_kl"])) <= tol
+    gtol = 1e-7 if dn == "f32" else 0.0
+    assert (icv.grad - T(z[f"{key}_grad_icv"])).abs().max() <= gtol
+    assert (alpha.grad - T(z[f"{key}_grad_alpha"])).abs().max() <= gtol
+
+
+def test_g6_student_logits_and_ce(golden):
+    z, arch, sd, stu, tea = _g6_setup(golden, torch.float32)
+    icv_eff = O.scale_icv(O.encoder_alpha(T(z["enc_alpha_param"]), True), T(z["enc_icv"]))
+    with torch.no_grad():
+        lg = R.forward(sd, arch, **stu, icv=icv_eff, hook_layers=list(range(arch.num_layers)))
+    assert (lg - T(z["f32_student_logits"])).abs().max() <= 1e-6
+    ce = O.ce_masked(lg, stu["input_ids"], stu["attention_mask"])
+    assert abs(float(ce) - float(z["f32_student_ce"])) <= 1e-5
+
+
+def test_g7_adamw_cosine(golden):
+    z = golden("g7_optim")
+    icv, alpha = T(z["icv0"]).clone(), T(z["alpha0"]).clone()
+    mi, vi, ma, va = [torch.zeros_like(x) for x in (icv, icv, alpha, alpha)]
+    total, warm = float(z["total"]), float(z["warm"])
+    for s in range(z["lrs"].shape[0]):
+        lam = O.cosine_warmup_lambda(s, warm, total)
+        lr_a, lr_i = 1e-2 * lam, 1e-4 * lam
+        assert np.allclose([lr_a, lr_i], z["lrs"][s], rtol=1e-12, atol=0)
+        (ga, gi), _ = O.clip_grad_norm([T(z["grads_alpha"][s]), T(z["grads_icv"][s])], 1.0)
+        alpha, ma, va = O.adamw_step(alpha, ga, ma, va, s + 1, lr_a)
+        icv, mi, vi = O.adamw_step(icv, gi, mi, vi, s + 1, lr_i)
+        assert (icv - T(z["icv_steps"][s])).abs().max() <= 1e-8
+        assert (alpha - T(z["alpha_steps"][s])).abs().max() <= 1e-7
