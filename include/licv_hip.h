@@ -1,0 +1,156 @@
+/*
+ * licv_hip.h — C-ABI of liblicv_hip.so: the MI355X (gfx950) kernels of the L-ICV hot path.
+ *
+ * Boundary: the reference is pure Python; its FFI for this path would be a
+ * ctypes binding.  Each entry point below names the reference/HF interface whose arithmetic it
+ * replaces (ref: = ForJadeForest/LICV-VQA, hf: = transformers/models).  Conventions:
+ *   - plain pointers + sizes, no torch types; every pointer is a DEVICE pointer unless noted;
+ *   - the caller owns all buffers; the library allocates nothing and never synchronises;
+ *   - every launch goes on the `stream` argument (a hipStream_t passed as void*);
+ *   - return 0 on success, a negative LICV_E_* otherwise; licv_last_error() gives the text
+ *     (thread-local, host pointer);
+ *   - dtype arguments use the LICV_* enums; leading dimensions (`ld*`) are in ELEMENTS.
+ */
+#ifndef LICV_HIP_H
+#define LICV_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LICV_ABI_VERSION 1
+
+enum { LICV_BF16 = 0, LICV_F32 = 1 };
+enum { LICV_OK = 0, LICV_E_BADARG = -1, LICV_E_UNSUPPORTED = -2, LICV_E_HIP = -3 };
+
+int         licv_version(void);
+const char* licv_last_error(void);
+
+/* ---- the hook: ref:icv_src/icv_model/icv_intervention.py:61-86 (intervention_function) ----
+ * out[r,:] = (h[r,:]+v) / ||h[r,:]+v|| * ||h[r,:]||, fp32 maths, fp32 output (torch promotion of a
+ * bf16/fp32 stream with the fp32 ICV).  v = alpha*icv[layer] when `alpha` != NULL (folds
+ * ref:icv_src/icv_module.py:89-92), else v = icv_row as given.  `alpha` is a device pointer to one float.
+ * If norm_w != NULL the RMSNorm that consumes the edited stream next (hf:idefics/modeling_idefics.py:342-350)
+ * is fused: xn_out (bf16) = w * bf16(out * rsqrt(mean(out^2)+eps)).  out may alias h when h is fp32. */
+int licv_inject_renorm_fwd(const void* h, int h_dtype, const float* icv_row, const float* alpha,
+                           float* out, int64_t rows, int64_t hidden,
+                           const void* norm_w, void* xn_out, float norm_eps, void* stream);
+
+/* backward of the hook for training (gradients reach icv and alpha only through here;
+ * ref:icv_src/icv_module.py:97-98 runs the student pass with grad).  grad_h may be NULL.
+ * grad_v_partial: (n_partials, hidden) fp32 workspace, fully overwritten; the caller sums over
+ * dim 0.  n_partials = licv_inject_bwd_partials(rows). */
+int64_t licv_inject_bwd_partials(int64_t rows);
+int licv_inject_renorm_bwd(const void* h, int h_dtype, const float* icv_row, const float* alpha,
+                           const float* grad_out, float* grad_h, float* grad_v_partial,
+                           int64_t rows, int64_t hidden, void* stream);
+
+/* ---- norms ----
+ * Row r of the (rows x dim) problem lives at  x + (r / inner)*ld_outer + (r % inner)*dim  (same for out
+ * with its own ld); inner=1, ld=dim is the dense case, inner=n_heads covers per-head q/k norms.
+ * RMSNorm flavours: 0 = Idefics (hf:idefics/modeling_idefics.py:342-350: cast to bf16 THEN * weight),
+ *                   1 = Mistral (hf:mistral/modeling_mistral.py:182-199: weight * cast-back).          */
+int licv_rmsnorm_fwd(const void* x, int x_dtype, const void* w_bf16, void* out_bf16,
+                     int64_t rows, int64_t dim, int64_t inner, int64_t ld_x, int64_t ld_out,
+                     float eps, int flavour, void* stream);
+/* nn.LayerNorm on a bf16 tensor (hf:idefics/vision.py:286-299, perceiver.py:140-141,155-156): fp32
+ * statistics, one rounding.  Input rows addressed as for RMSNorm; output row r goes to
+ *   out + (r / inner)*ld_out + (r % inner)*dim + (out_group > 0 ? (r / out_group)*out_group_extra : 0)
+ * which lets LN(context) and LN(latents) land directly inside the perceiver's concatenated K/V input. */
+int licv_layernorm_fwd(const void* x_bf16, const void* w_bf16, const void* b_bf16, void* out_bf16,
+                       int64_t rows, int64_t dim, int64_t inner, int64_t ld_x, int64_t ld_out,
+                       int64_t out_group, int64_t out_group_extra, float eps, void* stream);
+
+/* ---- rotary: hf:idefics/modeling_idefics.py:396-428 (rotate_half form, gathered by position_ids) ----
+ * In place on `n_tensors` (1 or 2: q and k) head-major slices of a (rows x ld) bf16 buffer:
+ * tensor t, head h, row r at x + r*ld + t*tensor_stride + h*head_dim.  cos/sin: (n_pos, head_dim) bf16. */
+int licv_rotary_fwd(void* x_bf16, const void* cos_bf16, const void* sin_bf16, const int64_t* position_ids,
+                    int64_t rows, int64_t n_heads, int64_t head_dim, int64_t ld, int64_t tensor_stride,
+                    int n_tensors, int64_t n_pos, void* stream);
+
+/* ---- dense layers: nn.Linear on MFMA (every F.linear under hf:idefics/ and hf:idefics2/) ----
+ * C[M,N] = epilogue( A[M,K] (bf16, lda) x W[N,K]^T (bf16, ldw) ), fp32 accumulation.
+ * Epilogue, in this order (each step rounds to bf16 as the unfused torch ops would):
+ *   y = bf16(acc + bias[n])                      bias_bf16 may be NULL
+ *   y = bf16(act(y))                             act: 0 none, 1 GELU(erf), 2 GELU(tanh), 3 ReLU
+ *   swiglu != 0: columns come in (gate,up) 16-wide interleaved pairs (weights packed by
+ *                licv_pack_gate_up) and y = bf16(bf16(silu(g)) * u); the output has N/2 columns
+ *   row_gate (fp32 per row) != NULL: y = 0 where row_gate[m] == 0     (cross_attention_gate)
+ *   scale != 0 flag `use_scale`: y = bf16(scale * y)                   (tanh(alpha) gates)
+ *   residual != NULL: out = residual[m,n] + y   in the residual dtype (bf16 or fp32 stream)
+ *   store to C as out_dtype (bf16 or fp32).  C may alias residual.
+ * Requirements: K % 8 == 0, lda/ldw % 8 == 0, ldc % 4 == 0, 16-byte aligned base pointers. */
+typedef struct {
+    const void* bias_bf16;
+    const float* row_gate;
+    const void* residual;
+    int   residual_dtype;
+    int64_t ld_res;
+    int   act;
+    int   swiglu;
+    int   use_scale;
+    float scale;
+    int   out_dtype;
+} licv_gemm_epilogue;
+
+int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
+                   int64_t M, int64_t N, int64_t K, const licv_gemm_epilogue* ep, void* stream);
+/* (2I x K) gate/up weights -> the 16-row interleaved layout the swiglu epilogue expects. */
+int licv_pack_gate_up(const void* gate_bf16, const void* up_bf16, void* packed_bf16,
+                      int64_t inter, int64_t K, void* stream);
+
+/* ---- attention (hf eager_attention_forward, hf:idefics/modeling_idefics.py:450-470; perceiver
+ * hf:idefics/perceiver.py:150-166) as a tiled online-softmax kernel ----
+ * Q: (B, Sq, n_heads, hd) at q + b*q_bs + s*q_rs + h*hd;  K,V likewise with (kv_bs, kv_rs) and
+ * n_kv_heads (GQA: head h reads kv head h / (n_heads/n_kv_heads)).  O: (B, Sq, n_heads*hd) dense bf16.
+ * mask_mode: 0 none; 1 causal with q offset (Sk - Sq) AND key_valid[b,key] != 0 (int32, may be NULL);
+ *            2 key_valid only (bidirectional key-padding mask);
+ *            3 image mask: allowed iff img_mask[b, q, key / img_len] != 0 (int32 (B,Sq,n_img)).
+ * Rows with no allowed key produce zeros. */
+typedef struct {
+    const void* q; int64_t q_bs, q_rs;
+    const void* k; const void* v; int64_t kv_bs, kv_rs;
+    void* o;
+    int64_t B, Sq, Sk, n_heads, n_kv_heads, head_dim;
+    float scale;
+    int   mask_mode;
+    const int32_t* key_valid;
+    const int32_t* img_mask; int64_t n_img, img_len;
+} licv_attn_args;
+
+int licv_attn_fwd(const licv_attn_args* a, void* stream);
+
+/* ---- small data-movement kernels ---- */
+/* hf:idefics/modeling_idefics.py:230-267 IdeficsDecoupledEmbedding (ids >= vocab -> additional table) */
+int licv_embed_gather(const int64_t* ids, const void* table_bf16, const void* extra_bf16, void* out_bf16,
+                      int64_t n_tokens, int64_t dim, int64_t vocab, int64_t n_extra, void* stream);
+/* Conv2d(k=s=patch, no padding) as im2col: pixels (n_img,3,H,W) bf16 -> (n_img*gh*gw, ld_out) with the
+ * first 3*patch*patch columns filled (channel-major, as conv weight.flatten(1)) and the rest zeroed. */
+int licv_im2col_patches(const void* pix_bf16, void* out_bf16, int64_t n_img, int64_t height, int64_t width,
+                        int64_t patch, int64_t ld_out, void* stream);
+/* hf:idefics/vision.py:152-166 + pre_layrnorm :369: x = cat(cls, patches) + pos; emb_out = x (optional),
+ * ln_out = LayerNorm(x).  patches: (n_img*n_patch, dim) bf16. */
+int licv_vit_embed_ln(const void* patches_bf16, const void* cls_bf16, const void* pos_bf16,
+                      const void* ln_w, const void* ln_b, void* out_bf16,
+                      int64_t n_img, int64_t n_patch, int64_t dim, float eps, void* stream);
+/* out[r, :] = src[r % period, :]  (latents.repeat, hf:idefics/perceiver.py:96) */
+int licv_tile_rows(const void* src_bf16, void* out_bf16, int64_t rows, int64_t dim, int64_t period, void* stream);
+/* silu(g)*u for an un-fused (M, 2I) [gate | up] buffer (kept for tests / odd shapes). */
+int licv_swiglu(const void* gu_bf16, void* out_bf16, int64_t rows, int64_t inter, void* stream);
+
+/* ---- loss + optimiser (ref:icv_src/icv_module.py:121-134, :171-209) ---- */
+/* per-row KL(teacher||student) with eps inside the log, rows gathered by index; out_rows fp32 (n_rows). */
+int licv_kl_rows_fwd(const void* stu_logits, const void* tea_logits, int dtype,
+                     const int64_t* stu_rows, const int64_t* tea_rows, int64_t n_rows, int64_t vocab,
+                     int64_t ld_stu, int64_t ld_tea, float temperature, float eps, float* out_rows, void* stream);
+/* fused AdamW over a flat fp32 buffer; lr per element group given by a split index (alpha first). */
+int licv_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t n_group0,
+                    float lr0, float lr1, float beta1, float beta2, float eps, float weight_decay,
+                    int64_t step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LICV_HIP_H */

@@ -1,0 +1,268 @@
+// Tiled online-softmax attention for gfx950 (replaces hf eager_attention_forward,
+// hf:idefics/modeling_idefics.py:450-470, vision.py:169-189, and the perceiver's einsum attention,
+// hf:idefics/perceiver.py:150-166).  One kernel serves: causal self-attention with a key-padding mask,
+// ViT / SigLIP bidirectional attention, the gated cross-attention with the per-token image mask, and the
+// perceiver's latents -> [context, latents] attention; head dims 8..128, GQA, ragged Sq / Sk.
+//
+// Layout of the computation (wave = 64 lanes, 16x16x32 bf16 MFMA):
+//   * workgroup = 4 waves = 64 query rows of one (batch, head); each wave owns 16 queries;
+//   * K and V tiles of 64 keys are staged global -> VGPR -> LDS (issued before the MFMAs of the current
+//     tile, written after them), zero-padded to the MFMA K granularity;
+//   * S^T = K.Q^T (keys on the accumulator rows, the QUERY on lane&15), so every softmax statistic of a
+//     query is lane-local up to two xor-shuffles (lanes l, l^16, l^32, l^48 share a query);
+//   * P^T is then already in B-operand layout for  O^T = V^T.P^T : no LDS round trip for P; V^T
+//     fragments come from the row-major V tile through the transposing LDS read ds_read_b64_tr_b16;
+//   * O^T keeps the query on the lane too, so the running rescale is one multiply per register and the
+//     epilogue stores 4 consecutive head-dim elements (8 bytes) per lane.
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+#define ATT_QB 64     // queries per workgroup
+#define ATT_KB 64     // keys per tile
+
+struct AttnP {
+    const bf16_t* q; int64_t q_bs, q_rs;
+    const bf16_t* k; const bf16_t* v; int64_t kv_bs, kv_rs;
+    bf16_t* o;
+    int B, Sq, Sk, nh, nkv, hd;
+    float scale;
+    int mask_mode;
+    const int32_t* key_valid;
+    const int32_t* img_mask; int n_img, img_len;
+};
+
+__device__ __forceinline__ bf16x4 lds_read_tr(const char* p) {
+    typedef __attribute__((ext_vector_type(4))) short s4;
+    s4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(p));
+    return *reinterpret_cast<bf16x4*>(&r);
+}
+
+template <int DPK, int DPV>
+__global__ __launch_bounds__(256)
+void attn_fwd_k(AttnP a) {
+    constexpr int KSTR = DPK * 2 + 16;          // K tile row stride in bytes (+16: spreads rows over banks)
+    constexpr int VSTR = DPV * 2 + 16;
+    constexpr int KCH = DPK / 8, VCH = DPV / 8; // 16-byte chunks per row
+    constexpr int KLD = (ATT_KB * KCH + 255) / 256, VLD = (ATT_KB * VCH + 255) / 256;
+    __shared__ __attribute__((aligned(16))) char sK[ATT_KB * KSTR];
+    __shared__ __attribute__((aligned(16))) char sV[ATT_KB * VSTR];
+    __shared__ int sValid[ATT_KB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, ql = lane & 15;
+    const int qtiles = (a.Sq + ATT_QB - 1) / ATT_QB;
+    int bid = blockIdx.x;
+    const int qt = bid % qtiles; bid /= qtiles;
+    const int head = bid % a.nh;
+    const int b = bid / a.nh;
+    const int kvh = head / (a.nh / a.nkv);
+    const int q0 = qt * ATT_QB;
+    const int qrow = q0 + wave * 16 + ql;                 // this lane's query
+    const bool qok = qrow < a.Sq;
+    const int coff = a.Sk - a.Sq;                          // causal offset (decode steps: Sq < Sk)
+
+    // ---- Q fragments (B operand of S^T = K.Q^T): Q[qrow][ks*32 + 8g .. +7]
+    bf16x8 qf[DPK / 32];
+    {
+        const bf16_t* qp = a.q + (int64_t)b * a.q_bs + (int64_t)qrow * a.q_rs + (int64_t)head * a.hd;
+#pragma unroll
+        for (int ks = 0; ks < DPK / 32; ++ks) {
+            const int d = ks * 32 + g * 8;
+            u32x4 r = u32x4{0u, 0u, 0u, 0u};
+            if (qok && d < a.hd) r = *reinterpret_cast<const u32x4*>(qp + d);
+            qf[ks] = *reinterpret_cast<bf16x8*>(&r);
+        }
+    }
+
+    int kend = a.Sk;
+    if (a.mask_mode == 1) kend = min(a.Sk, q0 + ATT_QB + coff);      // keys beyond the last query's diagonal
+    const int ntiles = (kend + ATT_KB - 1) / ATT_KB;
+
+    const bf16_t* kbase = a.k + (int64_t)b * a.kv_bs + (int64_t)kvh * a.hd;
+    const bf16_t* vbase = a.v + (int64_t)b * a.kv_bs + (int64_t)kvh * a.hd;
+    u32x4 rk[KLD], rv[VLD];
+    int rvalid = 1;
+    auto load_tile = [&](int t) {
+        const int key0 = t * ATT_KB;
+#pragma unroll
+        for (int i = 0; i < KLD; ++i) {
+            const int c = tid + i * 256;
+            const int row = c / KCH, ch = c % KCH;
+            u32x4 r = u32x4{0u, 0u, 0u, 0u};
+            if (c < ATT_KB * KCH && key0 + row < a.Sk && ch * 8 < a.hd)
+                r = *reinterpret_cast<const u32x4*>(kbase + (int64_t)(key0 + row) * a.kv_rs + ch * 8);
+            rk[i] = r;
+        }
+#pragma unroll
+        for (int i = 0; i < VLD; ++i) {
+            const int c = tid + i * 256;
+            const int row = c / VCH, ch = c % VCH;
+            u32x4 r = u32x4{0u, 0u, 0u, 0u};
+            if (c < ATT_KB * VCH && key0 + row < a.Sk && ch * 8 < a.hd)
+                r = *reinterpret_cast<const u32x4*>(vbase + (int64_t)(key0 + row) * a.kv_rs + ch * 8);
+            rv[i] = r;
+        }
+        if (tid < ATT_KB) {
+            const int key = key0 + tid;
+            int ok = key < a.Sk;
+            if (ok && a.key_valid && (a.mask_mode == 1 || a.mask_mode == 2)) ok = a.key_valid[(int64_t)b * a.Sk + key] != 0;
+            rvalid = ok;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < KLD; ++i) {
+            const int c = tid + i * 256;
+            if (c < ATT_KB * KCH) *reinterpret_cast<u32x4*>(sK + (c / KCH) * KSTR + (c % KCH) * 16) = rk[i];
+        }
+#pragma unroll
+        for (int i = 0; i < VLD; ++i) {
+            const int c = tid + i * 256;
+            if (c < ATT_KB * VCH) *reinterpret_cast<u32x4*>(sV + (c / VCH) * VSTR + (c % VCH) * 16) = rv[i];
+        }
+        if (tid < ATT_KB) sValid[tid] = rvalid;
+    };
+
+    floatx4 oacc[DPV / 16];
+#pragma unroll
+    for (int i = 0; i < DPV / 16; ++i) oacc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+
+    if (ntiles > 0) { load_tile(0); store_tile(); }
+    __syncthreads();
+
+    const int32_t* imrow = (a.mask_mode == 3 && qok) ? a.img_mask + ((int64_t)b * a.Sq + qrow) * a.n_img : nullptr;
+    const bool img_uniform = (a.mask_mode == 3) && (a.img_len % ATT_KB == 0);
+
+    for (int t = 0; t < ntiles; ++t) {
+        if (t + 1 < ntiles) load_tile(t + 1);
+        const int key0 = t * ATT_KB;
+
+        // ---- S^T tile: 4 sub-tiles of 16 keys; lane holds keys key0 + st*16 + 4g + r for query ql
+        floatx4 s[4];
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            s[st] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < DPK / 32; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (st * 16 + ql) * KSTR + (ks * 32 + g * 8) * 2);
+                s[st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[st], 0, 0, 0);
+            }
+        }
+        // ---- scale + mask
+        int img_ok_tile = 1;
+        if (img_uniform) img_ok_tile = imrow ? (imrow[key0 / a.img_len] != 0) : 0;
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const int kl = st * 16 + g * 4;
+            const int4 kv4 = *reinterpret_cast<const int4*>(&sValid[kl]);
+            const int kvv[4] = {kv4.x, kv4.y, kv4.z, kv4.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = key0 + kl + r;
+                bool ok = qok && kvv[r] != 0;
+                if (a.mask_mode == 1) ok = ok && (key <= qrow + coff);
+                if (a.mask_mode == 3) {
+                    if (img_uniform) ok = ok && img_ok_tile;
+                    else ok = ok && imrow && (imrow[key / a.img_len] != 0);
+                }
+                const float v = ok ? s[st][r] * a.scale : -INFINITY;
+                s[st][r] = v;
+                tmax = fmaxf(tmax, v);
+            }
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = __expf(m_run - m_use);           // m_run = -inf -> 0
+        float psum = 0.f;
+        bf16x8 pf[2];
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __expf(s[st][r] - m_use);
+                psum += p;
+                pf[st >> 1][(st & 1) * 4 + r] = (__bf16)p;
+            }
+        }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int i = 0; i < DPV / 16; ++i) oacc[i] *= alpha;
+
+        // ---- O^T += V^T . P^T : k-step s2 covers sub-tiles 2*s2, 2*s2+1
+#pragma unroll
+        for (int dt = 0; dt < DPV / 16; ++dt) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const char* p0 = sV + ((2 * s2) * 16 + g * 4 + (ql >> 2)) * VSTR + (dt * 16 + (ql & 3) * 4) * 2;
+                const bf16x4 lo = lds_read_tr(p0);
+                const bf16x4 hi = lds_read_tr(p0 + 16 * VSTR);
+                bf16x8 vf;
+                vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+                vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+                oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[s2], oacc[dt], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                   // everyone done reading this tile
+        if (t + 1 < ntiles) store_tile();
+        __syncthreads();
+    }
+
+    // ---- epilogue: O[b, qrow, head*hd + d], lane holds d = dt*16 + 4g + r
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+    if (qok) {
+        bf16_t* op = a.o + ((int64_t)b * a.Sq + qrow) * ((int64_t)a.nh * a.hd) + (int64_t)head * a.hd;
+#pragma unroll
+        for (int dt = 0; dt < DPV / 16; ++dt) {
+            const int d = dt * 16 + g * 4;
+            if (d < a.hd) {
+                uint2 u;
+                u.x = (uint32_t)f2bf(oacc[dt][0] * inv) | ((uint32_t)f2bf(oacc[dt][1] * inv) << 16);
+                u.y = (uint32_t)f2bf(oacc[dt][2] * inv) | ((uint32_t)f2bf(oacc[dt][3] * inv) << 16);
+                *reinterpret_cast<uint2*>(op + d) = u;
+            }
+        }
+    }
+}
+
+extern "C" int licv_attn_fwd(const licv_attn_args* x, void* stream) {
+    LICV_CHECK_ARG(x && x->q && x->k && x->v && x->o, "attn_fwd: null pointer");
+    LICV_CHECK_ARG(x->B > 0 && x->Sq > 0 && x->Sk > 0 && x->n_heads > 0 && x->n_kv_heads > 0, "attn_fwd: bad shape");
+    LICV_CHECK_ARG(x->n_heads % x->n_kv_heads == 0, "attn_fwd: n_heads must be a multiple of n_kv_heads");
+    LICV_CHECK_ARG(x->head_dim % 8 == 0 && x->head_dim >= 8 && x->head_dim <= 128, "attn_fwd: head_dim %lld unsupported (multiple of 8, <= 128)", (long long)x->head_dim);
+    LICV_CHECK_ARG(x->q_rs % 8 == 0 && x->kv_rs % 8 == 0 && x->q_bs % 8 == 0 && x->kv_bs % 8 == 0, "attn_fwd: strides must be multiples of 8 elements");
+    LICV_CHECK_ARG(((uintptr_t)x->q & 15) == 0 && ((uintptr_t)x->k & 15) == 0 && ((uintptr_t)x->v & 15) == 0 && ((uintptr_t)x->o & 7) == 0, "attn_fwd: misaligned pointer");
+    LICV_CHECK_ARG(x->mask_mode >= 0 && x->mask_mode <= 3, "attn_fwd: bad mask mode %d", x->mask_mode);
+    LICV_CHECK_ARG(x->mask_mode != 3 || (x->img_mask && x->n_img > 0 && x->img_len > 0 && x->n_img * x->img_len >= x->Sk), "attn_fwd: image mask arguments inconsistent");
+    LICV_CHECK_ARG(x->Sq < (1ll << 30) && x->Sk < (1ll << 30), "attn_fwd: sequence too long");
+    AttnP p;
+    p.q = (const bf16_t*)x->q; p.q_bs = x->q_bs; p.q_rs = x->q_rs;
+    p.k = (const bf16_t*)x->k; p.v = (const bf16_t*)x->v; p.kv_bs = x->kv_bs; p.kv_rs = x->kv_rs;
+    p.o = (bf16_t*)x->o;
+    p.B = (int)x->B; p.Sq = (int)x->Sq; p.Sk = (int)x->Sk; p.nh = (int)x->n_heads; p.nkv = (int)x->n_kv_heads; p.hd = (int)x->head_dim;
+    p.scale = x->scale; p.mask_mode = x->mask_mode; p.key_valid = x->key_valid;
+    p.img_mask = x->img_mask; p.n_img = (int)x->n_img; p.img_len = (int)x->img_len;
+    const int64_t qtiles = (x->Sq + ATT_QB - 1) / ATT_QB;
+    const int64_t nblk = x->B * x->n_heads * qtiles;
+    LICV_CHECK_ARG(nblk < (1ll << 31), "attn_fwd: grid too large");
+    const dim3 grid((unsigned)nblk), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    const int hd = p.hd;
+    if (hd <= 16)        attn_fwd_k<32, 16><<<grid, block, 0, st>>>(p);
+    else if (hd <= 32)   attn_fwd_k<32, 32><<<grid, block, 0, st>>>(p);
+    else if (hd <= 64)   attn_fwd_k<64, 64><<<grid, block, 0, st>>>(p);
+    else if (hd <= 80)   attn_fwd_k<96, 80><<<grid, block, 0, st>>>(p);
+    else if (hd <= 96)   attn_fwd_k<96, 96><<<grid, block, 0, st>>>(p);
+    else                 attn_fwd_k<128, 128><<<grid, block, 0, st>>>(p);
+    LICV_LAUNCH_CHECK();
+    return LICV_OK;
+}

@@ -1,0 +1,565 @@
+// Row-wise, HBM-bound kernels of the L-ICV hot path for gfx950: the ICV hook (inject + norm-preserve),
+// RMSNorm / LayerNorm, rotary, and the small gather / layout kernels.
+//
+// Shape of every row kernel: ONE 64-lane wave owns one row, keeps it in registers (NCH chunks of
+// 4 elements per lane, coalesced 16-B / 8-B accesses), reduces with cross-lane shuffles (no LDS, no
+// barrier), and writes the row once: algorithmic traffic = 1 read + 1 write.  4 waves per workgroup.
+#include "common.h"
+
+#define WAVES_PER_BLOCK 4
+
+template <int DT> struct RowIO;
+template <> struct RowIO<LICV_F32> {
+    static __device__ __forceinline__ floatx4 load4(const void* p, int64_t i) {
+        return *reinterpret_cast<const floatx4*>(reinterpret_cast<const float*>(p) + i);
+    }
+};
+template <> struct RowIO<LICV_BF16> {
+    static __device__ __forceinline__ floatx4 load4(const void* p, int64_t i) {
+        const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(p) + i);
+        floatx4 r;
+        r[0] = __uint_as_float(u.x << 16); r[1] = __uint_as_float(u.x & 0xffff0000u);
+        r[2] = __uint_as_float(u.y << 16); r[3] = __uint_as_float(u.y & 0xffff0000u);
+        return r;
+    }
+};
+__device__ __forceinline__ void store4_bf16(void* p, int64_t i, floatx4 v) {
+    uint2 u;
+    u.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+    u.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p) + i) = u;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ICV hook forward.  ref:icv_src/icv_model/icv_intervention.py:62-84
+// ------------------------------------------------------------------------------------------------
+template <int DT, int NCH, bool FUSE_NORM>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK)
+void inject_renorm_fwd_k(const void* __restrict__ h, const float* __restrict__ icv, const float* __restrict__ alpha,
+                         float* __restrict__ out, int64_t rows, int hidden,
+                         const bf16_t* __restrict__ norm_w, bf16_t* __restrict__ xn, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float a = alpha ? *alpha : 1.0f;
+    const int64_t base = row * hidden;
+    floatx4 x[NCH];
+    float ss = 0.f, hh = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int i = (c * 64 + lane) * 4;
+        if (i < hidden) {
+            const floatx4 hv = RowIO<DT>::load4(h, base + i);
+            const floatx4 vv = *reinterpret_cast<const floatx4*>(icv + i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float s = hv[j] + a * vv[j];
+                hh += hv[j] * hv[j];
+                ss += s * s;
+                x[c][j] = s;
+            }
+        }
+    }
+    ss = wave_sum(ss);
+    hh = wave_sum(hh);
+    // shifted / ||shifted|| * ||h||  in that order, as the reference writes it
+    const float ns = sqrtf(ss), nh = sqrtf(hh);
+    float q2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int i = (c * 64 + lane) * 4;
+        if (i < hidden) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                x[c][j] = x[c][j] / ns * nh;
+                q2 += x[c][j] * x[c][j];
+            }
+            *reinterpret_cast<floatx4*>(out + base + i) = x[c];
+        }
+    }
+    if (FUSE_NORM) {
+        q2 = wave_sum(q2);
+        const float rs = rsqrtf(q2 / (float)hidden + eps);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int i = (c * 64 + lane) * 4;
+            if (i < hidden) {
+                const floatx4 w = RowIO<LICV_BF16>::load4(norm_w, i);
+                floatx4 y;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) y[j] = w[j] * rbf(x[c][j] * rs);
+                store4_bf16(xn, base + i, y);
+            }
+        }
+    }
+}
+
+// ICV hook backward: grad wrt h (optional) and per-wave partial sums of grad wrt v.
+template <int DT, int NCH>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK)
+void inject_renorm_bwd_k(const void* __restrict__ h, const float* __restrict__ icv, const float* __restrict__ alpha,
+                         const float* __restrict__ go, float* __restrict__ gh, float* __restrict__ gv_part,
+                         int64_t rows, int hidden) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * WAVES_PER_BLOCK;
+    const float a = alpha ? *alpha : 1.0f;
+    floatx4 acc[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) acc[c] = floatx4{0.f, 0.f, 0.f, 0.f};
+    for (int64_t row = wave; row < rows; row += nwaves) {
+        const int64_t base = row * hidden;
+        floatx4 s[NCH], g[NCH], hv[NCH];
+        float ss = 0.f, hh = 0.f, gs = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int i = (c * 64 + lane) * 4;
+            if (i < hidden) {
+                hv[c] = RowIO<DT>::load4(h, base + i);
+                g[c] = *reinterpret_cast<const floatx4*>(go + base + i);
+                const floatx4 vv = *reinterpret_cast<const floatx4*>(icv + i);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    s[c][j] = hv[c][j] + a * vv[j];
+                    ss += s[c][j] * s[c][j];
+                    hh += hv[c][j] * hv[c][j];
+                    gs += g[c][j] * s[c][j];
+                }
+            }
+        }
+        ss = wave_sum(ss); hh = wave_sum(hh); gs = wave_sum(gs);
+        const float ns = sqrtf(ss), nh = sqrtf(hh);
+        const float r = nh / ns;                 // d out / d s = r * (I - u u^T),  u = s/ns
+        const float gu = gs / ns;                // <g, u>
+        const float kh = gu / nh;                // d out / d h (through ||h||) = u h^T / nh
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int i = (c * 64 + lane) * 4;
+            if (i < hidden) {
+                floatx4 dh;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float dsj = r * (g[c][j] - s[c][j] / ns * gu);
+                    acc[c][j] += dsj;
+                    dh[j] = dsj + kh * hv[c][j];
+                }
+                if (gh) *reinterpret_cast<floatx4*>(gh + base + i) = dh;
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int i = (c * 64 + lane) * 4;
+        if (i < hidden) *reinterpret_cast<floatx4*>(gv_part + (int64_t)wave * hidden + i) = acc[c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// RMSNorm.  hf:idefics/modeling_idefics.py:342-350 (flavour 0), hf:mistral/modeling_mistral.py:182-199 (1)
+// ------------------------------------------------------------------------------------------------
+template <int DT, int NCH>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK)
+void rmsnorm_fwd_k(const void* __restrict__ x, const bf16_t* __restrict__ w, bf16_t* __restrict__ out,
+                   int64_t rows, int dim, int64_t inner, int64_t ld_x, int64_t ld_out, float eps, int flavour) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int64_t ro = row / inner, ri = row % inner;
+    const int64_t xb = ro * ld_x + ri * dim, ob = ro * ld_out + ri * dim;
+    floatx4 v[NCH];
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int i = (c * 64 + lane) * 4;
+        if (i < dim) {
+            v[c] = RowIO<DT>::load4(x, xb + i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ss += v[c][j] * v[c][j];
+        }
+    }
+    ss = wave_sum(ss);
+    const float rs = rsqrtf(ss / (float)dim + eps);
+    const bool single_round = (flavour == 1 && DT == LICV_F32);   // Mistral norm on an fp32 stream
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int i = (c * 64 + lane) * 4;
+        if (i < dim) {
+            const floatx4 wv = RowIO<LICV_BF16>::load4(w, i);
+            floatx4 y;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float n = v[c][j] * rs;
+                y[j] = wv[j] * (single_round ? n : rbf(n));
+            }
+            store4_bf16(out, ob + i, y);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm on bf16 (nn.LayerNorm): fp32 statistics, one rounding at the end.
+// ------------------------------------------------------------------------------------------------
+template <int NCH>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK)
+void layernorm_fwd_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, const bf16_t* __restrict__ b,
+                     bf16_t* __restrict__ out, int64_t rows, int dim, int64_t inner, int64_t ld_x, int64_t ld_out,
+                     int64_t out_group, int64_t out_group_extra, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int64_t ro = row / inner, ri = row % inner;
+    const int64_t xb = ro * ld_x + ri * dim;
+    const int64_t ob = ro * ld_out + ri * dim + (out_group > 0 ? (row / out_group) * out_group_extra : 0);
+    floatx4 v[NCH];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int i = (c * 64 + lane) * 4;
+        if (i < dim) {
+            v[c] = RowIO<LICV_BF16>::load4(x, xb + i);
+            s += v[c][0] + v[c][1] + v[c][2] + v[c][3];
+        }
+    }
+    const float mean = wave_sum(s) / (float)dim;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int i = (c * 64 + lane) * 4;
+        if (i < dim) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float d = v[c][j] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)dim + eps);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int i = (c * 64 + lane) * 4;
+        if (i < dim) {
+            const floatx4 wv = RowIO<LICV_BF16>::load4(w, i);
+            const floatx4 bv = RowIO<LICV_BF16>::load4(b, i);
+            floatx4 y;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[j] = (v[c][j] - mean) * rstd * wv[j] + bv[j];
+            store4_bf16(out, ob + i, y);
+        }
+    }
+}
+
+// ViT embeddings + pre-LN: hf:idefics/vision.py:152-166 then :369
+template <int NCH>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK)
+void vit_embed_ln_k(const bf16_t* __restrict__ patches, const bf16_t* __restrict__ cls, const bf16_t* __restrict__ pos,
+                    const bf16_t* __restrict__ w, const bf16_t* __restrict__ b, bf16_t* __restrict__ out,
+                    int64_t n_img, int n_patch, int dim, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const int T = n_patch + 1;
+    if (row >= n_img * T) return;
+    const int64_t img = row / T;
+    const int t = (int)(row % T);
+    const bf16_t* src = (t == 0) ? cls : patches + (img * n_patch + (t - 1)) * (int64_t)dim;
+    floatx4 v[NCH];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int i = (c * 64 + lane) * 4;
+        if (i < dim) {
+            const floatx4 a = RowIO<LICV_BF16>::load4(src, i);
+            const floatx4 p = RowIO<LICV_BF16>::load4(pos, (int64_t)t * dim + i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[c][j] = rbf(a[j] + p[j]); s += v[c][j]; }
+        }
+    }
+    const float mean = wave_sum(s) / (float)dim;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int i = (c * 64 + lane) * 4;
+        if (i < dim) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float d = v[c][j] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)dim + eps);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int i = (c * 64 + lane) * 4;
+        if (i < dim) {
+            const floatx4 wv = RowIO<LICV_BF16>::load4(w, i);
+            const floatx4 bv = RowIO<LICV_BF16>::load4(b, i);
+            floatx4 y;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[j] = (v[c][j] - mean) * rstd * wv[j] + bv[j];
+            store4_bf16(out, row * dim + i, y);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Rotary, rotate_half form.  hf:idefics/modeling_idefics.py:396-428.  Each bf16 torch op rounds:
+// q*cos, rotate_half(q)*sin, and the sum.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void rotary_fwd_k(bf16_t* __restrict__ x, const bf16_t* __restrict__ cosT, const bf16_t* __restrict__ sinT,
+                  const int64_t* __restrict__ pos, int64_t rows, int n_heads, int head_dim, int64_t ld,
+                  int64_t tensor_stride, int n_tensors, int64_t n_pos) {
+    const int half = head_dim >> 1;
+    const int qper = half >> 2;                       // 4-wide groups per head
+    const int64_t total = rows * n_tensors * (int64_t)n_heads * qper;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(idx % qper);
+        int64_t r = idx / qper;
+        const int hd = (int)(r % n_heads); r /= n_heads;
+        const int t = (int)(r % n_tensors);
+        const int64_t row = r / n_tensors;
+        int64_t p = pos[row];
+        p = p < 0 ? 0 : (p >= n_pos ? n_pos - 1 : p);
+        const int i = g * 4;
+        bf16_t* base = x + row * ld + t * tensor_stride + (int64_t)hd * head_dim;
+        const floatx4 lo = RowIO<LICV_BF16>::load4(base, i);
+        const floatx4 hi = RowIO<LICV_BF16>::load4(base, i + half);
+        const floatx4 c = RowIO<LICV_BF16>::load4(cosT, p * head_dim + i);
+        const floatx4 s = RowIO<LICV_BF16>::load4(sinT, p * head_dim + i);
+        floatx4 olo, ohi;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            olo[j] = rbf(lo[j] * c[j]) + rbf(-hi[j] * s[j]);
+            ohi[j] = rbf(hi[j] * c[j]) + rbf(lo[j] * s[j]);
+        }
+        store4_bf16(base, i, olo);
+        store4_bf16(base, i + half, ohi);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// gathers / layout
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void embed_gather_k(const int64_t* __restrict__ ids, const bf16_t* __restrict__ table, const bf16_t* __restrict__ extra,
+                    bf16_t* __restrict__ out, int64_t n_tokens, int dim, int64_t vocab, int64_t n_extra) {
+    const int vec = dim >> 3;                          // 16-byte chunks per row
+    const int64_t total = n_tokens * vec;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t tok = idx / vec;
+        const int c = (int)(idx % vec);
+        int64_t id = ids[tok];
+        const bf16_t* src;
+        if (id >= vocab) { int64_t e = id - vocab; e = e >= n_extra ? n_extra - 1 : e; src = extra + e * dim; }
+        else { id = id < 0 ? 0 : id; src = table + id * dim; }
+        reinterpret_cast<uint4*>(out + tok * dim)[c] = reinterpret_cast<const uint4*>(src)[c];
+    }
+}
+
+__global__ __launch_bounds__(256)
+void im2col_k(const bf16_t* __restrict__ pix, bf16_t* __restrict__ out, int64_t n_img, int H, int W, int P, int64_t ld_out) {
+    const int gh = H / P, gw = W / P;
+    const int kdim = 3 * P * P;
+    const int64_t total = n_img * gh * gw * ld_out;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int col = (int)(idx % ld_out);
+        const int64_t r = idx / ld_out;
+        bf16_t val = 0;
+        if (col < kdim) {
+            const int c = col / (P * P), rem = col % (P * P);
+            const int py = rem / P, px = rem % P;
+            const int gx = (int)(r % gw);
+            const int gy = (int)((r / gw) % gh);
+            const int64_t img = r / ((int64_t)gw * gh);
+            val = pix[((img * 3 + c) * H + (gy * P + py)) * (int64_t)W + gx * P + px];
+        }
+        out[idx] = val;
+    }
+}
+
+__global__ __launch_bounds__(256)
+void tile_rows_k(const bf16_t* __restrict__ src, bf16_t* __restrict__ out, int64_t rows, int dim, int64_t period) {
+    const int vec = dim >> 3;
+    const int64_t total = rows * vec;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = idx / vec;
+        const int c = (int)(idx % vec);
+        reinterpret_cast<uint4*>(out + r * dim)[c] = reinterpret_cast<const uint4*>(src + (r % period) * dim)[c];
+    }
+}
+
+__global__ __launch_bounds__(256)
+void swiglu_k(const bf16_t* __restrict__ gu, bf16_t* __restrict__ out, int64_t rows, int64_t inter) {
+    const int64_t total = rows * inter;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = idx / inter, c = idx % inter;
+        const float g = bf2f(gu[r * 2 * inter + c]);
+        const float u = bf2f(gu[r * 2 * inter + inter + c]);
+        const float s = rbf(g / (1.0f + __expf(-g)));
+        out[idx] = f2bf(s * u);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host launchers
+// ------------------------------------------------------------------------------------------------
+static inline int pick_nch(int64_t dim) {
+    for (int n = 1; n <= 32; n <<= 1) if ((int64_t)n * 256 >= dim) return n;
+    return 0;
+}
+static inline int row_blocks(int64_t rows) { return (int)((rows + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK); }
+static inline int flat_blocks(int64_t total) {
+    int64_t b = (total + 255) / 256;
+    return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+#define DISPATCH_NCH(nch, CALL) switch (nch) { \
+    case 1: { constexpr int N = 1; CALL; } break; case 2: { constexpr int N = 2; CALL; } break; \
+    case 4: { constexpr int N = 4; CALL; } break; case 8: { constexpr int N = 8; CALL; } break; \
+    case 16: { constexpr int N = 16; CALL; } break; case 32: { constexpr int N = 32; CALL; } break; \
+    default: return licv_set_error(LICV_E_UNSUPPORTED, "row length %lld too large", (long long)dim_); }
+
+extern "C" int licv_inject_renorm_fwd(const void* h, int h_dtype, const float* icv_row, const float* alpha,
+                                      float* out, int64_t rows, int64_t hidden,
+                                      const void* norm_w, void* xn_out, float norm_eps, void* stream) {
+    LICV_CHECK_ARG(h && icv_row && out, "inject_renorm_fwd: null pointer");
+    LICV_CHECK_ARG(hidden > 0 && hidden % 4 == 0, "inject_renorm_fwd: hidden (%lld) must be a positive multiple of 4", (long long)hidden);
+    LICV_CHECK_ARG(h_dtype == LICV_BF16 || h_dtype == LICV_F32, "inject_renorm_fwd: bad dtype %d", h_dtype);
+    LICV_CHECK_ARG((norm_w == nullptr) == (xn_out == nullptr), "inject_renorm_fwd: norm_w and xn_out go together");
+    if (rows <= 0) return LICV_OK;
+    const int64_t dim_ = hidden;
+    const int nch = pick_nch(hidden);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(row_blocks(rows)), block(64 * WAVES_PER_BLOCK);
+    const bool fuse = norm_w != nullptr;
+#define LAUNCH_INJ(DTV, FUSE) inject_renorm_fwd_k<DTV, N, FUSE><<<grid, block, 0, st>>>( \
+        h, icv_row, alpha, out, rows, (int)hidden, (const bf16_t*)norm_w, (bf16_t*)xn_out, norm_eps)
+    if (h_dtype == LICV_F32) { if (fuse) { DISPATCH_NCH(nch, LAUNCH_INJ(LICV_F32, true)); } else { DISPATCH_NCH(nch, LAUNCH_INJ(LICV_F32, false)); } }
+    else                     { if (fuse) { DISPATCH_NCH(nch, LAUNCH_INJ(LICV_BF16, true)); } else { DISPATCH_NCH(nch, LAUNCH_INJ(LICV_BF16, false)); } }
+#undef LAUNCH_INJ
+    LICV_LAUNCH_CHECK();
+    return LICV_OK;
+}
+
+static inline int bwd_blocks(int64_t rows) { int b = row_blocks(rows); return b > 128 ? 128 : (b < 1 ? 1 : b); }
+extern "C" int64_t licv_inject_bwd_partials(int64_t rows) { return (int64_t)bwd_blocks(rows) * WAVES_PER_BLOCK; }
+
+extern "C" int licv_inject_renorm_bwd(const void* h, int h_dtype, const float* icv_row, const float* alpha,
+                                      const float* grad_out, float* grad_h, float* grad_v_partial,
+                                      int64_t rows, int64_t hidden, void* stream) {
+    LICV_CHECK_ARG(h && icv_row && grad_out && grad_v_partial, "inject_renorm_bwd: null pointer");
+    LICV_CHECK_ARG(hidden > 0 && hidden % 4 == 0, "inject_renorm_bwd: hidden must be a multiple of 4");
+    LICV_CHECK_ARG(h_dtype == LICV_BF16 || h_dtype == LICV_F32, "inject_renorm_bwd: bad dtype %d", h_dtype);
+    const int64_t dim_ = hidden;
+    const int nch = pick_nch(hidden);
+    LICV_CHECK_ARG(nch > 0 && nch <= 16, "inject_renorm_bwd: hidden %lld unsupported", (long long)hidden);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(bwd_blocks(rows)), block(64 * WAVES_PER_BLOCK);
+#define LAUNCH_INJB(DTV) inject_renorm_bwd_k<DTV, N><<<grid, block, 0, st>>>(h, icv_row, alpha, grad_out, grad_h, grad_v_partial, rows, (int)hidden)
+    if (h_dtype == LICV_F32) { DISPATCH_NCH(nch, LAUNCH_INJB(LICV_F32)); } else { DISPATCH_NCH(nch, LAUNCH_INJB(LICV_BF16)); }
+#undef LAUNCH_INJB
+    LICV_LAUNCH_CHECK();
+    return LICV_OK;
+}
+
+extern "C" int licv_rmsnorm_fwd(const void* x, int x_dtype, const void* w, void* out, int64_t rows, int64_t dim,
+                                int64_t inner, int64_t ld_x, int64_t ld_out, float eps, int flavour, void* stream) {
+    LICV_CHECK_ARG(x && w && out, "rmsnorm_fwd: null pointer");
+    LICV_CHECK_ARG(dim > 0 && dim % 4 == 0 && inner >= 1, "rmsnorm_fwd: dim (%lld) must be a multiple of 4", (long long)dim);
+    LICV_CHECK_ARG(ld_x % 4 == 0 && ld_out % 4 == 0, "rmsnorm_fwd: leading dims must be multiples of 4");
+    LICV_CHECK_ARG(x_dtype == LICV_BF16 || x_dtype == LICV_F32, "rmsnorm_fwd: bad dtype %d", x_dtype);
+    LICV_CHECK_ARG(flavour == 0 || flavour == 1, "rmsnorm_fwd: bad flavour %d", flavour);
+    if (rows <= 0) return LICV_OK;
+    const int64_t dim_ = dim;
+    const int nch = pick_nch(dim);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(row_blocks(rows)), block(64 * WAVES_PER_BLOCK);
+#define LAUNCH_RMS(DTV) rmsnorm_fwd_k<DTV, N><<<grid, block, 0, st>>>(x, (const bf16_t*)w, (bf16_t*)out, rows, (int)dim, inner, ld_x, ld_out, eps, flavour)
+    if (x_dtype == LICV_F32) { DISPATCH_NCH(nch, LAUNCH_RMS(LICV_F32)); } else { DISPATCH_NCH(nch, LAUNCH_RMS(LICV_BF16)); }
+#undef LAUNCH_RMS
+    LICV_LAUNCH_CHECK();
+    return LICV_OK;
+}
+
+extern "C" int licv_layernorm_fwd(const void* x, const void* w, const void* b, void* out, int64_t rows, int64_t dim,
+                                  int64_t inner, int64_t ld_x, int64_t ld_out, int64_t out_group,
+                                  int64_t out_group_extra, float eps, void* stream) {
+    LICV_CHECK_ARG(x && w && b && out, "layernorm_fwd: null pointer");
+    LICV_CHECK_ARG(dim > 0 && dim % 4 == 0 && inner >= 1, "layernorm_fwd: dim (%lld) must be a multiple of 4", (long long)dim);
+    LICV_CHECK_ARG(ld_x % 4 == 0 && ld_out % 4 == 0 && out_group_extra % 4 == 0, "layernorm_fwd: strides must be multiples of 4");
+    if (rows <= 0) return LICV_OK;
+    const int64_t dim_ = dim;
+    const int nch = pick_nch(dim);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(row_blocks(rows)), block(64 * WAVES_PER_BLOCK);
+    DISPATCH_NCH(nch, (layernorm_fwd_k<N><<<grid, block, 0, st>>>((const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)b,
+                 (bf16_t*)out, rows, (int)dim, inner, ld_x, ld_out, out_group, out_group_extra, eps)));
+    LICV_LAUNCH_CHECK();
+    return LICV_OK;
+}
+
+extern "C" int licv_vit_embed_ln(const void* patches, const void* cls, const void* pos, const void* ln_w, const void* ln_b,
+                                 void* out, int64_t n_img, int64_t n_patch, int64_t dim, float eps, void* stream) {
+    LICV_CHECK_ARG(patches && cls && pos && ln_w && ln_b && out, "vit_embed_ln: null pointer");
+    LICV_CHECK_ARG(dim > 0 && dim % 4 == 0, "vit_embed_ln: dim must be a multiple of 4");
+    const int64_t rows = n_img * (n_patch + 1);
+    if (rows <= 0) return LICV_OK;
+    const int64_t dim_ = dim;
+    const int nch = pick_nch(dim);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(row_blocks(rows)), block(64 * WAVES_PER_BLOCK);
+    DISPATCH_NCH(nch, (vit_embed_ln_k<N><<<grid, block, 0, st>>>((const bf16_t*)patches, (const bf16_t*)cls, (const bf16_t*)pos,
+                 (const bf16_t*)ln_w, (const bf16_t*)ln_b, (bf16_t*)out, n_img, (int)n_patch, (int)dim, eps)));
+    LICV_LAUNCH_CHECK();
+    return LICV_OK;
+}
+
+extern "C" int licv_rotary_fwd(void* x, const void* cosT, const void* sinT, const int64_t* position_ids, int64_t rows,
+                               int64_t n_heads, int64_t head_dim, int64_t ld, int64_t tensor_stride, int n_tensors,
+                               int64_t n_pos, void* stream) {
+    LICV_CHECK_ARG(x && cosT && sinT && position_ids, "rotary_fwd: null pointer");
+    LICV_CHECK_ARG(head_dim > 0 && head_dim % 8 == 0, "rotary_fwd: head_dim (%lld) must be a multiple of 8", (long long)head_dim);
+    LICV_CHECK_ARG(ld % 4 == 0 && tensor_stride % 4 == 0 && n_tensors >= 1 && n_pos > 0, "rotary_fwd: bad strides");
+    if (rows <= 0) return LICV_OK;
+    const int64_t total = rows * n_tensors * n_heads * (head_dim / 8);
+    rotary_fwd_k<<<flat_blocks(total), 256, 0, (hipStream_t)stream>>>((bf16_t*)x, (const bf16_t*)cosT, (const bf16_t*)sinT,
+        position_ids, rows, (int)n_heads, (int)head_dim, ld, tensor_stride, n_tensors, n_pos);
+    LICV_LAUNCH_CHECK();
+    return LICV_OK;
+}
+
+extern "C" int licv_embed_gather(const int64_t* ids, const void* table, const void* extra, void* out, int64_t n_tokens,
+                                 int64_t dim, int64_t vocab, int64_t n_extra, void* stream) {
+    LICV_CHECK_ARG(ids && table && out, "embed_gather: null pointer");
+    LICV_CHECK_ARG(dim > 0 && dim % 8 == 0, "embed_gather: dim must be a multiple of 8");
+    LICV_CHECK_ARG(n_extra == 0 || extra, "embed_gather: additional table missing");
+    if (n_tokens <= 0) return LICV_OK;
+    embed_gather_k<<<flat_blocks(n_tokens * (dim / 8)), 256, 0, (hipStream_t)stream>>>(ids, (const bf16_t*)table,
+        (const bf16_t*)extra, (bf16_t*)out, n_tokens, (int)dim, n_extra > 0 ? vocab : INT64_MAX, n_extra);
+    LICV_LAUNCH_CHECK();
+    return LICV_OK;
+}
+
+extern "C" int licv_im2col_patches(const void* pix, void* out, int64_t n_img, int64_t height, int64_t width, int64_t patch,
+                                   int64_t ld_out, void* stream) {
+    LICV_CHECK_ARG(pix && out, "im2col_patches: null pointer");
+    LICV_CHECK_ARG(patch > 0 && height % patch == 0 && width % patch == 0, "im2col_patches: image not a multiple of the patch");
+    LICV_CHECK_ARG(ld_out >= 3 * patch * patch, "im2col_patches: ld_out too small");
+    const int64_t total = n_img * (height / patch) * (width / patch) * ld_out;
+    if (total <= 0) return LICV_OK;
+    im2col_k<<<flat_blocks(total), 256, 0, (hipStream_t)stream>>>((const bf16_t*)pix, (bf16_t*)out, n_img, (int)height,
+        (int)width, (int)patch, ld_out);
+    LICV_LAUNCH_CHECK();
+    return LICV_OK;
+}
+
+extern "C" int licv_tile_rows(const void* src, void* out, int64_t rows, int64_t dim, int64_t period, void* stream) {
+    LICV_CHECK_ARG(src && out && period > 0, "tile_rows: bad argument");
+    LICV_CHECK_ARG(dim > 0 && dim % 8 == 0, "tile_rows: dim must be a multiple of 8");
+    if (rows <= 0) return LICV_OK;
+    tile_rows_k<<<flat_blocks(rows * (dim / 8)), 256, 0, (hipStream_t)stream>>>((const bf16_t*)src, (bf16_t*)out, rows, (int)dim, period);
+    LICV_LAUNCH_CHECK();
+    return LICV_OK;
+}
+
+extern "C" int licv_swiglu(const void* gu, void* out, int64_t rows, int64_t inter, void* stream) {
+    LICV_CHECK_ARG(gu && out && inter > 0, "swiglu: bad argument");
+    if (rows <= 0) return LICV_OK;
+    swiglu_k<<<flat_blocks(rows * inter), 256, 0, (hipStream_t)stream>>>((const bf16_t*)gu, (bf16_t*)out, rows, inter);
+    LICV_LAUNCH_CHECK();
+    return LICV_OK;
+}

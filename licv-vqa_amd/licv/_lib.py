@@ -1,0 +1,100 @@
+"""ctypes binding of liblicv_hip.so (the C-ABI declared in include/licv_hip.h).
+
+This is the binding a maintainer of the reference would add.  The library is
+looked up in-tree only; a missing library is a hard error — there is no fallback path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get("LICV_HIP_LIB", _HERE / "liblicv_hip.so"))
+HEADER = _HERE.parents[1] / "include" / "licv_hip.h"
+
+LICV_BF16, LICV_F32 = 0, 1
+
+_lib = None
+
+
+class LicvError(RuntimeError):
+    pass
+
+
+class GemmEpilogue(C.Structure):
+    _fields_ = [("bias_bf16", C.c_void_p), ("row_gate", C.c_void_p), ("residual", C.c_void_p),
+                ("residual_dtype", C.c_int), ("ld_res", C.c_int64), ("act", C.c_int), ("swiglu", C.c_int),
+                ("use_scale", C.c_int), ("scale", C.c_float), ("out_dtype", C.c_int)]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [("q", C.c_void_p), ("q_bs", C.c_int64), ("q_rs", C.c_int64),
+                ("k", C.c_void_p), ("v", C.c_void_p), ("kv_bs", C.c_int64), ("kv_rs", C.c_int64),
+                ("o", C.c_void_p),
+                ("B", C.c_int64), ("Sq", C.c_int64), ("Sk", C.c_int64), ("n_heads", C.c_int64),
+                ("n_kv_heads", C.c_int64), ("head_dim", C.c_int64),
+                ("scale", C.c_float), ("mask_mode", C.c_int),
+                ("key_valid", C.c_void_p), ("img_mask", C.c_void_p), ("n_img", C.c_int64), ("img_len", C.c_int64)]
+
+
+def declared_symbols():
+    """Every function name declared in include/licv_hip.h."""
+    text = HEADER.read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(licv_[a-z0-9_]+)\s*\(", text)))
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise LicvError(
+                f"{LIB_PATH} not found: the L-ICV hot path has no CPU fallback. Build it with "
+                f"`python __graft_entry__.py` (hipcc --offload-arch=gfx950).")
+        _lib = C.CDLL(str(LIB_PATH))
+        _lib.licv_last_error.restype = C.c_char_p
+        _lib.licv_version.restype = C.c_int
+        _lib.licv_inject_bwd_partials.restype = C.c_int64
+        _lib.licv_inject_bwd_partials.argtypes = [C.c_int64]
+        P, I64, F, I = C.c_void_p, C.c_int64, C.c_float, C.c_int
+        sig = {
+            "licv_inject_renorm_fwd": [P, I, P, P, P, I64, I64, P, P, F, P],
+            "licv_inject_renorm_bwd": [P, I, P, P, P, P, P, I64, I64, P],
+            "licv_rmsnorm_fwd": [P, I, P, P, I64, I64, I64, I64, I64, F, I, P],
+            "licv_layernorm_fwd": [P, P, P, P, I64, I64, I64, I64, I64, I64, I64, F, P],
+            "licv_rotary_fwd": [P, P, P, P, I64, I64, I64, I64, I64, I, I64, P],
+            "licv_gemm_bf16": [P, I64, P, I64, P, I64, I64, I64, I64, C.POINTER(GemmEpilogue), P],
+            "licv_pack_gate_up": [P, P, P, I64, I64, P],
+            "licv_attn_fwd": [C.POINTER(AttnArgs), P],
+            "licv_embed_gather": [P, P, P, P, I64, I64, I64, I64, P],
+            "licv_im2col_patches": [P, P, I64, I64, I64, I64, I64, P],
+            "licv_vit_embed_ln": [P, P, P, P, P, P, I64, I64, I64, F, P],
+            "licv_tile_rows": [P, P, I64, I64, I64, P],
+            "licv_swiglu": [P, P, I64, I64, P],
+            "licv_kl_rows_fwd": [P, P, I, P, P, I64, I64, I64, I64, F, F, P, P],
+            "licv_adamw_step": [P, P, P, P, I64, I64, F, F, F, F, F, F, I64, F, P],
+        }
+        for name, args in sig.items():
+            fn = getattr(_lib, name)
+            fn.argtypes = args
+            fn.restype = C.c_int
+    return _lib
+
+
+def check_exports():
+    """The library exports every symbol the header declares (no compute calls)."""
+    l = lib()
+    missing = [s for s in declared_symbols() if not hasattr(l, s)]
+    if missing:
+        raise LicvError(f"liblicv_hip.so lacks symbols declared in licv_hip.h: {missing}")
+    if l.licv_version() < 1:
+        raise LicvError("bad ABI version")
+    return True
+
+
+def check(status: int):
+    if status != 0:
+        msg = lib().licv_last_error().decode()
+        raise LicvError(f"liblicv_hip error {status}: {msg}")

@@ -1,0 +1,244 @@
+"""Tensor-level wrappers over the C-ABI (torch only provides device memory and the stream)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import LICV_BF16, LICV_F32, AttnArgs, GemmEpilogue, check
+
+ACT = {None: 0, "none": 0, "gelu": 1, "gelu_tanh": 2, "gelu_pytorch_tanh": 2, "relu": 3}
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.bfloat16:
+        return LICV_BF16
+    if t.dtype == torch.float32:
+        return LICV_F32
+    raise TypeError(f"unsupported dtype {t.dtype} (bf16 or fp32 only)")
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream(t: torch.Tensor):
+    assert t.is_cuda, "liblicv_hip operates on device memory only (no CPU fallback)"
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _bf16c(t: torch.Tensor, name: str):
+    assert t.dtype == torch.bfloat16 and t.is_contiguous(), f"{name}: contiguous bf16 tensor expected"
+
+
+# ------------------------------------------------------------------------------------------ hook
+def inject_renorm(h: torch.Tensor, icv_row: torch.Tensor, alpha: Optional[torch.Tensor] = None,
+                  out: Optional[torch.Tensor] = None, norm_weight: Optional[torch.Tensor] = None,
+                  norm_eps: float = 1e-6):
+    """h: (..., H) bf16/fp32 contiguous; icv_row: (H,) fp32; alpha: 0-d/1-elem fp32 tensor or None.
+    Returns fp32 h' (and the bf16 RMSNorm of h' when norm_weight is given)."""
+    H = h.shape[-1]
+    assert h.is_contiguous() and icv_row.dtype == torch.float32 and icv_row.numel() == H and icv_row.is_contiguous()
+    rows = h.numel() // H
+    if out is None:
+        out = torch.empty(h.shape, dtype=torch.float32, device=h.device)
+    xn = None
+    if norm_weight is not None:
+        _bf16c(norm_weight, "norm_weight")
+        xn = torch.empty(h.shape, dtype=torch.bfloat16, device=h.device)
+    if alpha is not None:
+        assert alpha.dtype == torch.float32 and alpha.numel() == 1
+    check(_lib.lib().licv_inject_renorm_fwd(_p(h), _dt(h), _p(icv_row), _p(alpha), _p(out), rows, H,
+                                            _p(norm_weight), _p(xn), float(norm_eps), _stream(h)))
+    return (out, xn) if norm_weight is not None else out
+
+
+def inject_renorm_bwd(h: torch.Tensor, icv_row: torch.Tensor, alpha: Optional[torch.Tensor], grad_out: torch.Tensor,
+                      need_grad_h: bool = True):
+    """Returns (grad_h fp32 or None, grad_v (H,) fp32) with v = alpha*icv_row."""
+    H = h.shape[-1]
+    rows = h.numel() // H
+    assert grad_out.dtype == torch.float32 and grad_out.is_contiguous() and h.is_contiguous()
+    gh = torch.empty(h.shape, dtype=torch.float32, device=h.device) if need_grad_h else None
+    nparts = int(_lib.lib().licv_inject_bwd_partials(rows))
+    part = torch.empty((nparts, H), dtype=torch.float32, device=h.device)
+    check(_lib.lib().licv_inject_renorm_bwd(_p(h), _dt(h), _p(icv_row), _p(alpha), _p(grad_out), _p(gh), _p(part),
+                                            rows, H, _stream(h)))
+    return gh, part.sum(0)
+
+
+# ------------------------------------------------------------------------------------------ norms
+def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float, flavour: int = 0, out: Optional[torch.Tensor] = None,
+            inner: int = 1, ld_x: Optional[int] = None, ld_out: Optional[int] = None, rows: Optional[int] = None,
+            dim: Optional[int] = None):
+    """Dense case: x (..., dim) contiguous.  Strided per-head case: pass rows/dim/inner/ld explicitly."""
+    dim = x.shape[-1] if dim is None else dim
+    rows = x.numel() // dim if rows is None else rows
+    ld_x = dim * inner if ld_x is None else ld_x
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    ld_out = dim * inner if ld_out is None else ld_out
+    check(_lib.lib().licv_rmsnorm_fwd(_p(x), _dt(x), _p(w), _p(out), rows, dim, inner, ld_x, ld_out, float(eps), flavour, _stream(x)))
+    return out
+
+
+def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None,
+              inner: int = 1, ld_x: Optional[int] = None, ld_out: Optional[int] = None, rows: Optional[int] = None,
+              dim: Optional[int] = None, out_group: int = 0, out_group_extra: int = 0):
+    dim = x.shape[-1] if dim is None else dim
+    rows = x.numel() // dim if rows is None else rows
+    ld_x = dim * inner if ld_x is None else ld_x
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    ld_out = dim * inner if ld_out is None else ld_out
+    check(_lib.lib().licv_layernorm_fwd(_p(x), _p(w), _p(b), _p(out), rows, dim, inner, ld_x, ld_out, out_group,
+                                        out_group_extra, float(eps), _stream(x)))
+    return out
+
+
+def rotary_(buf: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, position_ids: torch.Tensor, rows: int, n_heads: int,
+            head_dim: int, ld: int, tensor_stride: int, n_tensors: int):
+    """In place on q (and k) inside a (rows, ld) bf16 buffer."""
+    assert position_ids.dtype == torch.int64 and position_ids.is_contiguous() and position_ids.numel() == rows
+    check(_lib.lib().licv_rotary_fwd(_p(buf), _p(cos), _p(sin), _p(position_ids), rows, n_heads, head_dim, ld,
+                                     tensor_stride, n_tensors, cos.shape[0], _stream(buf)))
+    return buf
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act=None, swiglu: bool = False,
+           row_gate: Optional[torch.Tensor] = None, scale: Optional[float] = None, residual: Optional[torch.Tensor] = None,
+           out: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None, M: Optional[int] = None,
+           lda: Optional[int] = None, ldc: Optional[int] = None, ld_res: Optional[int] = None):
+    """out = epilogue(a @ w.T).  a: (M, K) bf16 (row stride lda), w: (N, K) bf16 contiguous."""
+    assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and w.is_contiguous()
+    K = w.shape[1]
+    N = w.shape[0]
+    if M is None:
+        M = a.numel() // K
+    lda = K if lda is None else lda
+    n_out = N // 2 if swiglu else N
+    if out_dtype is None:
+        out_dtype = residual.dtype if residual is not None else torch.bfloat16
+    if out is None:
+        out = torch.empty((M, n_out), dtype=out_dtype, device=a.device)
+        ldc = n_out
+    elif ldc is None:
+        ldc = n_out
+    ep = GemmEpilogue()
+    ep.bias_bf16 = bias.data_ptr() if bias is not None else None
+    ep.row_gate = row_gate.data_ptr() if row_gate is not None else None
+    if row_gate is not None:
+        assert row_gate.dtype == torch.float32 and row_gate.numel() >= M
+    ep.residual = residual.data_ptr() if residual is not None else None
+    ep.residual_dtype = _dt(residual) if residual is not None else 0
+    ep.ld_res = (n_out if ld_res is None else ld_res)
+    ep.act = ACT[act]
+    ep.swiglu = 1 if swiglu else 0
+    ep.use_scale = 0 if scale is None else 1
+    ep.scale = 0.0 if scale is None else float(scale)
+    ep.out_dtype = _dt(out)
+    check(_lib.lib().licv_gemm_bf16(_p(a), lda, _p(w), K, _p(out), ldc, M, N, K, C.byref(ep), _stream(a)))
+    return out
+
+
+def pack_gate_up(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
+    _bf16c(gate, "gate"); _bf16c(up, "up")
+    inter, K = gate.shape
+    out = torch.empty((2 * inter, K), dtype=torch.bfloat16, device=gate.device)
+    check(_lib.lib().licv_pack_gate_up(_p(gate), _p(up), _p(out), inter, K, _stream(gate)))
+    return out
+
+
+# ------------------------------------------------------------------------------------------ attention
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, Sq: int, Sk: int, n_heads: int, n_kv_heads: int,
+              head_dim: int, q_bs: int, q_rs: int, kv_bs: int, kv_rs: int, scale: float, mask_mode: int = 0,
+              key_valid: Optional[torch.Tensor] = None, img_mask: Optional[torch.Tensor] = None, img_len: int = 0,
+              out: Optional[torch.Tensor] = None):
+    """q/k/v are (possibly offset views into) bf16 buffers; strides are in elements.  Returns (B, Sq, nh*hd) bf16."""
+    if out is None:
+        out = torch.empty((B, Sq, n_heads * head_dim), dtype=torch.bfloat16, device=q.device)
+    a = AttnArgs()
+    a.q, a.q_bs, a.q_rs = q.data_ptr(), q_bs, q_rs
+    a.k, a.v, a.kv_bs, a.kv_rs = k.data_ptr(), v.data_ptr(), kv_bs, kv_rs
+    a.o = out.data_ptr()
+    a.B, a.Sq, a.Sk, a.n_heads, a.n_kv_heads, a.head_dim = B, Sq, Sk, n_heads, n_kv_heads, head_dim
+    a.scale, a.mask_mode = float(scale), mask_mode
+    if key_valid is not None:
+        assert key_valid.dtype == torch.int32 and key_valid.is_contiguous()
+    a.key_valid = key_valid.data_ptr() if key_valid is not None else None
+    if img_mask is not None:
+        assert img_mask.dtype == torch.int32 and img_mask.is_contiguous()
+        a.img_mask, a.n_img, a.img_len = img_mask.data_ptr(), img_mask.shape[-1], img_len
+    else:
+        a.img_mask, a.n_img, a.img_len = None, 0, 0
+    check(_lib.lib().licv_attn_fwd(C.byref(a), _stream(q)))
+    return out
+
+
+# ------------------------------------------------------------------------------------------ gathers
+def embed_gather(ids: torch.Tensor, table: torch.Tensor, extra: Optional[torch.Tensor], vocab: int) -> torch.Tensor:
+    assert ids.dtype == torch.int64 and ids.is_contiguous()
+    dim = table.shape[1]
+    out = torch.empty((*ids.shape, dim), dtype=torch.bfloat16, device=table.device)
+    check(_lib.lib().licv_embed_gather(_p(ids), _p(table), _p(extra), _p(out), ids.numel(), dim, vocab,
+                                       0 if extra is None else extra.shape[0], _stream(table)))
+    return out
+
+
+def im2col_patches(pix: torch.Tensor, patch: int, ld_out: int) -> torch.Tensor:
+    """pix: (n_img, 3, H, W) bf16 contiguous -> (n_img*gh*gw, ld_out) bf16, zero padded past 3*patch^2."""
+    _bf16c(pix, "pixel_values")
+    n, c, H, W = pix.shape
+    assert c == 3
+    out = torch.empty((n * (H // patch) * (W // patch), ld_out), dtype=torch.bfloat16, device=pix.device)
+    check(_lib.lib().licv_im2col_patches(_p(pix), _p(out), n, H, W, patch, ld_out, _stream(pix)))
+    return out
+
+
+def vit_embed_ln(patches: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor, w: torch.Tensor, b: torch.Tensor,
+                 n_img: int, n_patch: int, eps: float) -> torch.Tensor:
+    dim = cls.numel()
+    out = torch.empty((n_img, n_patch + 1, dim), dtype=torch.bfloat16, device=patches.device)
+    check(_lib.lib().licv_vit_embed_ln(_p(patches), _p(cls), _p(pos), _p(w), _p(b), _p(out), n_img, n_patch, dim,
+                                       float(eps), _stream(patches)))
+    return out
+
+
+def tile_rows(src: torch.Tensor, rows: int) -> torch.Tensor:
+    _bf16c(src, "src")
+    period, dim = src.shape
+    out = torch.empty((rows, dim), dtype=torch.bfloat16, device=src.device)
+    check(_lib.lib().licv_tile_rows(_p(src), _p(out), rows, dim, period, _stream(src)))
+    return out
+
+
+def swiglu(gu: torch.Tensor) -> torch.Tensor:
+    _bf16c(gu, "gu")
+    rows, two_i = gu.shape
+    out = torch.empty((rows, two_i // 2), dtype=torch.bfloat16, device=gu.device)
+    check(_lib.lib().licv_swiglu(_p(gu), _p(out), rows, two_i // 2, _stream(gu)))
+    return out
+
+
+# ------------------------------------------------------------------------------------------ loss / optim
+def kl_rows(stu: torch.Tensor, tea: torch.Tensor, stu_rows: torch.Tensor, tea_rows: torch.Tensor, vocab: int,
+            temperature: float, eps: float) -> torch.Tensor:
+    """stu/tea: 2-D logits buffers (rows x ld); *_rows: int64 row indices (same count).  Returns fp32 per-row KL."""
+    assert stu.dtype == tea.dtype and stu.dim() == 2 and tea.dim() == 2
+    n = stu_rows.numel()
+    out = torch.empty((n,), dtype=torch.float32, device=stu.device)
+    check(_lib.lib().licv_kl_rows_fwd(_p(stu), _p(tea), _dt(stu), _p(stu_rows), _p(tea_rows), n, vocab, stu.stride(0),
+                                      tea.stride(0), float(temperature), float(eps), _p(out), _stream(stu)))
+    return out
+
+
+def adamw_step_(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, n_group0: int, lr0: float, lr1: float,
+                step: int, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=1e-3, grad_scale=1.0):
+    for t in (p, g, m, v):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+    check(_lib.lib().licv_adamw_step(_p(p), _p(g), _p(m), _p(v), p.numel(), n_group0, lr0, lr1, beta1, beta2, eps,
+                                     weight_decay, step, grad_scale, _stream(p)))
+    return p

@@ -1,0 +1,395 @@
+"""Op-level parity: every HIP kernel (called through the C-ABI) against the CPU oracle on seeded inputs.
+
+Tolerances (written here, per the parity bar): fp32 kernels 1e-5 relative to the row scale; bf16-output
+kernels must agree with the oracle's bf16 result to within ONE bf16 ulp (2^-8 relative) on every element
+and bit-exactly on >= 99 % of them (accumulation order inside a reduction may flip a rounding)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import icv_ref as O
+from oracle import idefics_ref as R
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def ops():
+    from licv import ops as _ops
+    return _ops
+
+
+def g(seed=0):
+    return torch.Generator().manual_seed(seed)
+
+
+def close_bf16(got, ref, ulps=1.0, exact_frac=0.99, scale_floor=None):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    floor = ref.abs().max() * 2 ** -8 if scale_floor is None else scale_floor
+    tol = ulps * (ref.abs() * 2 ** -7 + floor * 2 ** -1) * 1.001
+    bad = (got - ref).abs() > tol
+    assert not bad.any(), f"{int(bad.sum())} elements beyond {ulps} bf16 ulp; max diff {(got - ref).abs().max()}"
+    if exact_frac:
+        frac = float((got == ref).float().mean())
+        assert frac >= exact_frac, f"only {frac:.4f} of elements bit-exact"
+
+
+# ------------------------------------------------------------------------------------------- hook
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 5, 64), (3, 7, 4096), (1, 9, 96), (2, 3, 8192)])
+def test_inject_renorm_fwd(dt, shape):
+    h = (torch.randn(shape, generator=g(1)) * 2).to(dt)
+    v = torch.randn(shape[-1], generator=g(2)) * 0.3
+    ref = O.inject_renorm(h, v)
+    out = ops().inject_renorm(h.to(DEV), v.to(DEV))
+    assert out.dtype == torch.float32
+    assert (out.cpu() - ref).abs().max() <= 1e-5 * ref.abs().max()
+    alpha = torch.tensor([0.37])
+    ref2 = O.inject_renorm(h, alpha * v)
+    out2 = ops().inject_renorm(h.to(DEV), v.to(DEV), alpha=alpha.to(DEV))
+    assert (out2.cpu() - ref2).abs().max() <= 1e-5 * ref2.abs().max()
+
+
+def test_inject_renorm_norm_is_preserved_at_headline_size():
+    # size-independent property at the full (B=8, S=800, H=4096) shape: ||h'|| == ||h|| per token
+    h = torch.randn(8 * 800, 4096, device=DEV)
+    v = torch.randn(4096, device=DEV) * 0.05
+    out = ops().inject_renorm(h, v)
+    rel = (out.norm(dim=-1) - h.norm(dim=-1)).abs() / h.norm(dim=-1)
+    assert rel.max() < 1e-6
+    # idempotence-like property: injecting v=0 returns h
+    out0 = ops().inject_renorm(h, torch.zeros(4096, device=DEV))
+    assert (out0 - h).abs().max() <= 1e-6 * h.abs().max()
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_inject_renorm_fused_rmsnorm(dt):
+    h = (torch.randn(4, 11, 256, generator=g(3))).to(dt)
+    v = torch.randn(256, generator=g(4)) * 0.2
+    w = (1 + 0.1 * torch.randn(256, generator=g(5))).to(torch.bfloat16)
+    ref_h = O.inject_renorm(h, v)
+    ref_x = R.rms_norm(ref_h, w, 1e-6)
+    out, xn = ops().inject_renorm(h.to(DEV), v.to(DEV), norm_weight=w.to(DEV), norm_eps=1e-6)
+    assert (out.cpu() - ref_h).abs().max() <= 1e-5 * ref_h.abs().max()
+    close_bf16(xn, ref_x)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 5, 64), (2, 300, 4096)])
+def test_inject_renorm_bwd(dt, shape):
+    h = (torch.randn(shape, generator=g(6)) * 2).to(dt)
+    v = torch.randn(shape[-1], generator=g(7)) * 0.3
+    go = torch.randn(shape, generator=g(8))
+    gh_ref, gv_ref = O.inject_renorm_bwd(h.float(), v, go)
+    gh, gv = ops().inject_renorm_bwd(h.to(DEV), v.to(DEV), None, go.to(DEV))
+    assert (gh.cpu().double() - gh_ref).abs().max() <= 2e-5 * gh_ref.abs().max()
+    assert (gv.cpu().double() - gv_ref).abs().max() <= 2e-5 * gv_ref.abs().max() * math.sqrt(h.numel() / shape[-1])
+
+
+# ------------------------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dim", [64, 128, 4096, 1280])
+def test_rmsnorm_dense(dt, dim):
+    x = (torch.randn(37, dim, generator=g(9)) * 3).to(dt)
+    w = (1 + 0.1 * torch.randn(dim, generator=g(10))).to(torch.bfloat16)
+    ref = R.rms_norm(x, w, 1e-6)
+    close_bf16(ops().rmsnorm(x.to(DEV), w.to(DEV), 1e-6), ref)
+
+
+def test_rmsnorm_per_head_strided_in_place():
+    # q/k RMSNorm over head_dim inside a fused (tokens, 2*H) k|v buffer (hf:idefics/modeling_idefics.py:598-600)
+    T_, nh, hd = 19, 4, 128
+    buf = torch.randn(T_, 2 * nh * hd, generator=g(11)).to(torch.bfloat16)
+    w = (1 + 0.1 * torch.randn(hd, generator=g(12))).to(torch.bfloat16)
+    ref = buf.clone()
+    ref[:, : nh * hd] = R.rms_norm(buf[:, : nh * hd].reshape(T_, nh, hd), w, 1e-6).reshape(T_, nh * hd)
+    d = buf.to(DEV)
+    ops().rmsnorm(d, w.to(DEV), 1e-6, out=d, inner=nh, ld_x=2 * nh * hd, ld_out=2 * nh * hd, rows=T_ * nh, dim=hd)
+    close_bf16(d, ref)
+
+
+@pytest.mark.parametrize("dim", [32, 96, 1280])
+def test_layernorm(dim):
+    x = (torch.randn(29, dim, generator=g(13)) * 2 + 0.5).to(torch.bfloat16)
+    w = (1 + 0.1 * torch.randn(dim, generator=g(14))).to(torch.bfloat16)
+    b = (0.1 * torch.randn(dim, generator=g(15))).to(torch.bfloat16)
+    ref = F.layer_norm(x, (dim,), w, b, 1e-5)
+    close_bf16(ops().layernorm(x.to(DEV), w.to(DEV), b.to(DEV), 1e-5), ref, exact_frac=0.98)
+
+
+def test_layernorm_grouped_output_builds_perceiver_concat():
+    n_img, T_, L, dim = 3, 5, 4, 64
+    ctx = torch.randn(n_img * T_, dim, generator=g(16)).to(torch.bfloat16)
+    lat = torch.randn(n_img * L, dim, generator=g(17)).to(torch.bfloat16)
+    w = torch.ones(dim).to(torch.bfloat16); b = torch.zeros(dim).to(torch.bfloat16)
+    ref = torch.cat([F.layer_norm(ctx, (dim,), w, b).view(n_img, T_, dim), F.layer_norm(lat, (dim,), w, b).view(n_img, L, dim)], 1)
+    out = torch.zeros(n_img, T_ + L, dim, dtype=torch.bfloat16, device=DEV)
+    o = ops()
+    o.layernorm(ctx.to(DEV), w.to(DEV), b.to(DEV), 1e-5, out=out, out_group=T_, out_group_extra=L * dim)
+    o.layernorm(lat.to(DEV), w.to(DEV), b.to(DEV), 1e-5, out=out.view(-1)[T_ * dim:], out_group=L, out_group_extra=T_ * dim)
+    close_bf16(out, ref, exact_frac=0.98)
+
+
+def test_rotary_matches_rotate_half_form():
+    B, S, nh, hd = 2, 9, 4, 128
+    H = nh * hd
+    qkv = torch.randn(B * S, 3 * H, generator=g(18)).to(torch.bfloat16)
+    cos, sin = R.rotary_tables(hd, 64, 10000.0, torch.bfloat16)
+    pos = torch.randint(0, 64, (B, S), generator=g(19))
+    q = qkv[:, :H].view(B, S, nh, hd).transpose(1, 2)
+    k = qkv[:, H:2 * H].view(B, S, nh, hd).transpose(1, 2)
+    qr, kr = R.apply_rotary(q, k, cos, sin, pos)
+    ref = qkv.clone()
+    ref[:, :H] = qr.transpose(1, 2).reshape(B * S, H)
+    ref[:, H:2 * H] = kr.transpose(1, 2).reshape(B * S, H)
+    d = qkv.to(DEV)
+    ops().rotary_(d, cos.to(DEV), sin.to(DEV), pos.reshape(-1).to(DEV), B * S, nh, hd, 3 * H, H, 2)
+    assert torch.equal(d.cpu(), ref)
+
+
+# ------------------------------------------------------------------------------------------- GEMM
+def _ref_linear(a, w, bias=None):
+    y = a.float() @ w.float().t()
+    if bias is not None:
+        y = y + bias.float()
+    return y.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (257, 384, 1280), (100, 98, 40), (640, 4096, 4096), (64, 32002, 256), (5, 16, 8)])
+def test_gemm_plain_and_bias(M, N, K):
+    a = torch.randn(M, K, generator=g(20)).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g(21)) * 0.05).to(torch.bfloat16)
+    bias = (torch.randn(N, generator=g(22)) * 0.1).to(torch.bfloat16)
+    close_bf16(ops().linear(a.to(DEV), w.to(DEV)), _ref_linear(a, w))
+    close_bf16(ops().linear(a.to(DEV), w.to(DEV), bias=bias.to(DEV)), _ref_linear(a, w, bias))
+
+
+def test_gemm_identity_weight_catches_transposed_output():
+    # A = I with an ASYMMETRIC W: a row<->col swap in the C write cannot hide
+    n = 128
+    a = torch.eye(n).to(torch.bfloat16)
+    w = (torch.arange(n * n).reshape(n, n) % 251).float().to(torch.bfloat16)
+    out = ops().linear(a.to(DEV), w.to(DEV))
+    assert torch.equal(out.cpu(), w.t().contiguous())
+
+
+@pytest.mark.parametrize("act", ["gelu", "gelu_tanh", "relu"])
+def test_gemm_activations(act):
+    a = torch.randn(70, 160, generator=g(23)).to(torch.bfloat16)
+    w = (torch.randn(224, 160, generator=g(24)) * 0.1).to(torch.bfloat16)
+    b = (torch.randn(224, generator=g(25)) * 0.1).to(torch.bfloat16)
+    y = _ref_linear(a, w, b)
+    ref = {"gelu": F.gelu(y), "gelu_tanh": F.gelu(y, approximate="tanh"), "relu": F.relu(y)}[act]
+    close_bf16(ops().linear(a.to(DEV), w.to(DEV), bias=b.to(DEV), act=act), ref, exact_frac=0.98)
+
+
+@pytest.mark.parametrize("res_dt", [torch.float32, torch.bfloat16])
+def test_gemm_residual_gate_scale(res_dt):
+    M, N, K = 90, 256, 352
+    a = torch.randn(M, K, generator=g(26)).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g(27)) * 0.05).to(torch.bfloat16)
+    res = torch.randn(M, N, generator=g(28)).to(res_dt)
+    gate = (torch.rand(M, generator=g(29)) > 0.3).float()
+    scale = float(torch.tanh(torch.tensor(0.7).to(torch.bfloat16)).float())
+    y = _ref_linear(a, w)
+    y = y.masked_fill((gate == 0)[:, None], 0.0)
+    ref = res + torch.tensor(scale).to(torch.bfloat16) * y              # torch promotion: fp32 or bf16 stream
+    out = ops().linear(a.to(DEV), w.to(DEV), row_gate=gate.to(DEV), scale=scale, residual=res.to(DEV))
+    assert out.dtype == res_dt
+    if res_dt == torch.float32:
+        assert (out.cpu() - ref).abs().max() <= 2 ** -7 * y.float().abs().max()
+    else:
+        close_bf16(out, ref, ulps=2, exact_frac=0.97)
+
+
+def test_gemm_swiglu_fused_matches_unfused_and_oracle():
+    M, I, K = 77, 352, 256
+    a = torch.randn(M, K, generator=g(30)).to(torch.bfloat16)
+    wg = (torch.randn(I, K, generator=g(31)) * 0.08).to(torch.bfloat16)
+    wu = (torch.randn(I, K, generator=g(32)) * 0.08).to(torch.bfloat16)
+    ref = F.silu(_ref_linear(a, wg)) * _ref_linear(a, wu)
+    o = ops()
+    packed = o.pack_gate_up(wg.to(DEV), wu.to(DEV))
+    close_bf16(o.linear(a.to(DEV), packed, swiglu=True), ref, exact_frac=0.98)
+    gu = o.linear(a.to(DEV), torch.cat([wg, wu]).to(DEV))
+    close_bf16(o.swiglu(gu), ref, exact_frac=0.98)
+
+
+def test_gemm_linearity_at_headline_shape():
+    # size-independent property at the full decoder shape (M = 8*800): f(a1 + a2) == f(a1) + f(a2) in fp32 out
+    M, N, K = 6400, 4096, 4096
+    a1 = torch.randn(M, K, device=DEV).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=DEV) * 0.02).to(torch.bfloat16)
+    o = ops()
+    y1 = o.linear(a1, w, out_dtype=torch.float32)
+    y2 = o.linear((a1.float() * 2).to(torch.bfloat16), w, out_dtype=torch.float32)      # exact doubling in bf16
+    assert torch.equal(y2, (y1.to(torch.bfloat16).float() * 2)) or (y2 - 2 * y1).abs().max() <= 2 ** -6 * y1.abs().max()
+    rows = torch.randint(0, M, (64,), device=DEV)
+    ref = (a1[rows].float() @ w.float().t())
+    assert (y1[rows] - ref.to(torch.bfloat16).float()).abs().max() <= 2 ** -7 * ref.abs().max()
+
+
+# ------------------------------------------------------------------------------------------- attention
+def _ref_attn(q, k, v, mask, scale):
+    w = (q.float() @ k.float().transpose(-1, -2)) * scale
+    if mask is not None:
+        w = w.masked_fill(~mask, float("-inf"))
+    p = torch.softmax(w, -1)
+    p = torch.nan_to_num(p, nan=0.0)
+    return (p @ v.float())
+
+
+@pytest.mark.parametrize("hd", [8, 16, 64, 80, 96, 128])
+@pytest.mark.parametrize("mode", ["none", "causal", "keypad"])
+def test_attention_self(hd, mode):
+    B, S, nh = 2, 150, 3
+    H = nh * hd
+    qkv = (torch.randn(B, S, 3 * H, generator=g(40))).to(torch.bfloat16)
+    q = qkv[..., :H].view(B, S, nh, hd).transpose(1, 2)
+    k = qkv[..., H:2 * H].view(B, S, nh, hd).transpose(1, 2)
+    v = qkv[..., 2 * H:].view(B, S, nh, hd).transpose(1, 2)
+    valid = torch.ones(B, S, dtype=torch.int32)
+    valid[1, 120:] = 0
+    mask = None
+    if mode == "causal":
+        mask = torch.tril(torch.ones(S, S, dtype=torch.bool))[None, None] & valid.bool()[:, None, None, :]
+    elif mode == "keypad":
+        mask = valid.bool()[:, None, None, :].expand(B, 1, S, S)
+    ref = _ref_attn(q, k, v, mask, hd ** -0.5).transpose(1, 2).reshape(B, S, H)
+    d = qkv.to(DEV)
+    out = ops().attention(d, d.view(-1)[H:], d.view(-1)[2 * H:], B, S, S, nh, nh, hd, S * 3 * H, 3 * H, S * 3 * H, 3 * H,
+                          hd ** -0.5, {"none": 0, "causal": 1, "keypad": 2}[mode], key_valid=valid.to(DEV))
+    err = (out.float().cpu() - ref).abs().max()
+    assert err <= 2e-2 * ref.abs().max(), err
+
+
+def test_attention_cross_image_mask_and_gqa_decode():
+    # cross-attention with the per-token image mask (rows seeing no image -> zeros), general img_len
+    B, Sq, nh, hd, n_img, img_len = 2, 70, 4, 128, 3, 8
+    Sk = n_img * img_len
+    q = torch.randn(B, Sq, nh * hd, generator=g(41)).to(torch.bfloat16)
+    kv = torch.randn(B, Sk, 2 * nh * hd, generator=g(42)).to(torch.bfloat16)
+    im = (torch.rand(B, Sq, n_img, generator=g(43)) > 0.6).int()
+    im[:, :5] = 0
+    mask = im.bool()[..., None].expand(-1, -1, -1, img_len).reshape(B, 1, Sq, Sk)
+    qh = q.view(B, Sq, nh, hd).transpose(1, 2)
+    kh = kv[..., : nh * hd].view(B, Sk, nh, hd).transpose(1, 2)
+    vh = kv[..., nh * hd:].view(B, Sk, nh, hd).transpose(1, 2)
+    ref = _ref_attn(qh, kh, vh, mask, hd ** -0.5).transpose(1, 2).reshape(B, Sq, nh * hd)
+    dq, dkv = q.to(DEV), kv.to(DEV)
+    out = ops().attention(dq, dkv, dkv.view(-1)[nh * hd:], B, Sq, Sk, nh, nh, hd, Sq * nh * hd, nh * hd, Sk * 2 * nh * hd,
+                          2 * nh * hd, hd ** -0.5, 3, img_mask=im.to(DEV), img_len=img_len)
+    assert (out.float().cpu() - ref).abs().max() <= 2e-2 * ref.abs().max()
+    assert out[:, :5].abs().max() == 0
+    # tile-uniform image mask path (img_len % 64 == 0) + GQA + causal decode offset (Sq < Sk)
+    B, Sq, Sk, nh, nkv, hd = 2, 3, 200, 8, 2, 64
+    q = torch.randn(B, Sq, nh * hd, generator=g(44)).to(torch.bfloat16)
+    k = torch.randn(B, Sk, nkv * hd, generator=g(45)).to(torch.bfloat16)
+    v = torch.randn(B, Sk, nkv * hd, generator=g(46)).to(torch.bfloat16)
+    qh = q.view(B, Sq, nh, hd).transpose(1, 2)
+    kh = k.view(B, Sk, nkv, hd).transpose(1, 2).repeat_interleave(nh // nkv, 1)
+    vh = v.view(B, Sk, nkv, hd).transpose(1, 2).repeat_interleave(nh // nkv, 1)
+    mask = (torch.arange(Sk)[None, :] <= (torch.arange(Sq)[:, None] + Sk - Sq))[None, None]
+    ref = _ref_attn(qh, kh, vh, mask, 0.125).transpose(1, 2).reshape(B, Sq, nh * hd)
+    out = ops().attention(q.to(DEV), k.to(DEV), v.to(DEV), B, Sq, Sk, nh, nkv, hd, Sq * nh * hd, nh * hd, Sk * nkv * hd,
+                          nkv * hd, 0.125, 1)
+    assert (out.float().cpu() - ref).abs().max() <= 2e-2 * ref.abs().max()
+    B, Sq, n_img, img_len, nh, hd = 1, 9, 2, 64, 2, 128
+    Sk = n_img * img_len
+    q = torch.randn(B, Sq, nh * hd, generator=g(47)).to(torch.bfloat16)
+    kv = torch.randn(B, Sk, 2 * nh * hd, generator=g(48)).to(torch.bfloat16)
+    im = torch.tensor([[1, 0], [0, 1], [1, 1], [0, 0], [1, 0], [0, 1], [1, 1], [0, 0], [1, 0]]).int()[None]
+    mask = im.bool()[..., None].expand(-1, -1, -1, img_len).reshape(B, 1, Sq, Sk)
+    ref = _ref_attn(q.view(B, Sq, nh, hd).transpose(1, 2), kv[..., :nh * hd].view(B, Sk, nh, hd).transpose(1, 2),
+                    kv[..., nh * hd:].view(B, Sk, nh, hd).transpose(1, 2), mask, hd ** -0.5).transpose(1, 2).reshape(B, Sq, nh * hd)
+    dkv = kv.to(DEV)
+    out = ops().attention(q.to(DEV), dkv, dkv.view(-1)[nh * hd:], B, Sq, Sk, nh, nh, hd, Sq * nh * hd, nh * hd,
+                          Sk * 2 * nh * hd, 2 * nh * hd, hd ** -0.5, 3, img_mask=im.to(DEV), img_len=img_len)
+    assert (out.float().cpu() - ref).abs().max() <= 2e-2 * ref.abs().max()
+
+
+def test_attention_softmax_rescale_branch_forced():
+    # a key far above the rest in a LATE tile forces the online-softmax rescale (guide rule 26)
+    B, S, nh, hd = 1, 300, 1, 128
+    q = torch.randn(B, S, hd, generator=g(49)).to(torch.bfloat16)
+    k = torch.randn(B, S, hd, generator=g(50)).to(torch.bfloat16)
+    v = torch.randn(B, S, hd, generator=g(51)).to(torch.bfloat16)
+    k[0, 250] = (q[0, 10].float() * 3).to(torch.bfloat16)
+    ref = _ref_attn(q[:, None], k[:, None], v[:, None], None, hd ** -0.5)[:, 0]
+    out = ops().attention(q.to(DEV), k.to(DEV), v.to(DEV), B, S, S, 1, 1, hd, S * hd, hd, S * hd, hd, hd ** -0.5, 0)
+    assert (out.float().cpu() - ref).abs().max() <= 2e-2 * ref.abs().max()
+
+
+# ------------------------------------------------------------------------------------------- gathers
+def test_embed_gather_decoupled():
+    table = torch.randn(50, 64, generator=g(60)).to(torch.bfloat16)
+    extra = torch.randn(2, 64, generator=g(61)).to(torch.bfloat16)
+    ids = torch.randint(0, 52, (3, 11), generator=g(62))
+    sd = {"model.embed_tokens.weight": table, "model.embed_tokens.additional_embedding.weight": extra}
+    ref = R.decoupled_embedding(ids, sd, 50)
+    assert torch.equal(ops().embed_gather(ids.to(DEV), table.to(DEV), extra.to(DEV), 50).cpu(), ref)
+    assert torch.equal(ops().embed_gather(ids.clamp(max=49).to(DEV), table.to(DEV), None, 50).cpu(), F.embedding(ids.clamp(max=49), table))
+
+
+def test_im2col_equals_conv_and_vit_embed():
+    n, P, Hh = 3, 14, 42
+    dim = 64
+    pix = torch.randn(n, 3, Hh, Hh, generator=g(63)).to(torch.bfloat16)
+    wconv = (torch.randn(dim, 3, P, P, generator=g(64)) * 0.05).to(torch.bfloat16)
+    kdim = 3 * P * P
+    ld = ((kdim + 63) // 64) * 64
+    cols = ops().im2col_patches(pix.to(DEV), P, ld)
+    assert cols.shape == (n * 9, ld) and cols[:, kdim:].abs().max() == 0
+    wp = torch.zeros(dim, ld, dtype=torch.bfloat16)
+    wp[:, :kdim] = wconv.flatten(1)
+    patches = ops().linear(cols, wp.to(DEV))
+    ref = F.conv2d(pix.float(), wconv.float(), stride=P).flatten(2).transpose(1, 2).to(torch.bfloat16)
+    close_bf16(patches.view(n, 9, dim), ref)
+    cls = torch.randn(dim, generator=g(65)).to(torch.bfloat16)
+    pos = (torch.randn(10, dim, generator=g(66)) * 0.1).to(torch.bfloat16)
+    w = (1 + 0.1 * torch.randn(dim, generator=g(67))).to(torch.bfloat16)
+    b = (0.1 * torch.randn(dim, generator=g(68))).to(torch.bfloat16)
+    x = torch.cat([cls.expand(n, 1, -1), patches.cpu().view(n, 9, dim)], 1) + pos[None]
+    refln = F.layer_norm(x, (dim,), w, b, 1e-5)
+    out = ops().vit_embed_ln(patches, cls.to(DEV), pos.to(DEV), w.to(DEV), b.to(DEV), n, 9, 1e-5)
+    close_bf16(out, refln, exact_frac=0.98)
+
+
+def test_tile_rows():
+    src = torch.randn(4, 32, generator=g(69)).to(torch.bfloat16)
+    assert torch.equal(ops().tile_rows(src.to(DEV), 12).cpu(), src.repeat(3, 1))
+
+
+# ------------------------------------------------------------------------------------------- loss / optim
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("temp", [1.0, 2.0])
+def test_kl_rows(dt, temp):
+    V = 1000
+    stu = (torch.randn(3, 7, V, generator=g(70)) * 2).to(dt)
+    tea = (torch.randn(2, 9, V, generator=g(71)) * 2).to(dt)
+    sr = torch.tensor([1, 5, 20, 13])
+    tr = torch.tensor([0, 8, 17, 3])
+    ref_rows = []
+    for a, b in zip(sr, tr):
+        ref_rows.append(O.kl_divergence(stu.view(-1, V)[a:a + 1], tea.view(-1, V)[b:b + 1], temp) / temp ** 2)
+    ref = torch.stack(ref_rows).float()
+    out = ops().kl_rows(stu.view(-1, V).to(DEV), tea.view(-1, V).to(DEV), sr.to(DEV), tr.to(DEV), V, temp, 1e-6).cpu()
+    tol = 1e-5 if dt == torch.float32 else 2 ** -6
+    assert ((out - ref).abs() <= tol * ref.abs().clamp(min=1e-3)).all(), (out, ref)
+
+
+def test_adamw_matches_oracle():
+    n0, n1 = 32, 4096
+    p = torch.randn(n0 + n1, generator=g(72)); gr = torch.randn(n0 + n1, generator=g(73))
+    m = torch.zeros_like(p); v = torch.zeros_like(p)
+    dp, dm, dv = p.to(DEV), m.to(DEV), v.to(DEV)
+    for step in (1, 2, 3):
+        pa, ma, va = O.adamw_step(p[:n0], gr[:n0], m[:n0], v[:n0], step, 1e-2)
+        pi, mi, vi = O.adamw_step(p[n0:], gr[n0:], m[n0:], v[n0:], step, 1e-4)
+        p, m, v = torch.cat([pa, pi]), torch.cat([ma, mi]), torch.cat([va, vi])
+        ops().adamw_step_(dp, gr.to(DEV), dm, dv, n0, 1e-2, 1e-4, step)
+        assert (dp.cpu() - p).abs().max() <= 1e-6
