@@ -62,8 +62,10 @@ void inject_renorm_fwd_k(const void* __restrict__ h, const float* __restrict__ i
     }
     ss = wave_sum(ss);
     hh = wave_sum(hh);
-    // shifted / ||shifted|| * ||h||  in that order, as the reference writes it
-    const float ns = sqrtf(ss), nh = sqrtf(hh);
+    // shifted / ||shifted|| * ||h||  in that order, as the reference writes it.  torch's .norm() returns
+    // the input dtype: for a bf16 stream ||h|| is ROUNDED to bf16 (||h+v|| is fp32: the sum was promoted).
+    const float ns = sqrtf(ss);
+    const float nh = (DT == LICV_BF16) ? rbf(sqrtf(hh)) : sqrtf(hh);
     float q2 = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -128,7 +130,8 @@ void inject_renorm_bwd_k(const void* __restrict__ h, const float* __restrict__ i
             }
         }
         ss = wave_sum(ss); hh = wave_sum(hh); gs = wave_sum(gs);
-        const float ns = sqrtf(ss), nh = sqrtf(hh);
+        const float ns = sqrtf(ss);
+        const float nh = (DT == LICV_BF16) ? rbf(sqrtf(hh)) : sqrtf(hh);
         const float r = nh / ns;                 // d out / d s = r * (I - u u^T),  u = s/ns
         const float gu = gs / ns;                // <g, u>
         const float kh = gu / nh;                // d out / d h (through ||h||) = u h^T / nh

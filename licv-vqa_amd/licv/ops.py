@@ -122,9 +122,11 @@ def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     n_out = N // 2 if swiglu else N
     if out_dtype is None:
         out_dtype = residual.dtype if residual is not None else torch.bfloat16
+    ret = None
     if out is None:
-        out = torch.empty((M, n_out), dtype=out_dtype, device=a.device)
-        ldc = n_out
+        ldc = (n_out + 7) // 8 * 8               # rows stay 16-byte aligned (e.g. the 32002-wide LM head)
+        out = torch.empty((M, ldc), dtype=out_dtype, device=a.device)
+        ret = out if ldc == n_out else out[:, :n_out]
     elif ldc is None:
         ldc = n_out
     ep = GemmEpilogue()
@@ -141,7 +143,7 @@ def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     ep.scale = 0.0 if scale is None else float(scale)
     ep.out_dtype = _dt(out)
     check(_lib.lib().licv_gemm_bf16(_p(a), lda, _p(w), K, _p(out), ldc, M, N, K, C.byref(ep), _stream(a)))
-    return out
+    return out if ret is None else ret
 
 
 def pack_gate_up(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:

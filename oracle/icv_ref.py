@@ -68,7 +68,8 @@ def inject_renorm_bwd(h: torch.Tensor, shift: torch.Tensor, grad_out: torch.Tens
     h64, v64, g64 = h.double(), shift.reshape(1, 1, -1).double(), grad_out.double()
     s = h64 + v64
     ns = s.norm(dim=-1, keepdim=True)
-    nh = h64.norm(dim=-1, keepdim=True)
+    # torch's .norm() returns the input dtype: for a bf16 stream the VALUE of ||h|| is bf16-rounded
+    nh = h.norm(dim=-1, keepdim=True).double() if h.dtype == torch.bfloat16 else h64.norm(dim=-1, keepdim=True)
     u = s / ns
     gu = (g64 * u).sum(-1, keepdim=True)
     gs = (nh / ns) * (g64 - u * gu)                 # through s/||s||

@@ -84,7 +84,7 @@ def test_inject_renorm_bwd(dt, shape):
     h = (torch.randn(shape, generator=g(6)) * 2).to(dt)
     v = torch.randn(shape[-1], generator=g(7)) * 0.3
     go = torch.randn(shape, generator=g(8))
-    gh_ref, gv_ref = O.inject_renorm_bwd(h.float(), v, go)
+    gh_ref, gv_ref = O.inject_renorm_bwd(h, v, go)
     gh, gv = ops().inject_renorm_bwd(h.to(DEV), v.to(DEV), None, go.to(DEV))
     assert (gh.cpu().double() - gh_ref).abs().max() <= 2e-5 * gh_ref.abs().max()
     assert (gv.cpu().double() - gv_ref).abs().max() <= 2e-5 * gv_ref.abs().max() * math.sqrt(h.numel() / shape[-1])
