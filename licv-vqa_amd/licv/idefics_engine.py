@@ -1,0 +1,330 @@
+"""Native Idefics forward for MI355X with the ICV hook fused into the layer loop.
+
+Replaces, for the hot path, ``IdeficsForVisionText2Text.forward`` (hf:idefics/modeling_idefics.py:934-1084,
+:1165-1182) + the baukit hook mechanism (ref:icv_src/icv_model/icv_intervention.py:88-98).  Every
+arithmetic step is a HIP kernel reached through the C-ABI (``licv.ops``); torch supplies device memory,
+the stream and a handful of integer mask preparations (position ids, key-valid mask, gate).
+
+Data layout in HBM (all row-major, tokens flattened to M = B*S rows):
+  * residual stream ``h``: (M, H); bf16 until the first hooked layer, fp32 afterwards (the fp32 ICV
+    promotes it in the reference) — every later residual add happens in fp32;
+  * GEMM inputs/outputs bf16; fused projections: QKV (3H x H), cross-attn KV (2H x E_v), gate|up
+    interleaved in 16-row blocks for the SwiGLU epilogue, LM head + additional_fc concatenated;
+  * attention reads Q/K/V straight out of the fused projection buffers through strides (no transposes);
+  * vision tokens (B*N_img*257, 1280) -> perceiver latents (B, N_img*64, 1280) -> cross-attn K/V.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import ops
+from .config import IdeficsArch
+
+
+def _bf(t: torch.Tensor, dev) -> torch.Tensor:
+    return t.detach().to(device=dev, dtype=torch.bfloat16).contiguous()
+
+
+def _pad_cols(w: torch.Tensor, to: int) -> torch.Tensor:
+    if w.shape[1] == to:
+        return w.contiguous()
+    out = torch.zeros((w.shape[0], to), dtype=w.dtype, device=w.device)
+    out[:, : w.shape[1]] = w
+    return out
+
+
+@dataclass
+class _VitLayer:
+    ln1_w: torch.Tensor; ln1_b: torch.Tensor; qkv_w: torch.Tensor; qkv_b: torch.Tensor
+    out_w: torch.Tensor; out_b: torch.Tensor; ln2_w: torch.Tensor; ln2_b: torch.Tensor
+    fc1_w: torch.Tensor; fc1_b: torch.Tensor; fc2_w: torch.Tensor; fc2_b: torch.Tensor
+
+
+@dataclass
+class _PercBlock:
+    ctx_w: torch.Tensor; ctx_b: torch.Tensor; lat_w: torch.Tensor; lat_b: torch.Tensor
+    q_w: torch.Tensor; kv_w: torch.Tensor; out_w: torch.Tensor
+    qn_w: Optional[torch.Tensor]; qn_b: Optional[torch.Tensor]; kn_w: Optional[torch.Tensor]; kn_b: Optional[torch.Tensor]
+    ln_w: torch.Tensor; ln_b: torch.Tensor; fc_w: torch.Tensor; cproj_w: torch.Tensor
+
+
+@dataclass
+class _DecLayer:
+    in_ln: torch.Tensor; qkv_w: torch.Tensor; o_w: torch.Tensor; post_ln: torch.Tensor
+    gu_w: torch.Tensor; down_w: torch.Tensor
+
+
+@dataclass
+class _XLayer:
+    in_ln: torch.Tensor; q_w: torch.Tensor; kv_w: torch.Tensor; o_w: torch.Tensor
+    qn_w: Optional[torch.Tensor]; kn_w: Optional[torch.Tensor]
+    post_ln: torch.Tensor; gu_w: torch.Tensor; down_w: torch.Tensor
+    gate_attn: float; gate_dense: float
+
+
+class IdeficsWeights:
+    """Engine-layout weights built from an HF-named state dict (bf16)."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], arch: IdeficsArch, device="cuda"):
+        a, dev = arch, torch.device(device)
+        self.arch, self.device = arch, dev
+        g = lambda k: _bf(sd[k], dev)
+        self.embed = g("model.embed_tokens.weight")
+        self.embed_extra = g("model.embed_tokens.additional_embedding.weight") if a.additional_vocab_size else None
+        vp = "model.vision_model."
+        kdim = 3 * a.v_patch * a.v_patch
+        self.patch_ld = (kdim + 63) // 64 * 64
+        self.patch_w = _pad_cols(g(vp + "embeddings.patch_embedding.weight").flatten(1), self.patch_ld)
+        self.cls = g(vp + "embeddings.class_embedding")
+        self.pos = g(vp + "embeddings.position_embedding.weight")
+        self.pre_ln_w, self.pre_ln_b = g(vp + "pre_layrnorm.weight"), g(vp + "pre_layrnorm.bias")
+        self.vit: List[_VitLayer] = []
+        for i in range(a.v_layers):
+            p = f"{vp}encoder.layers.{i}."
+            cat = lambda suf: torch.cat([g(p + f"self_attn.{n}_proj.{suf}") for n in ("q", "k", "v")]).contiguous()
+            self.vit.append(_VitLayer(g(p + "layer_norm1.weight"), g(p + "layer_norm1.bias"), cat("weight"), cat("bias"),
+                                      g(p + "self_attn.out_proj.weight"), g(p + "self_attn.out_proj.bias"),
+                                      g(p + "layer_norm2.weight"), g(p + "layer_norm2.bias"),
+                                      g(p + "mlp.fc1.weight"), g(p + "mlp.fc1.bias"), g(p + "mlp.fc2.weight"), g(p + "mlp.fc2.bias")))
+        self.perc: List[_PercBlock] = []
+        if a.use_resampler:
+            rp = "model.perceiver_resampler."
+            self.latents = g(rp + "latents")
+            for i in range(a.r_depth):
+                p, m = f"{rp}blocks.{i}.0.", f"{rp}blocks.{i}.1."
+                qn = a.r_qk_norm
+                self.perc.append(_PercBlock(
+                    g(p + "context_layer_norm.weight"), g(p + "context_layer_norm.bias"),
+                    g(p + "latents_layer_norm.weight"), g(p + "latents_layer_norm.bias"),
+                    g(p + "q_proj.weight"), torch.cat([g(p + "k_proj.weight"), g(p + "v_proj.weight")]).contiguous(),
+                    g(p + "output_proj.weight"),
+                    g(p + "q_layer_norm.weight") if qn else None, g(p + "q_layer_norm.bias") if qn else None,
+                    g(p + "k_layer_norm.weight") if qn else None, g(p + "k_layer_norm.bias") if qn else None,
+                    g(m + "ln.weight"), g(m + "ln.bias"), g(m + "fc.weight"), g(m + "c_proj.weight")))
+            self.perc_ln_w, self.perc_ln_b = g(rp + "layer_norm.weight"), g(rp + "layer_norm.bias")
+        self.dec: List[_DecLayer] = []
+        for i in range(a.num_layers):
+            p = f"model.layers.{i}."
+            qkv = torch.cat([g(p + f"self_attn.{n}_proj.weight") for n in ("q", "k", "v")]).contiguous()
+            gu = ops.pack_gate_up(g(p + "mlp.gate_proj.weight"), g(p + "mlp.up_proj.weight"))
+            self.dec.append(_DecLayer(g(p + "input_layernorm.weight"), qkv, g(p + "self_attn.o_proj.weight"),
+                                      g(p + "post_attention_layernorm.weight"), gu, g(p + "mlp.down_proj.weight")))
+        self.xat: List[_XLayer] = []
+        for j in range(a.num_cross_layers):
+            p = f"model.gated_cross_attn_layers.{j}."
+            kv = torch.cat([g(p + "cross_attn.k_proj.weight"), g(p + "cross_attn.v_proj.weight")]).contiguous()
+            gu = ops.pack_gate_up(g(p + "mlp.gate_proj.weight"), g(p + "mlp.up_proj.weight"))
+            # tanh(alpha) evaluated in bf16 like the module does (hf:idefics/modeling_idefics.py:793,800)
+            ga = float(torch.tanh(g(p + "alpha_cross_attn")).float().reshape(-1)[0])
+            gd = float(torch.tanh(g(p + "alpha_dense")).float().reshape(-1)[0])
+            self.xat.append(_XLayer(g(p + "input_layernorm.weight"), g(p + "cross_attn.q_proj.weight"), kv,
+                                    g(p + "cross_attn.o_proj.weight"),
+                                    g(p + "cross_attn.q_layer_norm.weight") if a.qk_layer_norms else None,
+                                    g(p + "cross_attn.k_layer_norm.weight") if a.qk_layer_norms else None,
+                                    g(p + "post_attention_layernorm.weight"), gu, g(p + "mlp.down_proj.weight"), ga, gd))
+        self.final_ln = g("model.norm.weight")
+        head = g("lm_head.weight")
+        if a.additional_vocab_size:
+            head = torch.cat([head, g("lm_head.additional_fc.weight")]).contiguous()
+        self.lm_head = head
+        # rotary tables exactly as hf:idefics/modeling_idefics.py:357-379 builds them (fp32 maths, cast to bf16)
+        inv = 1.0 / (a.rope_base ** (torch.arange(0, a.head_dim, 2, dtype=torch.int64).to(torch.float) / a.head_dim))
+        t = torch.arange(a.max_positions, dtype=torch.int64).to(torch.float)
+        emb = torch.cat((torch.outer(t, inv),) * 2, dim=-1)
+        self.cos, self.sin = _bf(emb.cos(), dev), _bf(emb.sin(), dev)
+
+
+class KVCache:
+    """Per-layer (B, max_len, 2, H) bf16 self-attention cache for hooked generate."""
+
+    def __init__(self, arch: IdeficsArch, batch: int, max_len: int, device):
+        H = arch.hidden_size
+        self.max_len, self.len = max_len, 0
+        self.kv = [torch.empty((batch, max_len, 2 * H), dtype=torch.bfloat16, device=device) for _ in range(arch.num_layers)]
+
+    def reorder(self, idx: torch.Tensor):
+        for i in range(len(self.kv)):
+            self.kv[i] = self.kv[i].index_select(0, idx)
+
+
+class IdeficsEngine:
+    def __init__(self, weights: IdeficsWeights, fuse_hook_norm: bool = True):
+        self.w, self.arch = weights, weights.arch
+        self.fuse_hook_norm = fuse_hook_norm
+
+    # ----------------------------------------------------------------------------------- vision side
+    def encode_images(self, pixel_values: torch.Tensor) -> torch.Tensor:
+        """pixel_values (B, N, 3, H, W) -> image_hidden_states (B, N*image_seq_len, E) bf16
+        (hf:idefics/modeling_idefics.py:986-1013; vision.py:341-381; perceiver.py:93-103)."""
+        a, w = self.arch, self.w
+        B, N = pixel_values.shape[:2]
+        n_img = B * N
+        pix = pixel_values.to(torch.bfloat16).reshape(n_img, *pixel_values.shape[2:]).contiguous()
+        assert pix.shape[-1] == a.v_image and pix.shape[-2] == a.v_image, "image size must match the vision config"
+        E, T, nh, hd = a.v_embed, a.v_tokens, a.v_heads, a.v_head_dim
+        cols = ops.im2col_patches(pix, a.v_patch, w.patch_ld)
+        patches = ops.linear(cols, w.patch_w)
+        del cols
+        x = ops.vit_embed_ln(patches, w.cls, w.pos, w.pre_ln_w, w.pre_ln_b, n_img, T - 1, a.v_ln_eps).view(n_img * T, E)
+        del patches
+        act = "gelu" if a.v_act == "gelu" else "gelu_tanh"
+        for L in w.vit:
+            y = ops.layernorm(x, L.ln1_w, L.ln1_b, a.v_ln_eps)
+            qkv = ops.linear(y, L.qkv_w, bias=L.qkv_b)
+            o = ops.attention(qkv, qkv.view(-1)[E:], qkv.view(-1)[2 * E:], n_img, T, T, nh, nh, hd,
+                              T * 3 * E, 3 * E, T * 3 * E, 3 * E, hd ** -0.5, 0)
+            del qkv
+            ops.linear(o.view(n_img * T, E), L.out_w, bias=L.out_b, residual=x, out=x)
+            y = ops.layernorm(x, L.ln2_w, L.ln2_b, a.v_ln_eps)
+            y = ops.linear(y, L.fc1_w, bias=L.fc1_b, act=act)
+            ops.linear(y, L.fc2_w, bias=L.fc2_b, residual=x, out=x)
+            del y, o
+        if not a.use_resampler:
+            return x.view(B, N * T, E)
+        return self._perceiver(x, n_img).view(B, N * a.r_latents, E)
+
+    def _perceiver(self, ctx: torch.Tensor, n_img: int) -> torch.Tensor:
+        a, w = self.arch, self.w
+        E, T, Lq, nh, hd = a.v_embed, a.v_tokens, a.r_latents, a.r_heads, a.r_head_dim
+        inner = nh * hd
+        lat = ops.tile_rows(w.latents, n_img * Lq)
+        kvin = torch.empty((n_img, T + Lq, E), dtype=torch.bfloat16, device=ctx.device)
+        for P in w.perc:
+            ops.layernorm(ctx, P.ctx_w, P.ctx_b, 1e-5, out=kvin, out_group=T, out_group_extra=Lq * E)
+            ops.layernorm(lat, P.lat_w, P.lat_b, 1e-5, out=kvin.view(-1)[T * E:], out_group=Lq, out_group_extra=T * E)
+            latn = ops.layernorm(lat, P.lat_w, P.lat_b, 1e-5)
+            q = ops.linear(latn, P.q_w)
+            kv = ops.linear(kvin.view(n_img * (T + Lq), E), P.kv_w)
+            if P.qn_w is not None:
+                ops.layernorm(q, P.qn_w, P.qn_b, 1e-5, out=q, inner=nh, ld_x=inner, ld_out=inner, rows=n_img * Lq * nh, dim=hd)
+                ops.layernorm(kv, P.kn_w, P.kn_b, 1e-5, out=kv, inner=nh, ld_x=2 * inner, ld_out=2 * inner,
+                              rows=n_img * (T + Lq) * nh, dim=hd)
+            o = ops.attention(q, kv, kv.view(-1)[inner:], n_img, Lq, T + Lq, nh, nh, hd, Lq * inner, inner,
+                              (T + Lq) * 2 * inner, 2 * inner, hd ** -0.5, 0)
+            ops.linear(o.view(n_img * Lq, inner), P.out_w, residual=lat, out=lat)
+            y = ops.layernorm(lat, P.ln_w, P.ln_b, 1e-5)
+            y = ops.linear(y, P.fc_w, act="relu")
+            ops.linear(y, P.cproj_w, residual=lat, out=lat)
+        return ops.layernorm(lat, w.perc_ln_w, w.perc_ln_b, 1e-5)
+
+    # ----------------------------------------------------------------------------------- language side
+    @staticmethod
+    def _position_ids(attention_mask: torch.Tensor, q_len: int) -> torch.Tensor:
+        pos = attention_mask.long().cumsum(-1) - 1                       # hf:idefics/modeling_idefics.py:972-976
+        pos = pos.masked_fill(attention_mask == 0, 1)
+        return pos[:, -q_len:].contiguous()
+
+    def forward(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
+                pixel_values: Optional[torch.Tensor] = None, image_attention_mask: Optional[torch.Tensor] = None,
+                image_states: Optional[torch.Tensor] = None, icv: Optional[torch.Tensor] = None,
+                hook_layers: Optional[Sequence[int]] = None, alpha: Optional[torch.Tensor] = None,
+                capture: Optional[dict] = None, kv_cache: Optional[KVCache] = None,
+                save_hook_inputs: Optional[list] = None, logits_rows: Optional[torch.Tensor] = None):
+        """Returns logits (B, S, V) bf16 (a view with a padded row stride).
+        icv: (1, n_hooked, H) fp32 — already alpha-scaled when ``alpha`` is None (the reference contract,
+        ref:icv_src/icv_module.py:89-92); with ``alpha`` (1, n_hooked) fp32 the scaling is folded into the kernel.
+        hook_layers: decoder-layer ids whose OUTPUT is edited (ref:config/lmm/idefics-9B.yaml:7)."""
+        a, w = self.arch, self.w
+        dev = w.device
+        B, S = input_ids.shape
+        M, H, nh, hd = B * S, a.hidden_size, a.num_heads, a.head_dim
+        if attention_mask is None:
+            attention_mask = torch.ones((B, S + (kv_cache.len if kv_cache else 0)), dtype=torch.long, device=dev)
+        Sk = attention_mask.shape[1]
+        if image_states is None:
+            image_states = self.encode_images(pixel_values)
+        Nk = image_states.shape[1]
+        E = image_states.shape[2]
+        img_len = a.image_seq_len
+        n_img = Nk // img_len
+        img_mask = image_attention_mask.to(torch.int32).contiguous()
+        gate = (img_mask != 0).any(-1).to(torch.float32).reshape(-1).contiguous()      # cross_attention_gate
+        key_valid = attention_mask.to(torch.int32).contiguous()
+        pos = self._position_ids(attention_mask, S).reshape(-1)
+        idx_of = {int(l): i for i, l in enumerate(hook_layers)} if (icv is not None and hook_layers is not None) else {}
+        if icv is not None:
+            icv = icv.to(device=dev, dtype=torch.float32).contiguous()
+            if alpha is not None:
+                alpha = alpha.to(device=dev, dtype=torch.float32).contiguous()
+
+        h = ops.embed_gather(input_ids.contiguous(), w.embed, w.embed_extra, a.vocab_size).view(M, H)
+        xn = None                                    # RMSNorm of h for the next block, when the hook kernel made it
+        img2d = image_states.reshape(B * Nk, E)
+        past = kv_cache.len if kv_cache is not None else 0
+        assert past + S == Sk, "attention_mask must span past + new tokens"
+
+        def next_norm_weight(l: int):
+            if l + 1 >= a.num_layers:
+                return w.final_ln
+            if (l + 1) % a.cross_layer_interval == 0:
+                return w.xat[(l + 1) // a.cross_layer_interval].in_ln
+            return w.dec[l + 1].in_ln
+
+        for l in range(a.num_layers):
+            if l % a.cross_layer_interval == 0:
+                X = w.xat[l // a.cross_layer_interval]
+                x = xn if xn is not None else ops.rmsnorm(h, X.in_ln, a.rms_eps)
+                xn = None
+                q = ops.linear(x, X.q_w)
+                kv = ops.linear(img2d, X.kv_w)
+                if X.qn_w is not None:
+                    ops.rmsnorm(q, X.qn_w, a.rms_eps, out=q, inner=nh, ld_x=H, ld_out=H, rows=M * nh, dim=hd)
+                    ops.rmsnorm(kv, X.kn_w, a.rms_eps, out=kv, inner=nh, ld_x=2 * H, ld_out=2 * H, rows=B * Nk * nh, dim=hd)
+                o = ops.attention(q, kv, kv.view(-1)[H:], B, S, Nk, nh, nh, hd, S * H, H, Nk * 2 * H, 2 * H, hd ** -0.5, 3,
+                                  img_mask=img_mask, img_len=img_len)
+                ops.linear(o.view(M, H), X.o_w, row_gate=gate, scale=X.gate_attn, residual=h, out=h)
+                x = ops.rmsnorm(h, X.post_ln, a.rms_eps)
+                act = ops.linear(x, X.gu_w, swiglu=True)
+                ops.linear(act, X.down_w, scale=X.gate_dense, residual=h, out=h)
+                del q, kv, o, act
+            D = w.dec[l]
+            x = xn if xn is not None else ops.rmsnorm(h, D.in_ln, a.rms_eps)
+            xn = None
+            if kv_cache is None:
+                qkv = ops.linear(x, D.qkv_w)
+                ops.rotary_(qkv, w.cos, w.sin, pos, M, nh, hd, 3 * H, H, 2)
+                o = ops.attention(qkv, qkv.view(-1)[H:], qkv.view(-1)[2 * H:], B, S, S, nh, nh, hd, S * 3 * H, 3 * H,
+                                  S * 3 * H, 3 * H, hd ** -0.5, 1, key_valid=key_valid)
+            else:
+                qkv = ops.linear(x, D.qkv_w)
+                ops.rotary_(qkv, w.cos, w.sin, pos, M, nh, hd, 3 * H, H, 2)
+                cache = kv_cache.kv[l]
+                cache[:, past:past + S] = qkv.view(B, S, 3 * H)[:, :, H:]          # append K|V (device copy)
+                o = ops.attention(qkv, cache, cache.view(-1)[H:], B, S, Sk, nh, nh, hd, S * 3 * H, 3 * H,
+                                  kv_cache.max_len * 2 * H, 2 * H, hd ** -0.5, 1, key_valid=key_valid)
+            ops.linear(o.view(M, H), D.o_w, residual=h, out=h)
+            x = ops.rmsnorm(h, D.post_ln, a.rms_eps)
+            act = ops.linear(x, D.gu_w, swiglu=True)
+            ops.linear(act, D.down_w, residual=h, out=h)
+            del qkv, o, act
+            if capture is not None:
+                capture.setdefault("raw", []).append(h.view(B, S, H).clone())
+            if l in idx_of:
+                i = idx_of[l]
+                if save_hook_inputs is not None:
+                    save_hook_inputs.append(h if h.dtype == torch.float32 else h.clone())
+                al = alpha[0, i:i + 1] if alpha is not None else None
+                in_place = h.dtype == torch.float32 and save_hook_inputs is None
+                if self.fuse_hook_norm:
+                    h, xn = ops.inject_renorm(h, icv[0, i], alpha=al, out=h if in_place else None,
+                                              norm_weight=next_norm_weight(l), norm_eps=a.rms_eps)
+                else:
+                    h = ops.inject_renorm(h, icv[0, i], alpha=al, out=h if in_place else None)
+            if capture is not None:
+                capture.setdefault("edited", []).append(h.view(B, S, H).clone())
+        if kv_cache is not None:
+            kv_cache.len = past + S
+        x = xn if xn is not None else ops.rmsnorm(h, w.final_ln, a.rms_eps)
+        if capture is not None:
+            capture["final_norm"] = x.view(B, S, H).clone()
+            capture["image_states"] = image_states
+        if logits_rows is not None:
+            x = x.index_select(0, logits_rows)
+            return ops.linear(x, w.lm_head)
+        logits = ops.linear(x, w.lm_head)
+        return logits.view(B, S, logits.shape[-1]) if logits.is_contiguous() else \
+            logits.as_strided((B, S, logits.shape[-1]), (S * logits.stride(0), logits.stride(0), 1))
