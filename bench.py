@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""Headline benchmark: VQA questions/sec of the ICV-injected Idefics-9B forward, 32-shot, bs=8, bf16
+(BASELINE.json configs[1]; SURVEY.md §8d shape "H") on N MI355X, one process per GPU.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = one full hooked forward over one batch resident in HBM: ViT-H/14 on B*33 images, perceiver,
+32 decoder + 8 gated cross-attention layers with the ICV hook on every decoder layer, LM head (logits for all
+positions).  Forward-only data parallel: questions shard across ranks, no data-path collective ("weak").
+Prints ONE JSON line (rank 0).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+for p in (str(ROOT), str(ROOT / "licv-vqa_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+WORKLOADS = {
+    # name: (arch preset, B, S, n_img, min_len)
+    "idefics9b_32shot_bs8": ("idefics-9b", 8, 800, 33, 720),
+    "idefics9b_student_bs8": ("idefics-9b", 8, 32, 1, 24),
+    "idefics_mid_debug": ("idefics-mid", 4, 96, 5, 80),
+}
+
+
+def cpu_baseline(arch, S, n_img, budget_s=25.0):
+    """The oracle (CPU restatement of the reference path) timed on this box's host cores on a BOUNDED sample:
+    one question at full width, depth-truncated (2 ViT layers, 1 perceiver block, 4 LM layers incl. 1 gated
+    cross-attention layer, LM head), scaled linearly in depth to the full model."""
+    from licv.synthetic import synth_idefics_weights, synth_vqa_batch
+    from oracle import idefics_ref as R
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    vl, rd, ll = 2, 1, arch.cross_layer_interval
+    small = arch.with_(v_layers=vl, r_depth=rd, num_layers=ll)
+    sd = synth_idefics_weights(small, seed=1, dtype=torch.bfloat16)
+    batch = synth_vqa_batch(small, 1, S, n_img, seed=2, min_len=S, dtype=torch.bfloat16)
+    icv = torch.randn(1, ll, arch.hidden_size) * 0.01
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        pv = batch["pixel_values"].view(n_img, *batch["pixel_values"].shape[2:])
+        x = R.vision_tower(pv, sd, small)
+        t1 = time.perf_counter()
+        img = R.perceiver(x, sd, small) if small.use_resampler else x
+        t2 = time.perf_counter()
+        img = img.view(1, -1, img.shape[-1])
+        R.forward(sd, small, batch["input_ids"], batch["attention_mask"], image_attention_mask=batch["image_attention_mask"],
+                  image_states=img, icv=icv, hook_layers=list(range(ll)))
+        t3 = time.perf_counter()
+        # head + embedding alone, to separate the depth-independent part of the LM leg
+        h = torch.randn(1, S, arch.hidden_size).to(torch.bfloat16)
+        R.lm_head(R.rms_norm(h, sd["model.norm.weight"], arch.rms_eps), sd)
+        t4 = time.perf_counter()
+    t_vit, t_perc, t_lm, t_head = t1 - t0, t2 - t1, t3 - t2, t4 - t3
+    full = t_vit * arch.v_layers / vl + t_perc * arch.r_depth / rd + (t_lm - t_head) * arch.num_layers / ll + t_head
+    return {
+        "value": 1.0 / full, "unit": "questions/s", "cores": cores, "kind": "port",
+        "sample": (f"1 question (S={S}, {n_img} images) through the CPU oracle in bf16, depth-truncated to {vl} ViT layers, "
+                   f"{rd} perceiver block, {ll} LM layers (+1 gated x-attn) and the LM head; measured {t3 - t0 + t_head:.1f} s, "
+                   f"scaled linearly in depth to {arch.v_layers}/{arch.r_depth}/{arch.num_layers} layers = {full:.1f} s/question"),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="idefics9b_32shot_bs8", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hooks", action="store_true", help="teacher shape: same forward with the intervention off")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU: the L-ICV hot path has no CPU fallback"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from licv import ops
+    from licv.config import idefics_arch
+    from licv.idefics_engine import IdeficsEngine, IdeficsWeights
+    from licv.roofline import PEAK_BF16_TFLOPS, PEAK_HBM_GBS, flops_per_question, inject_bytes_per_question
+    from licv.synthetic import synth_icv, synth_idefics_weights, synth_vqa_batch
+
+    preset, B, S, n_img, min_len = WORKLOADS[args.workload]
+    arch = idefics_arch(preset)
+    sd = synth_idefics_weights(arch, seed=426, dtype=torch.bfloat16, device=dev)       # full replica per GPU
+    eng = IdeficsEngine(IdeficsWeights(sd, arch, dev))
+    del sd
+    torch.cuda.empty_cache()
+    batch = synth_vqa_batch(arch, B, S, n_img, seed=426 + rank, min_len=min_len, dtype=torch.bfloat16, device=dev)
+    icv, alpha = synth_icv(arch.num_layers, arch.hidden_size, seed=426, alpha=0.1, device=dev)
+    layers = list(range(arch.num_layers))
+    hooks = {} if args.no_hooks else dict(icv=icv, alpha=alpha, hook_layers=layers)
+
+    def step():
+        return eng.forward(**batch, **hooks)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    prof = []
+    ops.set_profiler(prof)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    ops.set_profiler(None)
+    del out
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    qps = B * world * args.steps / elapsed
+
+    # roofline of the dominant kernel (the bf16 MFMA GEMM) from the in-run event pairs
+    def agg(kind):
+        ev = [(e0.elapsed_time(e1) * 1e-3, w) for k, e0, e1, w in prof if k == kind]
+        return sum(t for t, _ in ev), sum(w for _, w in ev), len(ev)
+    tg, fl, ng = agg("gemm")
+    ti, by, ni = agg("inject")
+    fq = flops_per_question(arch, S, n_img)
+    res = {
+        "metric": "VQA questions/sec (whole node), Idefics-9B 32-shot ICV forward",
+        "value": qps, "unit": "questions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic (random-init Idefics-9B weights, seeded image+text batches)",
+        "config": {"workload": args.workload, "arch": preset, "questions_per_gpu": B, "seq_len": S, "images_per_question": n_img,
+                   "hooked_layers": 0 if args.no_hooks else arch.num_layers, "parallelism": f"dp{world}"},
+        "roofline": {"bound": "mfma", "kernel": "gemm_bf16_tile128_k", "achieved": fl / tg / 1e12 if tg else None,
+                     "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": (fl / tg / 1e12) / PEAK_BF16_TFLOPS if tg else None,
+                     "traffic": None, "launches_per_step": ng // max(args.steps, 1),
+                     "avg_launch_us": 1e6 * tg / ng if ng else None, "gemm_share_of_step": tg / elapsed if elapsed else None},
+        "whole_path": {"tflop_per_question": fq["total"] / 1e12, "achieved_tflops_per_gpu": fq["total"] * B * args.steps / elapsed / 1e12,
+                       "frac_of_mfma_peak": fq["total"] * B * args.steps / elapsed / 1e12 / PEAK_BF16_TFLOPS},
+    }
+    if ni:
+        res["hook_kernel"] = {"bound": "hbm", "kernel": "inject_renorm_fwd_k (+fused RMSNorm)", "achieved": by / ti / 1e9,
+                              "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": by / ti / 1e9 / PEAK_HBM_GBS,
+                              "launches_per_step": ni // max(args.steps, 1), "avg_launch_us": 1e6 * ti / ni,
+                              "algorithmic_MB_per_question": inject_bytes_per_question(arch, S, arch.num_layers) / 1e6}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(arch, S, n_img)
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,145 @@
+"""``VQAICVModule`` — the L-ICV distillation step behind the reference's surface, on the native engine.
+
+Kept from ref:icv_src/icv_module.py:15-216: constructor ``(interface, module_cfg, lmm_cfg)``; sub-modules
+``icv_model`` / ``icv_encoder`` (state-dict keys ``icv_encoder.alpha`` / ``icv_encoder.icv``); ``temperature``;
+``forward(query_inputs, inputs, query_x_length, in_context_length) -> (loss_dict, ICVEncoderOutput)``;
+``calculate_kl_divergence``; ``get_mask``; ``decay_temperature``; the optimiser recipe of ``configure_optimizers``
+(two lr groups, AdamW, cosine warm-up).  PyTorch-Lightning / Hydra / DeepSpeed are not used: configs are plain
+attribute namespaces (or dicts) with the reference's key names, and the trainer is ``licv.trainer``.
+
+Teacher and student forwards, the masked KL rows and AdamW run as HIP kernels.  CE is computed here with pads
+masked by ``attention_mask`` (the pinned transformers 4.38.2 Idefics behaviour).
+"""
+from __future__ import annotations
+
+import math
+import types
+from typing import Any
+
+import torch
+
+from licv import ops
+
+from .icv_encoder.global_icv_encoder import GlobalICVEncoder
+from .icv_model.icv_intervention import LearnableICVInterventionLMM
+
+
+def _ns(cfg) -> Any:
+    if isinstance(cfg, dict):
+        return types.SimpleNamespace(**{k: _ns(v) if isinstance(v, dict) else v for k, v in cfg.items()})
+    return cfg
+
+
+def _get(cfg, key, default=None):
+    return getattr(cfg, key, default) if not isinstance(cfg, dict) else cfg.get(key, default)
+
+
+class VQAICVModule(torch.nn.Module):
+    def __init__(self, interface, module_cfg, lmm_cfg) -> None:
+        super().__init__()
+        self.module_cfg, self.lmm_cfg = _ns(module_cfg), _ns(lmm_cfg)
+        self.interface = interface
+        self.interface.requires_grad_(False)
+        if hasattr(self.interface.model, "gradient_checkpointing_enable"):
+            self.interface.model.gradient_checkpointing_enable()
+        self.icv_model = LearnableICVInterventionLMM(
+            interface, enable_intervention=True, intervention_layer=self.lmm_cfg.intervention_layer,
+            layer_format=self.lmm_cfg.layer_format, total_layers=self.lmm_cfg.total_layers)
+        enc_cfg = _get(self.module_cfg, "icv_encoder", None) or {}
+        enc_kw = {k: _get(enc_cfg, k) for k in ("alpha_learnable", "alpha_init_value", "use_sigmoid") if _get(enc_cfg, k) is not None}
+        self.icv_encoder = GlobalICVEncoder(lmm_hidden_dim=self.lmm_cfg.hidden_size,
+                                            lmm_layers=len(self.icv_model.intervention_layer_names), **enc_kw)
+        self.temperature = torch.nn.Parameter(torch.tensor(float(self.module_cfg.init_temperature)),
+                                              requires_grad=bool(_get(self.module_cfg, "learnable_t", False)))
+        self.global_step = 0
+        self.decay_per_step = None
+
+    # ------------------------------------------------------------------ masks / losses
+    def get_mask(self, inputs, mask_length):
+        """mask[b,t] = (t >= length[b]) & (ids[b,t] != pad): assumes right padding (ref :136-148)."""
+        ids = inputs[self.interface.input_ids_field_name]
+        steps = torch.arange(ids.shape[1], device=ids.device).unsqueeze(0).expand(ids.shape[0], -1)
+        return (steps >= mask_length.to(ids.device).unsqueeze(1)) & (ids != self.interface.tokenizer.pad_token_id)
+
+    def calculate_kl_divergence(self, stu_logits, tea_logits):
+        """mean over rows of sum_v p*(log(p+eps)-log(q+eps)), times T^2 (ref :121-134).  Rows are given as 2-D
+        (rows, V) tensors; the per-row reduction over the vocabulary is one HIP kernel."""
+        n, V = stu_logits.shape
+        idx = torch.arange(n, device=stu_logits.device)
+        rows = ops.kl_rows(stu_logits if stu_logits.stride(1) == 1 else stu_logits.contiguous(),
+                           tea_logits if tea_logits.stride(1) == 1 else tea_logits.contiguous(),
+                           idx, idx, V, float(self.temperature), float(self.module_cfg.kl_eps))
+        return rows.to(stu_logits.dtype).mean() * self.temperature ** 2
+
+    def _kl_from_masks(self, stu_logits, tea_logits, stu_mask, tea_mask):
+        """Same value as calculate_kl_divergence(stu[mask], tea[mask]) without materialising the gathered rows."""
+        B, Ss, V = stu_logits.shape
+        s_rows = stu_mask.reshape(-1).nonzero().squeeze(1)
+        t_rows = tea_mask.reshape(-1).nonzero().squeeze(1)
+        assert s_rows.numel() == t_rows.numel(), "student and teacher must mask the same number of answer tokens"
+        s2 = stu_logits.as_strided((B * Ss, V), (stu_logits.stride(1), 1))
+        t2 = tea_logits.as_strided((tea_logits.shape[0] * tea_logits.shape[1], V), (tea_logits.stride(1), 1))
+        rows = ops.kl_rows(s2, t2, s_rows, t_rows, V, float(self.temperature), float(self.module_cfg.kl_eps))
+        return rows.to(stu_logits.dtype).mean() * self.temperature ** 2
+
+    # ------------------------------------------------------------------ forward (ref :71-119)
+    def forward(self, query_inputs, inputs, query_x_length, in_context_length):
+        icl_context_mask = self.get_mask(inputs, in_context_length)
+        zero_shot_mask = self.get_mask(query_inputs, query_x_length)
+        enc = self.icv_encoder()
+        icv = enc.alpha.unsqueeze(dim=-1) * enc.in_context_vector
+        if self.module_cfg.hard_loss_weight:
+            query_inputs["labels"] = query_inputs["input_ids"]
+        self.icv_model.toggle_intervention(True)
+        icv_outputs = self.icv_model(**query_inputs, icv=icv.detach())
+        if _get(self.module_cfg, "only_hard_loss", False):
+            return {"loss": icv_outputs["loss"]}, enc
+        with torch.no_grad():
+            self.icv_model.toggle_intervention(False)
+            ice_logits = self.icv_model(**{k: v for k, v in inputs.items() if k != "labels"})["logits"]
+        kl_loss = self._kl_from_masks(icv_outputs["logits"], ice_logits, zero_shot_mask, icl_context_mask)
+        loss = 0.0 + kl_loss
+        loss_dict = {"kl_loss": kl_loss}
+        if self.module_cfg.hard_loss_weight:
+            loss = loss + self.module_cfg.hard_loss_weight * icv_outputs["loss"]
+            loss_dict["ce_loss"] = icv_outputs["loss"]
+        loss_dict["loss"] = loss
+        return loss_dict, enc
+
+    # ------------------------------------------------------------------ schedule helpers (ref :54-69, :150-158, :171-209)
+    def setup_temperature_decay(self, estimated_stepping_batches: int):
+        d = self.module_cfg.decay_per_step
+        if d < 0:
+            return
+        if isinstance(d, int):
+            self.decay_per_step = d
+        elif isinstance(d, float) and 0 < d < 1:
+            self.decay_per_step = int(estimated_stepping_batches * d)
+        else:
+            raise ValueError("decay_ratio must be an int or a float between 0 and 1")
+
+    def decay_temperature(self):
+        if self.module_cfg.decay_ratio < 0:
+            return
+        if self.global_step % self.decay_per_step == 0 and self.global_step != 0:
+            self.temperature = torch.clip(self.temperature * self.module_cfg.decay_ratio, min=self.module_cfg.min_tmeprature)
+
+    def optimizer_spec(self, estimated_stepping_batches: int):
+        """The reference's recipe as plain numbers: alpha group lr, icv group lr, weight decay, warm-up steps."""
+        w = self.module_cfg.warm_steps
+        if isinstance(w, float):
+            warm = w * estimated_stepping_batches
+        elif isinstance(w, int):
+            warm = w
+        else:
+            raise ValueError(f"the warm_steps should be int or float, but got {type(w)}")
+        return dict(alpha_lr=float(self.module_cfg.alpha_lr), icv_lr=float(self.module_cfg.icv_lr),
+                    weight_decay=float(self.module_cfg.weight_decay), warm_steps=warm, total_steps=estimated_stepping_batches)
+
+    @staticmethod
+    def lr_lambda(step: int, warm: float, total: float) -> float:
+        """transformers.get_cosine_schedule_with_warmup (num_cycles 0.5)."""
+        if step < warm:
+            return float(step) / float(max(1, warm))
+        progress = float(step - warm) / float(max(1, total - warm))
+        return max(0.0, 0.5 * (1.0 + math.cos(math.pi * progress)))

@@ -9,6 +9,28 @@ import torch
 from . import _lib
 from ._lib import LICV_BF16, LICV_F32, AttnArgs, GemmEpilogue, check
 
+# Optional launch profiler: when a list is installed, every GEMM and hook launch is bracketed by two events
+# on the launch stream and (kind, event0, event1, algorithmic work) is appended; bench.py derives
+# roofline.achieved from it (work = FLOPs for "gemm", bytes for "inject").
+_prof = None
+
+
+def set_profiler(store):
+    global _prof
+    _prof = store
+
+
+def _timed(kind, work, fn):
+    if _prof is None:
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = fn()
+    e1.record()
+    _prof.append((kind, e0, e1, work))
+    return r
+
+
 ACT = {None: 0, "none": 0, "gelu": 1, "gelu_tanh": 2, "gelu_pytorch_tanh": 2, "relu": 3}
 
 
@@ -50,8 +72,9 @@ def inject_renorm(h: torch.Tensor, icv_row: torch.Tensor, alpha: Optional[torch.
         xn = torch.empty(h.shape, dtype=torch.bfloat16, device=h.device)
     if alpha is not None:
         assert alpha.dtype == torch.float32 and alpha.numel() == 1
-    check(_lib.lib().licv_inject_renorm_fwd(_p(h), _dt(h), _p(icv_row), _p(alpha), _p(out), rows, H,
-                                            _p(norm_weight), _p(xn), float(norm_eps), _stream(h)))
+    nbytes = rows * H * (h.element_size() + 4 + (2 if norm_weight is not None else 0))
+    _timed("inject", float(nbytes), lambda: check(_lib.lib().licv_inject_renorm_fwd(
+        _p(h), _dt(h), _p(icv_row), _p(alpha), _p(out), rows, H, _p(norm_weight), _p(xn), float(norm_eps), _stream(h))))
     return (out, xn) if norm_weight is not None else out
 
 
@@ -142,7 +165,8 @@ def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     ep.use_scale = 0 if scale is None else 1
     ep.scale = 0.0 if scale is None else float(scale)
     ep.out_dtype = _dt(out)
-    check(_lib.lib().licv_gemm_bf16(_p(a), lda, _p(w), K, _p(out), ldc, M, N, K, C.byref(ep), _stream(a)))
+    _timed("gemm", 2.0 * M * N * K, lambda: check(_lib.lib().licv_gemm_bf16(
+        _p(a), lda, _p(w), K, _p(out), ldc, M, N, K, C.byref(ep), _stream(a))))
     return out if ret is None else ret
 
 

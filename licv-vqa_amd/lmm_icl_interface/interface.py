@@ -1,0 +1,136 @@
+from __future__ import annotations
+
+import re
+import types
+from pathlib import Path
+from typing import Dict, List, Optional
+
+import torch
+
+from licv.config import IdeficsArch
+from licv.generation import generate as native_generate
+from licv.idefics_engine import IdeficsEngine, IdeficsWeights
+
+
+class LMMOutput(dict):
+    """HF-ModelOutput-like: ``out["logits"]`` and ``out.logits`` both work."""
+    __getattr__ = dict.get
+
+
+class _NativeModel(torch.nn.Module):
+    """What ``interface.model`` exposes to the reference (ref:icv_src/icv_module.py:29-30)."""
+
+    def __init__(self, arch: IdeficsArch):
+        super().__init__()
+        self.config = types.SimpleNamespace(**arch.to_dict(), model_type="idefics")
+
+    def gradient_checkpointing_enable(self, *a, **k):      # the native engine recomputes instead
+        return None
+
+
+class LMMInterface(torch.nn.Module):
+    input_ids_field_name = "input_ids"
+
+    def __init__(self):
+        super().__init__()
+        self._plan = None
+
+
+class IdeficsInterface(LMMInterface):
+    """IdeficsInterface(model_name_or_path, precision, device, prompt_manager, instruction, image_field, label_field)
+    as called at ref:utils.py:41-50.  Extra keyword-only ``state_dict``/``arch`` build from in-memory weights
+    (tests, bench); otherwise ``model_name_or_path`` must be a local HF checkpoint directory."""
+
+    HOOK_SITE = re.compile(r"^model\.model\.layers\.(\d+)$")       # ref:config/lmm/idefics-9B.yaml:7
+
+    def __init__(self, model_name_or_path=None, precision="bf16", device="cuda", prompt_manager=None, instruction="",
+                 image_field="image", label_field="answer", *, state_dict: Optional[Dict[str, torch.Tensor]] = None,
+                 arch: Optional[IdeficsArch] = None, tokenizer=None, processor=None):
+        super().__init__()
+        if str(precision) not in ("bf16", "bfloat16", "torch.bfloat16"):
+            raise ValueError(f"the native Idefics path computes in bf16 only (got precision={precision!r})")
+        if state_dict is None:
+            state_dict, arch, tokenizer, processor = self._load_checkpoint(Path(model_name_or_path), tokenizer, processor)
+        self.arch = arch
+        self._device = torch.device(device)
+        self.engine = IdeficsEngine(IdeficsWeights(state_dict, arch, self._device))
+        self.model = _NativeModel(arch)
+        self.prompt_manager, self.instruction = prompt_manager, instruction
+        self.image_field, self.label_field = image_field, label_field
+        self.tokenizer = tokenizer if tokenizer is not None else types.SimpleNamespace(
+            pad_token_id=arch.pad_token_id, bos_token_id=arch.bos_token_id, eos_token_id=arch.eos_token_id, padding_side="right")
+        self.processor = processor
+
+    @staticmethod
+    def _load_checkpoint(path: Path, tokenizer, processor):
+        from safetensors.torch import load_file
+        from transformers import AutoConfig
+        if not path.is_dir():
+            raise FileNotFoundError(f"{path} is not a local checkpoint directory (no network access to fetch one)")
+        arch = IdeficsArch.from_hf(AutoConfig.from_pretrained(path))
+        sd = {}
+        for f in sorted(path.glob("*.safetensors")):
+            sd.update(load_file(str(f)))
+        if not sd:
+            raise FileNotFoundError(f"no *.safetensors shards under {path}")
+        if processor is None:
+            try:
+                from transformers import AutoProcessor
+                processor = AutoProcessor.from_pretrained(path)
+                tokenizer = tokenizer or processor.tokenizer
+            except Exception:                                           # tokenizer files are optional for the model side
+                processor = None
+        return sd, arch, tokenizer, processor
+
+    # ---- what the reference touches
+    @property
+    def device(self):
+        return self._device
+
+    def requires_grad_(self, flag: bool = True):                        # LMM weights are frozen constants here
+        return self
+
+    # ---- native hook plan (licv.intervention.NativeIntervention)
+    def install_intervention(self, layer_names: List[str], layer_to_icv_index: Dict[int, int], icv: torch.Tensor):
+        layers = []
+        for name in layer_names:
+            m = self.HOOK_SITE.match(name)
+            if m is None or int(m.group(1)) >= self.arch.num_layers:
+                raise LookupError(f"no hook site named {name!r} in the native Idefics engine "
+                                  f"(sites: model.model.layers.<0..{self.arch.num_layers - 1}>)")
+            layers.append(int(m.group(1)))
+        order = sorted(range(len(layers)), key=lambda i: layer_to_icv_index[layers[i]])
+        self._plan = ([layers[i] for i in order], icv)
+
+    def remove_intervention(self):
+        self._plan = None
+
+    def _hooks(self):
+        if self._plan is None:
+            return {}
+        layers, icv = self._plan
+        return dict(icv=icv, hook_layers=layers)
+
+    def forward(self, input_ids=None, attention_mask=None, pixel_values=None, image_attention_mask=None, labels=None, **_):
+        logits = self.engine.forward(input_ids.to(self._device), attention_mask.to(self._device), pixel_values.to(self._device),
+                                     image_attention_mask.to(self._device), **self._hooks())
+        out = LMMOutput(logits=logits)
+        if labels is not None:
+            # shift-by-one CE with pads masked by attention_mask: transformers 4.38.2 Idefics behaviour
+            keep = attention_mask[:, 1:].to(self._device) != 0
+            out["loss"] = torch.nn.functional.cross_entropy(logits[:, :-1][keep].float(), labels[:, 1:].to(self._device)[keep])
+        return out
+
+    @torch.no_grad()
+    def generate(self, input_ids=None, attention_mask=None, pixel_values=None, image_attention_mask=None,
+                 max_new_tokens=20, num_beams=1, length_penalty=1.0, min_new_tokens=0, early_stopping=False,
+                 eos_token_id=None, pad_token_id=None, do_sample=False, **_):
+        if do_sample:
+            raise NotImplementedError("sampling is not part of the reference's inference path")
+        return native_generate(self.engine, input_ids.to(self._device), attention_mask.to(self._device),
+                               pixel_values.to(self._device), image_attention_mask.to(self._device),
+                               max_new_tokens=max_new_tokens, num_beams=num_beams, length_penalty=length_penalty,
+                               min_new_tokens=min_new_tokens, early_stopping=early_stopping,
+                               eos_token_id=eos_token_id if eos_token_id is not None else getattr(self.tokenizer, "eos_token_id", None),
+                               pad_token_id=pad_token_id if pad_token_id is not None else getattr(self.tokenizer, "pad_token_id", None),
+                               **self._hooks())

@@ -1,0 +1,78 @@
+"""CPU checks of the drop-in surface: same names, arguments, attributes and errors as the reference
+(ref:icv_src/icv_encoder/*, ref:icv_src/icv_model/icv_intervention.py, ref:icv_src/icv_module.py), pinned by the
+fixtures the reference's own classes produced (g1, g2)."""
+import types
+
+import pytest
+import torch
+
+from icv_src.icv_encoder.base_icv_encoder import BaseICVEncoder, ICVEncoderOutput
+from icv_src.icv_encoder.global_icv_encoder import GlobalICVEncoder
+from icv_src.icv_model.icv_intervention import LearnableICVInterventionLMM
+
+T = torch.from_numpy
+
+
+def test_encoder_is_bit_identical_to_reference_under_same_seed(golden):
+    z = golden("g1_encoder")
+    for tag in ("a", "b"):
+        H, L, a0, sig = z[f"{tag}_cfg"]
+        torch.manual_seed(426)
+        enc = GlobalICVEncoder(lmm_hidden_dim=int(H), lmm_layers=int(L), alpha_init_value=float(a0), use_sigmoid=bool(sig))
+        out = enc()
+        assert isinstance(enc, BaseICVEncoder) and isinstance(out, ICVEncoderOutput)
+        assert out.in_context_feature is None
+        assert torch.equal(out.in_context_vector, T(z[f"{tag}_icv"]))
+        assert torch.equal(enc.alpha.detach(), T(z[f"{tag}_alpha_param"]))
+        assert torch.equal(out.alpha.detach(), T(z[f"{tag}_alpha_out"]))
+        assert sorted(enc.state_dict().keys()) == list(z[f"{tag}_state_keys"])
+    assert not GlobalICVEncoder(8, 2, alpha_learnable=False).alpha.requires_grad
+
+
+def test_intervention_wrapper_attributes_and_errors(golden):
+    z = golden("g2_intervention")
+    lmm = torch.nn.Linear(2, 2)
+    w = LearnableICVInterventionLMM(lmm, enable_intervention=True, intervention_layer=[3, 7, 1],
+                                    layer_format="model.model.layers.<LAYER_NUM>", total_layers=8)
+    assert w.intervention_layer_names == list(z["names"])
+    assert list(w.layer_to_icv_index.keys()) == list(z["map_keys"]) and list(w.layer_to_icv_index.values()) == list(z["map_vals"])
+    assert LearnableICVInterventionLMM(lmm, True, -1, "blk.<LAYER_NUM>.mlp", 5).intervention_layer_names == list(z["names_all"])
+    assert LearnableICVInterventionLMM(lmm, True, 2, "blk.<LAYER_NUM>", 5).intervention_layer_names == list(z["names_int"])
+    assert w.intervention_status is True and w.lmm is lmm and w.total_layers == 8
+    w.toggle_intervention(False)
+    assert w.intervention_enabled is False
+    with pytest.raises(ValueError) as e:
+        w.toggle_intervention(1)
+    assert str(e.value) == str(z["toggle_error"])
+    off = LearnableICVInterventionLMM(lmm, enable_intervention=False)
+    assert not hasattr(off, "intervention_layers") and not hasattr(off, "layer_to_icv_index")
+    # disabled wrapper is a passthrough (also on CPU: no kernel is involved)
+    x = torch.randn(3, 2)
+    assert torch.equal(off(None, x), lmm(x))
+    w.toggle_intervention(False)
+    assert torch.equal(w(None, x), lmm(x))
+
+
+def test_enabled_intervention_without_icv_or_with_unknown_layer_fails_loudly():
+    lmm = torch.nn.Sequential(torch.nn.Linear(2, 2))
+    w = LearnableICVInterventionLMM(lmm, True, [0], "<LAYER_NUM>", 1)
+    with pytest.raises(ValueError, match="no `icv`"):
+        w(None, torch.randn(1, 2))
+    w2 = LearnableICVInterventionLMM(lmm, True, [5], "layers.<LAYER_NUM>", 8)
+    with pytest.raises(LookupError):
+        w2(torch.zeros(1, 1, 2), torch.randn(1, 2))
+
+
+def test_checkpoint_dict_layout_round_trip(tmp_path):
+    """icv_cpk.pth layout written by ref:train.py:97-106 and read by ref:inference.py:95-100."""
+    enc = GlobalICVEncoder(16, 3, alpha_init_value=0.1, use_sigmoid=True)
+    ck = {"icv_encoder.alpha": enc.alpha.detach().clone(), "icv_encoder.icv": enc.icv.detach().clone(), "use_sigmoid": True,
+          "lmm_args": {"intervention_layer": -1, "layer_format": "model.model.layers.<LAYER_NUM>", "total_layers": 3}}
+    torch.save(ck, tmp_path / "icv_cpk.pth")
+    back = torch.load(tmp_path / "icv_cpk.pth")
+    enc2 = GlobalICVEncoder(16, 3)
+    enc2.load_state_dict({k.split(".", 1)[1]: v for k, v in back.items() if k.startswith("icv_encoder.")})
+    assert torch.equal(enc2.icv, enc.icv) and torch.equal(enc2.alpha, enc.alpha)
+    args = dict(back["lmm_args"])
+    w = LearnableICVInterventionLMM(torch.nn.Identity(), True, args["intervention_layer"], args["layer_format"], args["total_layers"])
+    assert w.intervention_layer_names == [f"model.model.layers.{i}" for i in range(3)]

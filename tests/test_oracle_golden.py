@@ -150,3 +150,22 @@ def test_g7_adamw_cosine(golden):
         icv, mi, vi = O.adamw_step(icv, gi, mi, vi, s + 1, lr_i)
         assert (icv - T(z["icv_steps"][s])).abs().max() <= 1e-8
         assert (alpha - T(z["alpha_steps"][s])).abs().max() <= 1e-7
+
+
+@pytest.mark.parametrize("side", ["left", "right"])
+def test_g5_generate(golden, side):
+    """Oracle decode == ids the reference wrapper + HF generate produced (fp32): beam (3 beams, 5 tokens,
+    length_penalty 0), greedy, and greedy with the intervention toggled off."""
+    from oracle.generate_ref import generate
+    z = golden("g5_generate")
+    arch = IDEFICS_TINY.with_(additional_vocab_size=0)
+    sd = synth_idefics_weights(arch, seed=21, dtype=torch.float32)
+    assert weights_checksum(sd) == float(z["weights_checksum"])
+    sd["model.embed_tokens.weight"] *= float(z["embed_scale"])
+    sd["lm_head.weight"] *= float(z["head_scale"])
+    b = {k: T(z[f"{side}_in_{k}"]) for k in ("input_ids", "attention_mask", "pixel_values", "image_attention_mask")}
+    icv, layers = T(z["icv"]), list(range(arch.num_layers))
+    kw = dict(max_new_tokens=5, length_penalty=0.0)
+    assert torch.equal(generate(sd, arch, **b, icv=icv, hook_layers=layers, num_beams=3, **kw), T(z[f"{side}_f32_beam_ids"]))
+    assert torch.equal(generate(sd, arch, **b, icv=icv, hook_layers=layers, num_beams=1, **kw), T(z[f"{side}_f32_greedy_ids"]))
+    assert torch.equal(generate(sd, arch, **b, num_beams=1, **kw), T(z[f"{side}_f32_greedy_off_ids"]))
