@@ -35,41 +35,58 @@ WORKLOADS = {
 }
 
 
-def cpu_baseline(arch, S, n_img, budget_s=25.0):
-    """The oracle (CPU restatement of the reference path) timed on this box's host cores on a BOUNDED sample:
-    one question at full width, depth-truncated (2 ViT layers, 1 perceiver block, 4 LM layers incl. 1 gated
-    cross-attention layer, LM head), scaled linearly in depth to the full model."""
+def _host_cores() -> int:
+    """CPU share of this process: cgroup quota if set, else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(arch, S, n_img):
+    """The oracle (CPU restatement of the reference path, bf16 like the reference model) timed on this box's host
+    cores on a BOUNDED sample: one question at full width through ONE layer of each kind (ViT layer on all images,
+    perceiver block, gated cross-attention layer, hooked decoder layer, LM head), scaled by the layer counts."""
     from licv.synthetic import synth_idefics_weights, synth_vqa_batch
+    from oracle import icv_ref as O
     from oracle import idefics_ref as R
-    cores = os.cpu_count() or 1
+    cores = _host_cores()
     torch.set_num_threads(cores)
-    vl, rd, ll = 2, 1, arch.cross_layer_interval
-    small = arch.with_(v_layers=vl, r_depth=rd, num_layers=ll)
+    small = arch.with_(v_layers=1, r_depth=1, num_layers=1, cross_layer_interval=1)
     sd = synth_idefics_weights(small, seed=1, dtype=torch.bfloat16)
     batch = synth_vqa_batch(small, 1, S, n_img, seed=2, min_len=S, dtype=torch.bfloat16)
-    icv = torch.randn(1, ll, arch.hidden_size) * 0.01
-    with torch.no_grad():
+    icv = torch.randn(1, 1, arch.hidden_size) * 0.01
+    tm = {}
+
+    def timed(name, fn):
         t0 = time.perf_counter()
+        r = fn()
+        tm[name] = time.perf_counter() - t0
+        return r
+
+    with torch.no_grad():
         pv = batch["pixel_values"].view(n_img, *batch["pixel_values"].shape[2:])
-        x = R.vision_tower(pv, sd, small)
-        t1 = time.perf_counter()
-        img = R.perceiver(x, sd, small) if small.use_resampler else x
-        t2 = time.perf_counter()
-        img = img.view(1, -1, img.shape[-1])
-        R.forward(sd, small, batch["input_ids"], batch["attention_mask"], image_attention_mask=batch["image_attention_mask"],
-                  image_states=img, icv=icv, hook_layers=list(range(ll)))
-        t3 = time.perf_counter()
-        # head + embedding alone, to separate the depth-independent part of the LM leg
-        h = torch.randn(1, S, arch.hidden_size).to(torch.bfloat16)
-        R.lm_head(R.rms_norm(h, sd["model.norm.weight"], arch.rms_eps), sd)
-        t4 = time.perf_counter()
-    t_vit, t_perc, t_lm, t_head = t1 - t0, t2 - t1, t3 - t2, t4 - t3
-    full = t_vit * arch.v_layers / vl + t_perc * arch.r_depth / rd + (t_lm - t_head) * arch.num_layers / ll + t_head
+        x = timed("vit_layer", lambda: R.vision_tower(pv, sd, small))
+        img = timed("perceiver_block", lambda: R.perceiver(x, sd, small)).view(1, -1, arch.v_embed)
+        pos, causal, img_mask, gate = R.build_masks(batch["attention_mask"], batch["image_attention_mask"], arch.image_seq_len,
+                                                    torch.bfloat16)
+        cos, sin = R.rotary_tables(arch.head_dim, arch.max_positions, arch.rope_base, torch.bfloat16)
+        h = R.decoupled_embedding(batch["input_ids"], sd, arch.vocab_size)
+        h = timed("xattn_layer", lambda: R.gated_xattn_layer(h, sd, 0, small, img, img_mask, gate))
+        h = timed("decoder_layer+hook", lambda: O.inject_renorm(R.decoder_layer(h, sd, 0, small, causal, pos, cos, sin), icv[:, 0]))
+        timed("norm+lm_head", lambda: R.lm_head(R.rms_norm(h, sd["model.norm.weight"], arch.rms_eps), sd))
+    full = (tm["vit_layer"] * arch.v_layers + tm["perceiver_block"] * arch.r_depth + tm["xattn_layer"] * arch.num_cross_layers
+            + tm["decoder_layer+hook"] * arch.num_layers + tm["norm+lm_head"])
     return {
         "value": 1.0 / full, "unit": "questions/s", "cores": cores, "kind": "port",
-        "sample": (f"1 question (S={S}, {n_img} images) through the CPU oracle in bf16, depth-truncated to {vl} ViT layers, "
-                   f"{rd} perceiver block, {ll} LM layers (+1 gated x-attn) and the LM head; measured {t3 - t0 + t_head:.1f} s, "
-                   f"scaled linearly in depth to {arch.v_layers}/{arch.r_depth}/{arch.num_layers} layers = {full:.1f} s/question"),
+        "sample": (f"1 question (S={S}, {n_img} images) through the CPU oracle in bf16, one layer of each kind: "
+                   + ", ".join(f"{k} {v:.2f}s" for k, v in tm.items())
+                   + f"; scaled by layer counts ({arch.v_layers} ViT, {arch.r_depth} perceiver, {arch.num_cross_layers} x-attn, "
+                   f"{arch.num_layers} decoder) = {full:.1f} s/question"),
     }
 
 
