@@ -1,24 +1,28 @@
 // bf16 MFMA GEMM for every nn.Linear of the path:  C[M,N] = epilogue(A[M,K] · W[N,K]^T), fp32 accumulate.
 //
-// gfx950 design (v1, "tile128"): 128x128x64 tile per 256-thread workgroup (4 waves in 2x2, 64x64 per
-// wave = 4x4 accumulators of v_mfma_f32_16x16x32_bf16).  Both operands are K-contiguous, so a lane's
-// MFMA fragment (8 consecutive k of one row) is one 16-byte LDS read.  Tiles are staged
-// global -> VGPR -> LDS (register staging so ragged M/N/K edges cost nothing: buffer loads return 0
-// out of range), double-buffered with ONE barrier per K-tile; the next tile's global loads are issued
-// before the MFMAs of the current one and written to LDS after them.  LDS rows are 128 B with the
-// 16-byte chunk index XOR-swizzled by (row & 7): conflict-free for the ds_read_b128 lane groups.
-// The MFMA is issued with W as the A operand and A as the B operand, so each lane ends up with 4
+// Two gfx950 kernels share one epilogue:
+//
+//  * gemm_bf16_tile256_k — the throughput kernel (M >= 512, K % 64 == 0).  256x256x64 tile per 512-thread
+//    workgroup (8 waves as 2(M) x 4(N), 128x64 per wave = 8x4 accumulators of v_mfma_f32_16x16x32_bf16),
+//    one workgroup per CU.  Tiles are staged global -> LDS directly by LDS-DMA (global_load_lds_dwordx4:
+//    no VGPR round trip, no ds_write), two 64 KiB stages; the DMA for K-tile t+1 is issued right after the
+//    single barrier of K-tile t and lands under that tile's 64 MFMAs per wave.  The LDS image is the
+//    DMA's lane-linear order; the 16-byte chunk XOR swizzle (chunk ^ (row & 7)) is applied on the per-lane
+//    SOURCE address and again on the ds_read_b128 address (same involution), so fragment reads are
+//    bank-conflict free.  Ragged M/N edges clamp the source row (those outputs are never stored).
+//  * gemm_bf16_tile128_k — the general kernel (any M, N; K % 8 == 0): 128x128x64 tile, 4 waves, register
+//    staged with buffer loads that return 0 out of range, same swizzle, one barrier per K-tile.
+//
+// Both issue the MFMA with W as the A operand and A as the B operand, so each lane ends up with 4
 // CONSECUTIVE output columns of one row: 8-byte bf16 / 16-byte fp32 stores, vector bias/residual loads.
-// Workgroup ids are remapped so that the 8 XCDs (private L2s) each own a compact block of the tile grid.
+// Workgroup ids are remapped so that the 8 XCDs (private L2s) each own a compact patch of the tile grid.
+#include <type_traits>
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
-#define BM 128
-#define BN 128
 #define BK 64
-#define GEMM_THREADS 256
 
 struct GemmEpi {
     const bf16_t* bias;
@@ -43,42 +47,522 @@ __device__ __forceinline__ float act_apply(float y, int act) {
     }
 }
 
-__device__ __forceinline__ int lds_off(int row, int chunk) {       // bytes within one 128x64 bf16 tile
+__device__ __forceinline__ int lds_off(int row, int chunk) {       // bytes within a [rows][64] bf16 tile
     return row * 128 + ((chunk ^ (row & 7)) << 4);
 }
 
-__global__ __launch_bounds__(GEMM_THREADS, 2)
-void gemm_bf16_tile128_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw,
-                         void* __restrict__ C, int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n, GemmEpi ep) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];     // [2 stages][A 16 KiB | B 16 KiB]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-
-    // ---- XCD-aware tile id: blocks b and b+8 share an XCD; give each XCD a contiguous run of tiles, and
-    // order tiles in groups of 8 tile-rows (N fastest inside a group) so a run is a compact 2-D patch.
+// XCD-aware tile id: blocks b and b+8 share an XCD; give each XCD a contiguous run of tiles, and order tiles
+// in groups of GROUP tile-rows (M fastest inside a group) so a run is a compact 2-D patch of the tile grid.
+__device__ __forceinline__ void tile_coords(int bid, int tiles_m, int tiles_n, int& tm, int& tn) {
     const int nwg = tiles_m * tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     const int GROUP = 8;
     const int per_group = GROUP * tiles_n;
-    const int gidx = bid / per_group;
-    const int first_m = gidx * GROUP;
+    const int first_m = (bid / per_group) * GROUP;
     const int gsize = min(tiles_m - first_m, GROUP);
-    const int tm = first_m + (bid % per_group) % gsize;
-    const int tn = (bid % per_group) / gsize;
-    const int m0 = tm * BM, n0 = tn * BN;
+    tm = first_m + (bid % per_group) % gsize;
+    tn = (bid % per_group) / gsize;
+}
 
-    // ---- buffer descriptors: out-of-range rows read as 0; K tail handled through the offset
+// compile-time loop: accumulator arrays must only ever be indexed by constants (a runtime index puts them in scratch)
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+
+// Epilogue of one 16-row block of a wave: acc[j][r] = C[m][col0 + j*16 + (lane>>4)*4 + r]
+template <int NT>
+__device__ __forceinline__ void epilogue_row(floatx4 (&acc)[NT], const GemmEpi& ep, void* __restrict__ C, int64_t ldc,
+                                             int M, int N, int m, int col0, int cq) {
+    if (m >= M) return;
+    const float gate = ep.row_gate ? ep.row_gate[m] : 1.0f;
+    static_for<0, NT>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        if (ep.swiglu && (j & 1)) return;
+        const int ncol = col0 + j * 16 + cq;               // column in the (packed) N space
+        if (ncol >= N) return;
+        float y[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = acc[j][r];
+            if (ep.bias) v += (ncol + r < N) ? bf2f(ep.bias[ncol + r]) : 0.f;
+            v = rbf(v);
+            if (ep.act) v = rbf(act_apply(v, ep.act));
+            if (ep.swiglu) {
+                const float u = rbf(acc[(j + 1) % NT][r]);
+                const float s = rbf(v / (1.0f + expf(-v)));
+                v = rbf(s * u);
+            }
+            if (ep.row_gate && gate == 0.0f) v = 0.0f;
+            if (ep.use_scale) v = rbf(ep.scale * v);
+            y[r] = v;
+        }
+        // output column: swiglu halves the column space (16-wide gate/up blocks alternate)
+        const int oc = ep.swiglu ? (col0 >> 1) + (j >> 1) * 16 + cq : ncol;
+        const int on = ep.swiglu ? (N >> 1) : N;
+        const int nvalid = min(4, on - oc);
+        if (ep.residual) {
+            if (ep.residual_dtype == LICV_F32) {
+                const float* rp = reinterpret_cast<const float*>(ep.residual) + (int64_t)m * ep.ld_res + oc;
+                if (nvalid == 4) { const floatx4 rv = *reinterpret_cast<const floatx4*>(rp);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) y[r] = rv[r] + y[r]; }
+                else for (int r = 0; r < nvalid; ++r) y[r] = rp[r] + y[r];
+            } else {
+                const bf16_t* rp = reinterpret_cast<const bf16_t*>(ep.residual) + (int64_t)m * ep.ld_res + oc;
+                if (nvalid == 4) { const uint2 u = *reinterpret_cast<const uint2*>(rp);
+                    y[0] = rbf(__uint_as_float(u.x << 16) + y[0]); y[1] = rbf(__uint_as_float(u.x & 0xffff0000u) + y[1]);
+                    y[2] = rbf(__uint_as_float(u.y << 16) + y[2]); y[3] = rbf(__uint_as_float(u.y & 0xffff0000u) + y[3]); }
+                else for (int r = 0; r < nvalid; ++r) y[r] = rbf(bf2f(rp[r]) + y[r]);
+            }
+        }
+        if (ep.out_dtype == LICV_F32) {
+            float* cp = reinterpret_cast<float*>(C) + (int64_t)m * ldc + oc;
+            if (nvalid == 4) *reinterpret_cast<floatx4*>(cp) = floatx4{y[0], y[1], y[2], y[3]};
+            else for (int r = 0; r < nvalid; ++r) cp[r] = y[r];
+        } else {
+            bf16_t* cp = reinterpret_cast<bf16_t*>(C) + (int64_t)m * ldc + oc;
+            if (nvalid == 4) {
+                uint2 u;
+                u.x = (uint32_t)f2bf(y[0]) | ((uint32_t)f2bf(y[1]) << 16);
+                u.y = (uint32_t)f2bf(y[2]) | ((uint32_t)f2bf(y[3]) << 16);
+                *reinterpret_cast<uint2*>(cp) = u;
+            } else for (int r = 0; r < nvalid; ++r) cp[r] = f2bf(y[r]);
+        }
+    });
+}
+
+// Epilogue for a wave holding MT x NT accumulators: acc[i][j][r] = C[row0 + i*16 + (lane&15)][col0 + j*16 + (lane>>4)*4 + r]
+template <int MT, int NT>
+__device__ __forceinline__ void epilogue(floatx4 (&acc)[MT][NT], const GemmEpi& ep, void* __restrict__ C, int64_t ldc,
+                                         int M, int N, int row0, int col0, int lane) {
+    const int rbase = row0 + (lane & 15);
+    const int cq = (lane >> 4) * 4;
+    static_for<0, MT>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        epilogue_row<NT>(acc[i], ep, C, ldc, M, N, rbase + i * 16, col0, cq);
+    });
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS-staged epilogue (all kernels).  Two measured problems of storing straight from the accumulator layout:
+// 32-byte row fragments per store, and — far worse — code size: the element-wise epilogue (erf / tanh / exp
+// bodies under run-time flags) unrolled over every accumulator register is hundreds of KiB of straight-line
+// code that misses the instruction cache on every tile (~30 us per 256x256 tile, more than the MFMAs of a
+// K=1280 tile).  So: phase A (unrolled, tiny) only does y0 = bf16(acc + bias) and parks the wave's block in
+// an LDS image of the tile (row stride +16 B against bank conflicts); after one barrier, phase B is a compact
+// run-time LOOP over full rows — 16 B per lane, whole 256/512-byte row segments — that applies activation /
+// SwiGLU pairing / row gate / tanh-gate scale / residual on the bf16 values (exactly where the unfused torch
+// ops would round) and stores bf16 or fp32.
+// ------------------------------------------------------------------------------------------------
+template <int TM, int TN, int NWAVES, int MT, int NT>
+__device__ __forceinline__ void epilogue_staged(floatx4 (&acc)[MT][NT], const GemmEpi& ep, void* __restrict__ C, int64_t ldc,
+                                                int M, int N, int m0, int n0, int wrow0, int wcol0, int wave, int lane, char* smem) {
+    constexpr int YS = TN * 2 + 16;                       // LDS row stride in bytes
+    // ---- phase A: registers -> LDS image of y0 = bf16(acc + bias)
+    {
+        const int rl = wrow0 + (lane & 15);
+        const int cq = (lane >> 4) * 4;
+        float bv[NT][4];
+        static_for<0, NT>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const int ncol = n0 + wcol0 + j * 16 + cq;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bv[j][r] = (ep.bias && ncol + r < N) ? bf2f(ep.bias[ncol + r]) : 0.f;
+        });
+        static_for<0, MT>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            static_for<0, NT>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                uint2 u;
+                u.x = (uint32_t)f2bf(acc[i][j][0] + bv[j][0]) | ((uint32_t)f2bf(acc[i][j][1] + bv[j][1]) << 16);
+                u.y = (uint32_t)f2bf(acc[i][j][2] + bv[j][2]) | ((uint32_t)f2bf(acc[i][j][3] + bv[j][3]) << 16);
+                *reinterpret_cast<uint2*>(smem + (rl + i * 16) * YS + (wcol0 + j * 16 + cq) * 2) = u;
+            });
+        });
+    }
+    __syncthreads();
+    // ---- phase B: compact loop over rows; lane -> 8 (bf16 out) or 4 (fp32 out) consecutive OUTPUT columns
+    const bool sw = ep.swiglu != 0;
+    const int tcols = sw ? TN / 2 : TN;                   // output columns this tile produces
+    const int on = sw ? (N >> 1) : N;
+    const int oc0 = sw ? (n0 >> 1) : n0;
+    const bool f32out = ep.out_dtype == LICV_F32;
+    const int epl = f32out ? 4 : 8;                       // elements per lane
+    const int lpr = tcols / epl;                          // lanes per row
+    const int rpi = 64 / lpr;                             // rows per wave-instruction
+    const int lr = lane / lpr, lcol = (lane % lpr) * epl;
+    for (int rb = wave * rpi; rb < TM; rb += NWAVES * rpi) {
+        const int row = rb + lr;
+        const int m = m0 + row;
+        const int c = oc0 + lcol;
+        if (m >= M || c >= on) continue;
+        const char* yrow = smem + row * YS;
+        float y[8];
+        if (!sw) {
+            if (f32out) {
+                const uint2 v = *reinterpret_cast<const uint2*>(yrow + lcol * 2);
+                y[0] = __uint_as_float(v.x << 16); y[1] = __uint_as_float(v.x & 0xffff0000u);
+                y[2] = __uint_as_float(v.y << 16); y[3] = __uint_as_float(v.y & 0xffff0000u);
+            } else {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(yrow + lcol * 2);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { y[2 * e] = __uint_as_float(v[e] << 16); y[2 * e + 1] = __uint_as_float(v[e] & 0xffff0000u); }
+            }
+            if (ep.act) {
+                for (int e = 0; e < epl; ++e) y[e] = rbf(act_apply(y[e], ep.act));
+            }
+        } else {
+            // output col lcol..lcol+epl-1 lives in packed cols (lcol/16)*32 + lcol%16 (gate) and +16 (up)
+            const int pc = (lcol >> 4) * 32 + (lcol & 15);
+            for (int e = 0; e < epl; ++e) {
+                const float gv = bf2f(*reinterpret_cast<const bf16_t*>(yrow + (pc + e) * 2));
+                const float uv = bf2f(*reinterpret_cast<const bf16_t*>(yrow + (pc + 16 + e) * 2));
+                const float sg = rbf(gv / (1.0f + expf(-gv)));
+                y[e] = rbf(sg * uv);
+            }
+        }
+        if (ep.row_gate && ep.row_gate[m] == 0.0f) { for (int e = 0; e < epl; ++e) y[e] = 0.0f; }
+        if (ep.use_scale) { for (int e = 0; e < epl; ++e) y[e] = rbf(ep.scale * y[e]); }
+        const int nv = min(epl, on - c);
+        if (ep.residual) {
+            if (ep.residual_dtype == LICV_F32) {
+                const float* rp = reinterpret_cast<const float*>(ep.residual) + (int64_t)m * ep.ld_res + c;
+                if (nv == epl) {
+                    const floatx4 r0 = *reinterpret_cast<const floatx4*>(rp);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y[e] = r0[e] + y[e];
+                    if (!f32out) { const floatx4 r1 = *reinterpret_cast<const floatx4*>(rp + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) y[4 + e] = r1[e] + y[4 + e]; }
+                } else for (int e = 0; e < nv; ++e) y[e] = rp[e] + y[e];
+            } else {
+                const bf16_t* rp = reinterpret_cast<const bf16_t*>(ep.residual) + (int64_t)m * ep.ld_res + c;
+                if (nv == epl && !f32out) {
+                    const u32x4 rv = *reinterpret_cast<const u32x4*>(rp);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        y[2 * e] = rbf(__uint_as_float(rv[e] << 16) + y[2 * e]);
+                        y[2 * e + 1] = rbf(__uint_as_float(rv[e] & 0xffff0000u) + y[2 * e + 1]);
+                    }
+                } else for (int e = 0; e < nv; ++e) y[e] = rbf(bf2f(rp[e]) + y[e]);
+            }
+        }
+        if (f32out) {
+            float* cp = reinterpret_cast<float*>(C) + (int64_t)m * ldc + c;
+            if (nv == 4) *reinterpret_cast<floatx4*>(cp) = floatx4{y[0], y[1], y[2], y[3]};
+            else for (int e = 0; e < nv; ++e) cp[e] = y[e];
+        } else {
+            bf16_t* cp = reinterpret_cast<bf16_t*>(C) + (int64_t)m * ldc + c;
+            if (nv == 8) {
+                u32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (uint32_t)f2bf(y[2 * e]) | ((uint32_t)f2bf(y[2 * e + 1]) << 16);
+                *reinterpret_cast<u32x4*>(cp) = o;
+            } else for (int e = 0; e < nv; ++e) cp[e] = f2bf(y[e]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 256 x 256 x 64, 8 waves, LDS-DMA staging
+// ------------------------------------------------------------------------------------------------
+#define T256_STAGE 65536          // A 32 KiB | W 32 KiB
+#define T256_LDS 139264           // two stages (128 KiB); the staged epilogue's 256 x 528 B output image needs 132 KiB
+
+template <int ABL>     // ablation builds for timing only: 1 = no DMA in the loop, 2 = DMA + barrier only (no LDS reads / MFMA)
+__global__ __launch_bounds__(512, 2)
+void gemm_bf16_tile256_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw,
+                         void* __restrict__ C, int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n, GemmEpi ep) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // [2 stages][A 32 KiB | W 32 KiB]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably wave-uniform (LDS-DMA base)
+    const int wm = wave >> 2, wn = wave & 3;
+    int tm, tn;
+    tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * 256, n0 = tn * 256;
+
+    // ---- LDS-DMA source addresses: wave w stages rows [32w, 32w+32) of both tiles, 8 rows (1 KiB) per
+    // instruction; lane l -> row l/8, LDS position l%8, which holds source chunk (l%8) ^ (row & 7).
+    const int srow = lane >> 3, spos = lane & 7;
+    const bf16_t* srcA[4];
+    const bf16_t* srcW[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = wave * 32 + i * 8 + srow;
+        const int chunk = spos ^ (row & 7);
+        srcA[i] = A + (int64_t)min(m0 + row, M - 1) * lda + chunk * 8;
+        srcW[i] = W + (int64_t)min(n0 + row, N - 1) * ldw + chunk * 8;
+    }
+    auto stage = [&](int kt, int st) {
+        char* sa = smem + st * T256_STAGE + wave * 32 * 128;
+        char* sw = sa + 32768;
+        const int64_t koff = (int64_t)kt * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + koff),
+                                             (__attribute__((address_space(3))) void*)(sa + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[i] + koff),
+                                             (__attribute__((address_space(3))) void*)(sw + i * 1024), 16, 0, 0);
+        }
+    };
+
+    floatx4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    const int nkt = K / BK;
+    stage(0, 0);
+    const int frow = lane & 15, fchunk = lane >> 4;
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();                       // drains this wave's DMA (vmcnt(0)) + everyone done with tile kt-1
+        if (ABL != 1 && kt + 1 < nkt) stage(kt + 1, (kt + 1) & 1);
+        if (ABL == 2) continue;
+        const char* sa = smem + (kt & 1) * T256_STAGE + (wm * 128) * 128;
+        const char* sw = smem + (kt & 1) * T256_STAGE + 32768 + (wn * 64) * 128;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 fa[8], fw[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fw[j] = *reinterpret_cast<const bf16x8*>(sw + lds_off(j * 16 + frow, kk * 4 + fchunk));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sa + lds_off(i * 16 + frow, kk * 4 + fchunk));
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();                           // every wave is done with the ring before it becomes the output image
+    epilogue_staged<256, 256, 8, 8, 4>(acc, ep, C, ldc, M, N, m0, n0, wm * 128, wn * 64, wave, lane, smem);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 256 x 256 tile, K-stages of 32, 5-deep LDS ring (160 KiB), counted vmcnt: "ring" kernel
+//   * stage = A[256 x 32] | W[256 x 32] = 32 KiB, filled by 4 LDS-DMA pieces per wave (16 rows x 64 B each);
+//   * the DMA runs 3 stages ahead of the MFMAs and is never drained inside the loop: each iteration waits
+//     only for the stage whose fragments it is about to read (s_waitcnt vmcnt(8) leaves 2 stages in flight),
+//     then one raw s_barrier (no vmcnt(0) fence) publishes it to the workgroup;
+//   * fragments of stage s+1 are read into a second register set while the 32 MFMAs of stage s execute.
+//   LDS rows are 64 B; chunk position = chunk ^ (((row>>2)&1)<<1) keeps ds_read_b128 conflict-free.
+// ------------------------------------------------------------------------------------------------
+#define RING_STAGES 5
+#define RING_STAGE_BYTES 32768
+
+__device__ __forceinline__ int ring_off(int row, int chunk) {      // bytes within a [256][32] bf16 half-stage
+    return row * 64 + ((chunk ^ (((row >> 2) & 1) << 1)) << 4);
+}
+
+__device__ __forceinline__ void wait_vmcnt(int n) {                 // n is wave-uniform: 12, 8, 4 or 0
+    if (n >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (n == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+__global__ __launch_bounds__(512, 2)
+void gemm_bf16_ring_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw,
+                      void* __restrict__ C, int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n, GemmEpi ep) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // [5 stages][A 16 KiB | W 16 KiB]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    int tm, tn;
+    tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * 256, n0 = tn * 256;
+
+    // DMA sources: wave w fills rows [32w, 32w+32) of both operands, 16 rows per piece
+    const bf16_t* srcA[2];
+    const bf16_t* srcW[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = wave * 32 + i * 16 + (lane >> 2);
+        const int chunk = (lane & 3) ^ (((row >> 2) & 1) << 1);
+        srcA[i] = A + (int64_t)min(m0 + row, M - 1) * lda + chunk * 8;
+        srcW[i] = W + (int64_t)min(n0 + row, N - 1) * ldw + chunk * 8;
+    }
+    auto issue = [&](int s) {
+        char* sa = smem + (s % RING_STAGES) * RING_STAGE_BYTES + wave * 32 * 64;
+        char* sw = sa + 16384;
+        const int64_t koff = (int64_t)s * 32;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + koff),
+                                             (__attribute__((address_space(3))) void*)(sa + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[i] + koff),
+                                             (__attribute__((address_space(3))) void*)(sw + i * 1024), 16, 0, 0);
+        }
+    };
+
+    floatx4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    const int ns = K / 32;                                   // >= 4 (host guarantees K >= 128)
+    const int frow = lane & 15, fchunk = lane >> 4;
+    const int fo = ring_off(frow, fchunk);                   // (row & 15) part of the offset is lane constant
+    auto read_frags = [&](int s, bf16x8 (&fa)[8], bf16x8 (&fw)[4]) {
+        const char* sa = smem + (s % RING_STAGES) * RING_STAGE_BYTES + (wm * 128) * 64 + fo;
+        const char* sw = smem + (s % RING_STAGES) * RING_STAGE_BYTES + 16384 + (wn * 64) * 64 + fo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fw[j] = *reinterpret_cast<const bf16x8*>(sw + j * 16 * 64);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 64);
+    };
+    auto mma = [&](bf16x8 (&fa)[8], bf16x8 (&fw)[4]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
+    };
+
+    // prologue: 4 stages in flight, stage 0 published, its fragments in registers
+    issue(0); issue(1); issue(2); issue(3);
+    wait_vmcnt(12);
+    __builtin_amdgcn_s_barrier();
+    bf16x8 fa0[8], fw0[4], fa1[8], fw1[4];
+    read_frags(0, fa0, fw0);
+
+    // iteration s: publish stage s+1, refill the slot stage s-1 used, prefetch fragments of s+1, MFMAs of s
+    auto step = [&](int s, bf16x8 (&fac)[8], bf16x8 (&fwc)[4], bf16x8 (&fan)[8], bf16x8 (&fwn)[4]) {
+        if (s + 1 < ns) {
+            wait_vmcnt(4 * min(2, ns - 2 - s));            // loads issued after stage s+1: stages s+2, s+3 (if they exist)
+            __builtin_amdgcn_s_barrier();
+            if (s + 4 < ns) issue(s + 4);
+            read_frags(s + 1, fan, fwn);
+        }
+        mma(fac, fwc);
+    };
+    for (int s = 0; s < ns; s += 2) {
+        step(s, fa0, fw0, fa1, fw1);
+        step(s + 1, fa1, fw1, fa0, fw0);
+    }
+    __syncthreads();                           // every wave is done with the ring before it becomes the output image
+    epilogue_staged<256, 256, 8, 8, 4>(acc, ep, C, ldc, M, N, m0, n0, wm * 128, wn * 64, wave, lane, smem);
+}
+
+// ------------------------------------------------------------------------------------------------
+// "ping-pong" kernel: same 256 x 256 tile / 32-deep K-stages / 5-slot LDS-DMA ring as the ring kernel, but the
+// two waves that share a SIMD (w and w+4) run half a stage apart: while one issues its 32 MFMAs (COMPUTE
+// phase, registers only) its partner runs its LOAD phase (12 fragment ds_reads of its next stage, 4 LDS-DMA
+// pieces for the stage 4 ahead, the counted vmcnt wait that retires the NEXT stage's pieces, lgkmcnt(0)).
+// One s_barrier per half-stage keeps the two groups complementary, publishes landed stages, and orders slot
+// reuse: a slot is refilled only after a barrier that follows the lgkmcnt(0) of its last readers.
+// ------------------------------------------------------------------------------------------------
+template <int ABL>     // ABL 1: timing-only build without the epilogue
+__global__ __launch_bounds__(512, 2)
+void gemm_bf16_pingpong_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw,
+                          void* __restrict__ C, int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n, GemmEpi ep) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // [5 stages][A 16 KiB | W 16 KiB]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;                         // group = wm: waves 0-3 lead, 4-7 trail
+    int tm, tn;
+    tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * 256, n0 = tn * 256;
+
+    const bf16_t* srcA[2];
+    const bf16_t* srcW[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = wave * 32 + i * 16 + (lane >> 2);
+        const int chunk = (lane & 3) ^ (((row >> 2) & 1) << 1);
+        srcA[i] = A + (int64_t)min(m0 + row, M - 1) * lda + chunk * 8;
+        srcW[i] = W + (int64_t)min(n0 + row, N - 1) * ldw + chunk * 8;
+    }
+    auto issue = [&](int s) {
+        char* sa = smem + (s % RING_STAGES) * RING_STAGE_BYTES + wave * 32 * 64;
+        char* sw = sa + 16384;
+        const int64_t koff = (int64_t)s * 32;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + koff),
+                                             (__attribute__((address_space(3))) void*)(sa + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[i] + koff),
+                                             (__attribute__((address_space(3))) void*)(sw + i * 1024), 16, 0, 0);
+        }
+    };
+
+    floatx4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    const int ns = K / 32;                                   // >= 4 (host guarantees K >= 128)
+    const int fo = ring_off(lane & 15, lane >> 4);
+    bf16x8 fa[8], fw[4];
+
+    issue(0); issue(1); issue(2); issue(3);
+    wait_vmcnt(12);                                          // my pieces of stage 0 have landed
+    __builtin_amdgcn_s_barrier();                            // stage 0 published
+    if (wm == 1) __builtin_amdgcn_s_barrier();               // trailing group starts half a stage later
+
+    for (int s = 0; s < ns; ++s) {
+        // ---- LOAD phase (partner computes)
+        {
+            const char* sa = smem + (s % RING_STAGES) * RING_STAGE_BYTES + (wm * 128) * 64 + fo;
+            const char* sw = smem + (s % RING_STAGES) * RING_STAGE_BYTES + 16384 + (wn * 64) * 64 + fo;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fw[j] = *reinterpret_cast<const bf16x8*>(sw + j * 16 * 64);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 64);
+            if (s + 4 < ns) issue(s + 4);
+            wait_vmcnt(4 * max(0, min(3, ns - 2 - s)));      // retire my pieces of stage s+1; later stages stay in flight
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_s_barrier();
+        // ---- COMPUTE phase (partner loads)
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();               // leading group: match the barrier count
+    if (ABL == 1) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(acc[i][j]));
+        return;
+    }
+    epilogue_staged<256, 256, 8, 8, 4>(acc, ep, C, ldc, M, N, m0, n0, wm * 128, wn * 64, wave, lane, smem);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 128 x 128 x 64, 4 waves, register staged (general shapes)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2)
+void gemm_bf16_tile128_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw,
+                         void* __restrict__ C, int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n, GemmEpi ep) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // [2 stages][A 16 KiB | W 16 KiB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    int tm, tn;
+    tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * 128, n0 = tn * 128;
+
+    // buffer descriptors: out-of-range rows read as 0; K tail handled through the offset
     const int64_t a_bytes = (int64_t)(M - m0) * lda * 2, w_bytes = (int64_t)(N - n0) * ldw * 2;
     const int lim = 0x7ffffff0;
     const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (int64_t)m0 * lda), 0, (int)(a_bytes < lim ? a_bytes : lim), 0x00020000);
     const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (int64_t)n0 * ldw), 0, (int)(w_bytes < lim ? w_bytes : lim), 0x00020000);
 
-    // staging map: thread -> (row = tid/8 + 32*i, chunk = tid%8), i = 0..3, for A and for W
-    const int srow = tid >> 3, schunk = tid & 7;
+    const int srow = tid >> 3, schunk = tid & 7;      // thread -> (row = tid/8 + 32*i, chunk = tid%8)
     u32x4 ra[4], rw[4];
     auto load_tile = [&](int kt) {
         const int k = kt * BK + schunk * 8;
@@ -92,8 +576,8 @@ void gemm_bf16_tile128_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t
             rw[i] = __builtin_amdgcn_raw_buffer_load_b128(rsW, offW, 0, 0);
         }
     };
-    auto store_tile = [&](int stage) {
-        char* sa = smem + stage * 32768;
+    auto store_tile = [&](int st) {
+        char* sa = smem + st * 32768;
         char* sw = sa + 16384;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -137,67 +621,7 @@ void gemm_bf16_tile128_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t
         if (kt + 1 < nkt) store_tile(cur ^ 1);
         __syncthreads();
     }
-
-    // ---- epilogue: lane holds C[m = .. + (lane&15)][n = .. + (lane>>4)*4 + r], r = 0..3
-    const int rbase = m0 + wm * 64 + (lane & 15);
-    const int cq = (lane >> 4) * 4;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = rbase + i * 16;
-        if (m >= M) continue;
-        const float gate = ep.row_gate ? ep.row_gate[m] : 1.0f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (ep.swiglu && (j & 1)) continue;
-            const int ncol = n0 + wn * 64 + j * 16 + cq;       // column in the (packed) N space
-            if (ncol >= N) continue;
-            float y[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = acc[i][j][r];
-                if (ep.bias) v += (ncol + r < N) ? bf2f(ep.bias[ncol + r]) : 0.f;
-                v = rbf(v);
-                if (ep.act) v = rbf(act_apply(v, ep.act));
-                if (ep.swiglu) {
-                    const float u = rbf(acc[i][j + 1][r]);
-                    const float s = rbf(v / (1.0f + expf(-v)));
-                    v = rbf(s * u);
-                }
-                if (ep.row_gate && gate == 0.0f) v = 0.0f;
-                if (ep.use_scale) v = rbf(ep.scale * v);
-                y[r] = v;
-            }
-            // output column: swiglu halves the column space (16-wide gate/up blocks alternate)
-            const int oc = ep.swiglu ? ((n0 + wn * 64) >> 1) + (j >> 1) * 16 + cq : ncol;
-            const int on = ep.swiglu ? (N >> 1) : N;
-            const int nvalid = min(4, on - oc);
-            if (ep.residual) {
-                if (ep.residual_dtype == LICV_F32) {
-                    const float* rp = reinterpret_cast<const float*>(ep.residual) + (int64_t)m * ep.ld_res + oc;
-                    if (nvalid == 4) { const floatx4 rv = *reinterpret_cast<const floatx4*>(rp);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) y[r] = rv[r] + y[r]; }
-                    else for (int r = 0; r < nvalid; ++r) y[r] = rp[r] + y[r];
-                } else {
-                    const bf16_t* rp = reinterpret_cast<const bf16_t*>(ep.residual) + (int64_t)m * ep.ld_res + oc;
-                    for (int r = 0; r < nvalid; ++r) y[r] = rbf(bf2f(rp[r]) + y[r]);
-                }
-            }
-            if (ep.out_dtype == LICV_F32) {
-                float* cp = reinterpret_cast<float*>(C) + (int64_t)m * ldc + oc;
-                if (nvalid == 4) *reinterpret_cast<floatx4*>(cp) = floatx4{y[0], y[1], y[2], y[3]};
-                else for (int r = 0; r < nvalid; ++r) cp[r] = y[r];
-            } else {
-                bf16_t* cp = reinterpret_cast<bf16_t*>(C) + (int64_t)m * ldc + oc;
-                if (nvalid == 4) {
-                    uint2 u;
-                    u.x = (uint32_t)f2bf(y[0]) | ((uint32_t)f2bf(y[1]) << 16);
-                    u.y = (uint32_t)f2bf(y[2]) | ((uint32_t)f2bf(y[3]) << 16);
-                    *reinterpret_cast<uint2*>(cp) = u;
-                } else for (int r = 0; r < nvalid; ++r) cp[r] = f2bf(y[r]);
-            }
-        }
-    }
+    epilogue_staged<128, 128, 4, 4, 4>(acc, ep, C, ldc, M, N, m0, n0, wm * 64, wn * 64, wave, lane, smem);
 }
 
 // gate/up rows interleaved in blocks of 16: packed[32b + i] = gate[16b + i], packed[32b + 16 + i] = up[16b + i]
@@ -211,6 +635,9 @@ void pack_gate_up_k(const bf16_t* __restrict__ g, const bf16_t* __restrict__ u, 
         reinterpret_cast<uint4*>(out + prow * K)[c] = reinterpret_cast<const uint4*>(src)[c];
     }
 }
+
+static int g_force_kernel = 0;     // 0 auto, 1 tile128, 2 tile256 (tests / A-B timing)
+extern "C" int licv_gemm_select(int which) { g_force_kernel = which; return LICV_OK; }
 
 extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
                               int64_t M, int64_t N, int64_t K, const licv_gemm_epilogue* e, void* stream) {
@@ -231,15 +658,45 @@ extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
     ep.bias = (const bf16_t*)e->bias_bf16; ep.row_gate = e->row_gate; ep.residual = e->residual;
     ep.residual_dtype = e->residual_dtype; ep.ld_res = e->ld_res; ep.act = e->act; ep.swiglu = e->swiglu;
     ep.use_scale = e->use_scale; ep.scale = e->scale; ep.out_dtype = e->out_dtype;
-    const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (int)((N + BN - 1) / BN);
-    const size_t lds = 2 * 32768;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm_bf16_tile128_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)gemm_bf16_tile128_k, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        hipFuncSetAttribute((const void*)gemm_bf16_pingpong_k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
+        hipFuncSetAttribute((const void*)gemm_bf16_pingpong_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
+        hipFuncSetAttribute((const void*)gemm_bf16_ring_k, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
+        hipFuncSetAttribute((const void*)gemm_bf16_tile256_k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, T256_LDS);
+        hipFuncSetAttribute((const void*)gemm_bf16_tile256_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, T256_LDS);
+        hipFuncSetAttribute((const void*)gemm_bf16_tile256_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, T256_LDS);
         attr_set = true;
     }
-    gemm_bf16_tile128_k<<<dim3(tiles_m * tiles_n), dim3(GEMM_THREADS), lds, (hipStream_t)stream>>>(
-        (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep);
+    const bool can256 = (K % BK == 0);
+    const bool big = can256 && M >= 512 && N >= 256;
+    const bool use256 = g_force_kernel >= 2 ? can256 : (g_force_kernel == 1 ? false : big);
+    if (use256) {
+        const int tiles_m = (int)((M + 255) / 256), tiles_n = (int)((N + 255) / 256);
+        const dim3 grid(tiles_m * tiles_n), block(512);
+#define LAUNCH256(ABL) gemm_bf16_tile256_k<ABL><<<grid, block, T256_LDS, (hipStream_t)stream>>>( \
+            (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep)
+        if (g_force_kernel == 3) LAUNCH256(1); else if (g_force_kernel == 4) LAUNCH256(2);
+        else if (g_force_kernel == 5 && K >= 128)
+            gemm_bf16_ring_k<<<grid, block, RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>(
+                (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep);
+        else if (g_force_kernel == 7 && K >= 128)
+            gemm_bf16_pingpong_k<1><<<grid, block, RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>(
+                (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep);
+        else if (g_force_kernel == 6 && K >= 128)
+            gemm_bf16_pingpong_k<0><<<grid, block, RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>(
+                (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep);
+        else if (g_force_kernel == 0 && K >= 128)
+            gemm_bf16_pingpong_k<0><<<grid, block, RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>(
+                (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep);
+        else LAUNCH256(0);
+#undef LAUNCH256
+    } else {
+        const int tiles_m = (int)((M + 127) / 128), tiles_n = (int)((N + 127) / 128);
+        gemm_bf16_tile128_k<<<dim3(tiles_m * tiles_n), dim3(256), 65536, (hipStream_t)stream>>>(
+            (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep);
+    }
     LICV_LAUNCH_CHECK();
     return LICV_OK;
 }

@@ -219,6 +219,41 @@ def test_gemm_swiglu_fused_matches_unfused_and_oracle():
     close_bf16(o.swiglu(gu), ref, exact_frac=0.98)
 
 
+@pytest.mark.parametrize("variant", ["plain", "bias_gelu", "swiglu", "res_f32", "res_bf16_gate_scale", "f32_out"])
+@pytest.mark.parametrize("M,N,K", [(700, 544, 192), (512, 256, 128), (1030, 1280, 1280)])
+def test_gemm_large_tile_kernels_match_general_kernel(variant, M, N, K):
+    """The 256x256 LDS-DMA kernels (ping-pong: select 6, single-barrier: select 2) against the general 128x128
+    kernel (select 1): identical accumulation order -> bit-identical outputs, for every fused epilogue and with
+    ragged M / N edges."""
+    from licv import _lib
+    o = ops()
+    a = torch.randn(M, K, generator=g(33)).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(N, K, generator=g(34)) * 0.05).to(torch.bfloat16).to(DEV)
+    kw = {}
+    if variant == "bias_gelu":
+        kw = dict(bias=(torch.randn(N, generator=g(35)) * 0.1).to(torch.bfloat16).to(DEV), act="gelu")
+    elif variant == "swiglu":
+        kw = dict(swiglu=True)
+    elif variant == "res_f32":
+        kw = dict(residual=torch.randn(M, N, generator=g(36)).to(DEV))
+    elif variant == "res_bf16_gate_scale":
+        kw = dict(residual=torch.randn(M, N, generator=g(36)).to(torch.bfloat16).to(DEV), scale=0.37,
+                  row_gate=(torch.rand(M, generator=g(37)) > 0.3).float().to(DEV))
+    elif variant == "f32_out":
+        kw = dict(out_dtype=torch.float32)
+    outs = {}
+    try:
+        for sel in (1, 2, 6):
+            _lib.lib().licv_gemm_select(sel)
+            outs[sel] = o.linear(a, w, **kw).clone()
+    finally:
+        _lib.lib().licv_gemm_select(0)
+    assert torch.equal(outs[1], outs[2]) and torch.equal(outs[1], outs[6])
+    ref = (a[:32].float() @ w.float().t())
+    if variant == "plain":
+        assert (outs[6][:32].float() - ref).abs().max() <= 2 ** -7 * ref.abs().max()
+
+
 def test_gemm_linearity_at_headline_shape():
     # size-independent property at the full decoder shape (M = 8*800): f(a1 + a2) == f(a1) + f(a2) in fp32 out
     M, N, K = 6400, 4096, 4096
