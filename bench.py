@@ -171,7 +171,7 @@ def main():
         "dtype": "bf16", "data": "synthetic (random-init Idefics-9B weights, seeded image+text batches)",
         "config": {"workload": args.workload, "arch": preset, "questions_per_gpu": B, "seq_len": S, "images_per_question": n_img,
                    "hooked_layers": 0 if args.no_hooks else arch.num_layers, "parallelism": f"dp{world}"},
-        "roofline": {"bound": "mfma", "kernel": "gemm_bf16_tile128_k", "achieved": fl / tg / 1e12 if tg else None,
+        "roofline": {"bound": "mfma", "kernel": "gemm_bf16_pingpong_k (256x256 LDS-DMA ring; small shapes: gemm_bf16_tile128_k)", "achieved": fl / tg / 1e12 if tg else None,
                      "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": (fl / tg / 1e12) / PEAK_BF16_TFLOPS if tg else None,
                      "traffic": None, "launches_per_step": ng // max(args.steps, 1),
                      "avg_launch_us": 1e6 * tg / ng if ng else None, "gemm_share_of_step": tg / elapsed if elapsed else None},

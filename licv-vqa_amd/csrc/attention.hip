@@ -49,7 +49,8 @@ void attn_fwd_k(AttnP a) {
     constexpr int KLD = (ATT_KB * KCH + 255) / 256, VLD = (ATT_KB * VCH + 255) / 256;
     __shared__ __attribute__((aligned(16))) char sK[ATT_KB * KSTR];
     __shared__ __attribute__((aligned(16))) char sV[ATT_KB * VSTR];
-    __shared__ int sValid[ATT_KB];
+    __shared__ __attribute__((aligned(16))) int sValid[ATT_KB];
+    __shared__ unsigned long long sImgUsed[4];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, ql = lane & 15;
@@ -80,6 +81,26 @@ void attn_fwd_k(AttnP a) {
     int kend = a.Sk;
     if (a.mask_mode == 1) kend = min(a.Sk, q0 + ATT_QB + coff);      // keys beyond the last query's diagonal
     const int ntiles = (kend + ATT_KB - 1) / ATT_KB;
+    const bool wave_active = (q0 + wave * 16) < a.Sq;      // waves past the last query only help with the loads
+
+    // image-mask mode with whole tiles inside one image: a tile is visited only if some query of this
+    // workgroup attends that image (a token attends ONE image of ~33: >95 % of the key tiles drop out)
+    const int32_t* imrow = (a.mask_mode == 3 && qok) ? a.img_mask + ((int64_t)b * a.Sq + qrow) * a.n_img : nullptr;
+    const bool img_uniform = (a.mask_mode == 3) && (a.img_len % ATT_KB == 0);
+    const bool img_skip = img_uniform && a.n_img <= 64;
+    unsigned long long used = ~0ull;
+    if (img_skip) {
+        unsigned long long mine = 0;
+        for (int n = 0; n < a.n_img; ++n) {
+            const bool hit = imrow && imrow[n] != 0;
+            if (__any(hit)) mine |= 1ull << n;
+        }
+        if (lane == 0) sImgUsed[wave] = mine;
+        __syncthreads();
+        used = sImgUsed[0] | sImgUsed[1] | sImgUsed[2] | sImgUsed[3];
+    }
+    auto tile_live = [&](int t) -> bool { return !img_skip || ((used >> ((t * ATT_KB) / a.img_len)) & 1ull); };
+    auto next_tile = [&](int t) -> int { while (t < ntiles && !tile_live(t)) ++t; return t; };
 
     const bf16_t* kbase = a.k + (int64_t)b * a.kv_bs + (int64_t)kvh * a.hd;
     const bf16_t* vbase = a.v + (int64_t)b * a.kv_bs + (int64_t)kvh * a.hd;
@@ -131,25 +152,28 @@ void attn_fwd_k(AttnP a) {
     for (int i = 0; i < DPV / 16; ++i) oacc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.f;
 
-    if (ntiles > 0) { load_tile(0); store_tile(); }
+    int t = next_tile(0);
+    if (t < ntiles) { load_tile(t); store_tile(); }
     __syncthreads();
 
-    const int32_t* imrow = (a.mask_mode == 3 && qok) ? a.img_mask + ((int64_t)b * a.Sq + qrow) * a.n_img : nullptr;
-    const bool img_uniform = (a.mask_mode == 3) && (a.img_len % ATT_KB == 0);
-
-    for (int t = 0; t < ntiles; ++t) {
-        if (t + 1 < ntiles) load_tile(t + 1);
+    while (t < ntiles) {
+        const int tn = next_tile(t + 1);
+        if (tn < ntiles) load_tile(tn);
         const int key0 = t * ATT_KB;
+        const int nst = min(4, (min(a.Sk, kend) - key0 + 15) >> 4);      // 16-key sub-tiles that hold real keys
+        if (wave_active) {
 
         // ---- S^T tile: 4 sub-tiles of 16 keys; lane holds keys key0 + st*16 + 4g + r for query ql
         floatx4 s[4];
 #pragma unroll
         for (int st = 0; st < 4; ++st) {
             s[st] = floatx4{0.f, 0.f, 0.f, 0.f};
+            if (st < nst) {
 #pragma unroll
-            for (int ks = 0; ks < DPK / 32; ++ks) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (st * 16 + ql) * KSTR + (ks * 32 + g * 8) * 2);
-                s[st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[st], 0, 0, 0);
+                for (int ks = 0; ks < DPK / 32; ++ks) {
+                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (st * 16 + ql) * KSTR + (ks * 32 + g * 8) * 2);
+                    s[st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[st], 0, 0, 0);
+                }
             }
         }
         // ---- scale + mask
@@ -201,6 +225,7 @@ void attn_fwd_k(AttnP a) {
         for (int dt = 0; dt < DPV / 16; ++dt) {
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
+                if (2 * s2 >= nst) continue;                 // both 16-key halves of this k-step are padding
                 const char* p0 = sV + ((2 * s2) * 16 + g * 4 + (ql >> 2)) * VSTR + (dt * 16 + (ql & 3) * 4) * 2;
                 const bf16x4 lo = lds_read_tr(p0);
                 const bf16x4 hi = lds_read_tr(p0 + 16 * VSTR);
@@ -210,9 +235,11 @@ void attn_fwd_k(AttnP a) {
                 oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[s2], oacc[dt], 0, 0, 0);
             }
         }
+        }   // wave_active
         __syncthreads();                                   // everyone done reading this tile
-        if (t + 1 < ntiles) store_tile();
+        if (tn < ntiles) store_tile();
         __syncthreads();
+        t = tn;
     }
 
     // ---- epilogue: O[b, qrow, head*hd + d], lane holds d = dt*16 + 4g + r

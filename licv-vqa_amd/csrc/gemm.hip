@@ -37,15 +37,30 @@ struct GemmEpi {
     int out_dtype;
 };
 
+// Activations evaluated on bf16-rounded inputs and rounded to bf16 again by the caller, so ~1e-6 relative
+// accuracy is ample; the libm erff/tanhf/expf bodies are 3-5x more VALU work (the GELU epilogue of the ViT fc1
+// GEMM measured 2x the MFMA time with erff).
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float gelu_erf_fast(float x) {
+    // 0.5 x (1 + erf(x/sqrt2)); erfc(|z|) by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7), used on the side where
+    // 1 + erf would cancel, so small outputs keep their relative accuracy
+    const float z = x * 0.70710678118654752440f, az = fabsf(z);
+    const float t = fast_rcp(1.0f + 0.3275911f * az);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float ec = poly * __expf(-az * az);                 // erfc(|z|)
+    return 0.5f * x * (z >= 0.f ? 2.0f - ec : ec);
+}
 __device__ __forceinline__ float act_apply(float y, int act) {
     switch (act) {
-        case 1: return 0.5f * y * (1.0f + erff(y * 0.70710678118654752440f));
-        case 2: { const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-                  return 0.5f * y * (1.0f + tanhf(k0 * (y + k1 * y * y * y))); }
+        case 1: return gelu_erf_fast(y);
+        case 2: { const float u = 0.7978845608028654f * (y + 0.044715f * y * y * y);
+                  const float th = 1.0f - 2.0f * fast_rcp(1.0f + __expf(2.0f * u));      // tanh(u)
+                  return 0.5f * y * (1.0f + th); }
         case 3: return fmaxf(y, 0.0f);
         default: return y;
     }
 }
+__device__ __forceinline__ float silu_fast(float v) { return v * fast_rcp(1.0f + __expf(-v)); }
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {       // bytes within a [rows][64] bf16 tile
     return row * 128 + ((chunk ^ (row & 7)) << 4);
@@ -71,78 +86,109 @@ __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
 }
 
-// Epilogue of one 16-row block of a wave: acc[j][r] = C[m][col0 + j*16 + (lane>>4)*4 + r]
-template <int NT>
-__device__ __forceinline__ void epilogue_row(floatx4 (&acc)[NT], const GemmEpi& ep, void* __restrict__ C, int64_t ldc,
-                                             int M, int N, int m, int col0, int cq) {
-    if (m >= M) return;
-    const float gate = ep.row_gate ? ep.row_gate[m] : 1.0f;
-    static_for<0, NT>([&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        if (ep.swiglu && (j & 1)) return;
-        const int ncol = col0 + j * 16 + cq;               // column in the (packed) N space
-        if (ncol >= N) return;
-        float y[4];
+// Phase B of the staged epilogue (see below): a compact run-time loop over the rows of the LDS image.
+template <int TM, int TN, int NWAVES, int EPL>            // EPL: output elements per lane (8 = bf16 out, 4 = fp32 out)
+__device__ __noinline__ void epilogue_rows(const GemmEpi& ep, void* __restrict__ C, int64_t ldc, int M, int N, int m0, int n0,
+                                           int wave, int lane, const char* smem) {
+    constexpr int YS = TN * 2 + 16;
+    constexpr bool F32 = (EPL == 4);
+    const bool sw = ep.swiglu != 0;
+    const int tcols = sw ? TN / 2 : TN;                   // output columns this tile produces
+    const int on = sw ? (N >> 1) : N;
+    const int oc0 = sw ? (n0 >> 1) : n0;
+    const int lpr = tcols / EPL;                          // lanes per row
+    const int rpi = 64 / lpr;                             // rows per wave-instruction
+    const int lr = lane / lpr, lcol = (lane % lpr) * EPL;
+    for (int rb = wave * rpi; rb < TM; rb += NWAVES * rpi) {
+        const int row = rb + lr;
+        const int m = m0 + row;
+        const int c = oc0 + lcol;
+        if (m >= M || c >= on) continue;
+        const char* yrow = smem + row * YS;
+        float y[EPL];
+        if (!sw) {
+            if (F32) {
+                const uint2 v = *reinterpret_cast<const uint2*>(yrow + lcol * 2);
+                y[0] = __uint_as_float(v.x << 16); y[1] = __uint_as_float(v.x & 0xffff0000u);
+                y[2] = __uint_as_float(v.y << 16); y[3] = __uint_as_float(v.y & 0xffff0000u);
+            } else {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(yrow + lcol * 2);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float v = acc[j][r];
-            if (ep.bias) v += (ncol + r < N) ? bf2f(ep.bias[ncol + r]) : 0.f;
-            v = rbf(v);
-            if (ep.act) v = rbf(act_apply(v, ep.act));
-            if (ep.swiglu) {
-                const float u = rbf(acc[(j + 1) % NT][r]);
-                const float s = rbf(v / (1.0f + expf(-v)));
-                v = rbf(s * u);
+                for (int e = 0; e < 4; ++e) { y[2 * e] = __uint_as_float(v[e] << 16); y[2 * e + 1] = __uint_as_float(v[e] & 0xffff0000u); }
             }
-            if (ep.row_gate && gate == 0.0f) v = 0.0f;
-            if (ep.use_scale) v = rbf(ep.scale * v);
-            y[r] = v;
+            if (ep.act) {
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) y[e] = rbf(act_apply(y[e], ep.act));
+            }
+        } else {
+            // output col lcol..lcol+EPL-1 lives in packed cols (lcol/16)*32 + lcol%16 (gate) and +16 (up)
+            const int pc = (lcol >> 4) * 32 + (lcol & 15);
+            float gv[EPL], uv[EPL];
+            if (F32) {
+                const uint2 g2 = *reinterpret_cast<const uint2*>(yrow + pc * 2);
+                const uint2 u2 = *reinterpret_cast<const uint2*>(yrow + (pc + 16) * 2);
+                gv[0] = __uint_as_float(g2.x << 16); gv[1] = __uint_as_float(g2.x & 0xffff0000u);
+                gv[2] = __uint_as_float(g2.y << 16); gv[3] = __uint_as_float(g2.y & 0xffff0000u);
+                uv[0] = __uint_as_float(u2.x << 16); uv[1] = __uint_as_float(u2.x & 0xffff0000u);
+                uv[2] = __uint_as_float(u2.y << 16); uv[3] = __uint_as_float(u2.y & 0xffff0000u);
+            } else {
+                const u32x4 g4 = *reinterpret_cast<const u32x4*>(yrow + pc * 2);
+                const u32x4 u4 = *reinterpret_cast<const u32x4*>(yrow + (pc + 16) * 2);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    gv[2 * e] = __uint_as_float(g4[e] << 16); gv[2 * e + 1] = __uint_as_float(g4[e] & 0xffff0000u);
+                    uv[2 * e] = __uint_as_float(u4[e] << 16); uv[2 * e + 1] = __uint_as_float(u4[e] & 0xffff0000u);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) y[e] = rbf(rbf(silu_fast(gv[e])) * uv[e]);
         }
-        // output column: swiglu halves the column space (16-wide gate/up blocks alternate)
-        const int oc = ep.swiglu ? (col0 >> 1) + (j >> 1) * 16 + cq : ncol;
-        const int on = ep.swiglu ? (N >> 1) : N;
-        const int nvalid = min(4, on - oc);
+        if (ep.row_gate && ep.row_gate[m] == 0.0f) {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) y[e] = 0.0f;
+        }
+        if (ep.use_scale) {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) y[e] = rbf(ep.scale * y[e]);
+        }
+        const int nv = min(EPL, on - c);
         if (ep.residual) {
             if (ep.residual_dtype == LICV_F32) {
-                const float* rp = reinterpret_cast<const float*>(ep.residual) + (int64_t)m * ep.ld_res + oc;
-                if (nvalid == 4) { const floatx4 rv = *reinterpret_cast<const floatx4*>(rp);
+                const float* rp = reinterpret_cast<const float*>(ep.residual) + (int64_t)m * ep.ld_res + c;
+                if (nv == EPL) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) y[r] = rv[r] + y[r]; }
-                else for (int r = 0; r < nvalid; ++r) y[r] = rp[r] + y[r];
+                    for (int q = 0; q < EPL / 4; ++q) {
+                        const floatx4 rv = *reinterpret_cast<const floatx4*>(rp + 4 * q);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) y[4 * q + e] = rv[e] + y[4 * q + e];
+                    }
+                } else for (int e = 0; e < nv; ++e) y[e] = rp[e] + y[e];
             } else {
-                const bf16_t* rp = reinterpret_cast<const bf16_t*>(ep.residual) + (int64_t)m * ep.ld_res + oc;
-                if (nvalid == 4) { const uint2 u = *reinterpret_cast<const uint2*>(rp);
-                    y[0] = rbf(__uint_as_float(u.x << 16) + y[0]); y[1] = rbf(__uint_as_float(u.x & 0xffff0000u) + y[1]);
-                    y[2] = rbf(__uint_as_float(u.y << 16) + y[2]); y[3] = rbf(__uint_as_float(u.y & 0xffff0000u) + y[3]); }
-                else for (int r = 0; r < nvalid; ++r) y[r] = rbf(bf2f(rp[r]) + y[r]);
+                const bf16_t* rp = reinterpret_cast<const bf16_t*>(ep.residual) + (int64_t)m * ep.ld_res + c;
+                if (nv == EPL && !F32) {
+                    const u32x4 rv = *reinterpret_cast<const u32x4*>(rp);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        y[2 * e] = rbf(__uint_as_float(rv[e] << 16) + y[2 * e]);
+                        y[2 * e + 1] = rbf(__uint_as_float(rv[e] & 0xffff0000u) + y[2 * e + 1]);
+                    }
+                } else for (int e = 0; e < nv; ++e) y[e] = rbf(bf2f(rp[e]) + y[e]);
             }
         }
-        if (ep.out_dtype == LICV_F32) {
-            float* cp = reinterpret_cast<float*>(C) + (int64_t)m * ldc + oc;
-            if (nvalid == 4) *reinterpret_cast<floatx4*>(cp) = floatx4{y[0], y[1], y[2], y[3]};
-            else for (int r = 0; r < nvalid; ++r) cp[r] = y[r];
+        if (F32) {
+            float* cp = reinterpret_cast<float*>(C) + (int64_t)m * ldc + c;
+            if (nv == 4) *reinterpret_cast<floatx4*>(cp) = floatx4{y[0], y[1], y[2], y[3]};
+            else for (int e = 0; e < nv; ++e) cp[e] = y[e];
         } else {
-            bf16_t* cp = reinterpret_cast<bf16_t*>(C) + (int64_t)m * ldc + oc;
-            if (nvalid == 4) {
-                uint2 u;
-                u.x = (uint32_t)f2bf(y[0]) | ((uint32_t)f2bf(y[1]) << 16);
-                u.y = (uint32_t)f2bf(y[2]) | ((uint32_t)f2bf(y[3]) << 16);
-                *reinterpret_cast<uint2*>(cp) = u;
-            } else for (int r = 0; r < nvalid; ++r) cp[r] = f2bf(y[r]);
+            bf16_t* cp = reinterpret_cast<bf16_t*>(C) + (int64_t)m * ldc + c;
+            if (nv == 8) {
+                u32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (uint32_t)f2bf(y[2 * e]) | ((uint32_t)f2bf(y[2 * e + 1]) << 16);
+                *reinterpret_cast<u32x4*>(cp) = o;
+            } else for (int e = 0; e < nv; ++e) cp[e] = f2bf(y[e]);
         }
-    });
-}
-
-// Epilogue for a wave holding MT x NT accumulators: acc[i][j][r] = C[row0 + i*16 + (lane&15)][col0 + j*16 + (lane>>4)*4 + r]
-template <int MT, int NT>
-__device__ __forceinline__ void epilogue(floatx4 (&acc)[MT][NT], const GemmEpi& ep, void* __restrict__ C, int64_t ldc,
-                                         int M, int N, int row0, int col0, int lane) {
-    const int rbase = row0 + (lane & 15);
-    const int cq = (lane >> 4) * 4;
-    static_for<0, MT>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        epilogue_row<NT>(acc[i], ep, C, ldc, M, N, rbase + i * 16, col0, cq);
-    });
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -184,85 +230,8 @@ __device__ __forceinline__ void epilogue_staged(floatx4 (&acc)[MT][NT], const Ge
     }
     __syncthreads();
     // ---- phase B: compact loop over rows; lane -> 8 (bf16 out) or 4 (fp32 out) consecutive OUTPUT columns
-    const bool sw = ep.swiglu != 0;
-    const int tcols = sw ? TN / 2 : TN;                   // output columns this tile produces
-    const int on = sw ? (N >> 1) : N;
-    const int oc0 = sw ? (n0 >> 1) : n0;
-    const bool f32out = ep.out_dtype == LICV_F32;
-    const int epl = f32out ? 4 : 8;                       // elements per lane
-    const int lpr = tcols / epl;                          // lanes per row
-    const int rpi = 64 / lpr;                             // rows per wave-instruction
-    const int lr = lane / lpr, lcol = (lane % lpr) * epl;
-    for (int rb = wave * rpi; rb < TM; rb += NWAVES * rpi) {
-        const int row = rb + lr;
-        const int m = m0 + row;
-        const int c = oc0 + lcol;
-        if (m >= M || c >= on) continue;
-        const char* yrow = smem + row * YS;
-        float y[8];
-        if (!sw) {
-            if (f32out) {
-                const uint2 v = *reinterpret_cast<const uint2*>(yrow + lcol * 2);
-                y[0] = __uint_as_float(v.x << 16); y[1] = __uint_as_float(v.x & 0xffff0000u);
-                y[2] = __uint_as_float(v.y << 16); y[3] = __uint_as_float(v.y & 0xffff0000u);
-            } else {
-                const u32x4 v = *reinterpret_cast<const u32x4*>(yrow + lcol * 2);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { y[2 * e] = __uint_as_float(v[e] << 16); y[2 * e + 1] = __uint_as_float(v[e] & 0xffff0000u); }
-            }
-            if (ep.act) {
-                for (int e = 0; e < epl; ++e) y[e] = rbf(act_apply(y[e], ep.act));
-            }
-        } else {
-            // output col lcol..lcol+epl-1 lives in packed cols (lcol/16)*32 + lcol%16 (gate) and +16 (up)
-            const int pc = (lcol >> 4) * 32 + (lcol & 15);
-            for (int e = 0; e < epl; ++e) {
-                const float gv = bf2f(*reinterpret_cast<const bf16_t*>(yrow + (pc + e) * 2));
-                const float uv = bf2f(*reinterpret_cast<const bf16_t*>(yrow + (pc + 16 + e) * 2));
-                const float sg = rbf(gv / (1.0f + expf(-gv)));
-                y[e] = rbf(sg * uv);
-            }
-        }
-        if (ep.row_gate && ep.row_gate[m] == 0.0f) { for (int e = 0; e < epl; ++e) y[e] = 0.0f; }
-        if (ep.use_scale) { for (int e = 0; e < epl; ++e) y[e] = rbf(ep.scale * y[e]); }
-        const int nv = min(epl, on - c);
-        if (ep.residual) {
-            if (ep.residual_dtype == LICV_F32) {
-                const float* rp = reinterpret_cast<const float*>(ep.residual) + (int64_t)m * ep.ld_res + c;
-                if (nv == epl) {
-                    const floatx4 r0 = *reinterpret_cast<const floatx4*>(rp);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) y[e] = r0[e] + y[e];
-                    if (!f32out) { const floatx4 r1 = *reinterpret_cast<const floatx4*>(rp + 4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) y[4 + e] = r1[e] + y[4 + e]; }
-                } else for (int e = 0; e < nv; ++e) y[e] = rp[e] + y[e];
-            } else {
-                const bf16_t* rp = reinterpret_cast<const bf16_t*>(ep.residual) + (int64_t)m * ep.ld_res + c;
-                if (nv == epl && !f32out) {
-                    const u32x4 rv = *reinterpret_cast<const u32x4*>(rp);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        y[2 * e] = rbf(__uint_as_float(rv[e] << 16) + y[2 * e]);
-                        y[2 * e + 1] = rbf(__uint_as_float(rv[e] & 0xffff0000u) + y[2 * e + 1]);
-                    }
-                } else for (int e = 0; e < nv; ++e) y[e] = rbf(bf2f(rp[e]) + y[e]);
-            }
-        }
-        if (f32out) {
-            float* cp = reinterpret_cast<float*>(C) + (int64_t)m * ldc + c;
-            if (nv == 4) *reinterpret_cast<floatx4*>(cp) = floatx4{y[0], y[1], y[2], y[3]};
-            else for (int e = 0; e < nv; ++e) cp[e] = y[e];
-        } else {
-            bf16_t* cp = reinterpret_cast<bf16_t*>(C) + (int64_t)m * ldc + c;
-            if (nv == 8) {
-                u32x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (uint32_t)f2bf(y[2 * e]) | ((uint32_t)f2bf(y[2 * e + 1]) << 16);
-                *reinterpret_cast<u32x4*>(cp) = o;
-            } else for (int e = 0; e < nv; ++e) cp[e] = f2bf(y[e]);
-        }
-    }
+    if (ep.out_dtype == LICV_F32) epilogue_rows<TM, TN, NWAVES, 4>(ep, C, ldc, M, N, m0, n0, wave, lane, smem);
+    else                          epilogue_rows<TM, TN, NWAVES, 8>(ep, C, ldc, M, N, m0, n0, wave, lane, smem);
 }
 
 // ------------------------------------------------------------------------------------------------

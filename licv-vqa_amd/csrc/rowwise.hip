@@ -200,8 +200,69 @@ void rmsnorm_fwd_k(const void* __restrict__ x, const bf16_t* __restrict__ w, bf1
 }
 
 // ------------------------------------------------------------------------------------------------
-// LayerNorm on bf16 (nn.LayerNorm): fp32 statistics, one rounding at the end.
+// LayerNorm on bf16 (nn.LayerNorm): fp32 statistics, one rounding at the end.  16-byte accesses: each lane
+// owns 8 consecutive elements per 512-element chunk (dim % 8 == 0), or 4 per 256-chunk otherwise.
 // ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_r;
+__device__ __forceinline__ void load8_bf16(const bf16_t* p, float (&o)[8]) {
+    const u32x4_r u = *reinterpret_cast<const u32x4_r*>(p);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[2 * e] = __uint_as_float(u[e] << 16); o[2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u); }
+}
+__device__ __forceinline__ void store8_bf16(bf16_t* p, const float (&v)[8]) {
+    u32x4_r u;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) u[e] = (uint32_t)f2bf(v[2 * e]) | ((uint32_t)f2bf(v[2 * e + 1]) << 16);
+    *reinterpret_cast<u32x4_r*>(p) = u;
+}
+
+template <int NCH>      // chunks of 512 elements
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK)
+void layernorm8_fwd_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, const bf16_t* __restrict__ b,
+                      bf16_t* __restrict__ out, int64_t rows, int dim, int64_t inner, int64_t ld_x, int64_t ld_out,
+                      int64_t out_group, int64_t out_group_extra, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int64_t ro = row / inner, ri = row % inner;
+    const bf16_t* xp = x + ro * ld_x + ri * dim;
+    bf16_t* op = out + ro * ld_out + ri * dim + (out_group > 0 ? (row / out_group) * out_group_extra : 0);
+    float v[NCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int i = (c * 64 + lane) * 8;
+        if (i < dim) {
+            load8_bf16(xp + i, v[c]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[c][j];
+        }
+    }
+    const float mean = wave_sum(s) / (float)dim;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int i = (c * 64 + lane) * 8;
+        if (i < dim) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = v[c][j] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)dim + eps);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int i = (c * 64 + lane) * 8;
+        if (i < dim) {
+            float wv[8], bv[8], y[8];
+            load8_bf16(w + i, wv);
+            load8_bf16(b + i, bv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y[j] = (v[c][j] - mean) * rstd * wv[j] + bv[j];
+            store8_bf16(op + i, y);
+        }
+    }
+}
+
 template <int NCH>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK)
 void layernorm_fwd_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, const bf16_t* __restrict__ b,
@@ -392,7 +453,7 @@ void swiglu_k(const bf16_t* __restrict__ gu, bf16_t* __restrict__ out, int64_t r
         const int64_t r = idx / inter, c = idx % inter;
         const float g = bf2f(gu[r * 2 * inter + c]);
         const float u = bf2f(gu[r * 2 * inter + inter + c]);
-        const float s = rbf(g / (1.0f + __expf(-g)));
+        const float s = rbf(g * __builtin_amdgcn_rcpf(1.0f + __expf(-g)));
         out[idx] = f2bf(s * u);
     }
 }
@@ -489,8 +550,19 @@ extern "C" int licv_layernorm_fwd(const void* x, const void* w, const void* b, v
     const int nch = pick_nch(dim);
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(row_blocks(rows)), block(64 * WAVES_PER_BLOCK);
-    DISPATCH_NCH(nch, (layernorm_fwd_k<N><<<grid, block, 0, st>>>((const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)b,
-                 (bf16_t*)out, rows, (int)dim, inner, ld_x, ld_out, out_group, out_group_extra, eps)));
+    const bool wide = dim % 8 == 0 && ld_x % 8 == 0 && ld_out % 8 == 0 && out_group_extra % 8 == 0 && dim >= 256 && dim <= 4096 &&
+                      ((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)b & 15) == 0;
+    if (wide) {
+        const int n8 = (int)((dim + 511) / 512);
+#define LAUNCH_LN8(NC) layernorm8_fwd_k<NC><<<grid, block, 0, st>>>((const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)b, \
+                 (bf16_t*)out, rows, (int)dim, inner, ld_x, ld_out, out_group, out_group_extra, eps)
+        switch (n8) { case 1: LAUNCH_LN8(1); break; case 2: LAUNCH_LN8(2); break; case 3: LAUNCH_LN8(3); break; case 4: LAUNCH_LN8(4); break;
+                      case 5: LAUNCH_LN8(5); break; case 6: LAUNCH_LN8(6); break; case 7: LAUNCH_LN8(7); break; default: LAUNCH_LN8(8); break; }
+#undef LAUNCH_LN8
+    } else {
+        DISPATCH_NCH(nch, (layernorm_fwd_k<N><<<grid, block, 0, st>>>((const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)b,
+                     (bf16_t*)out, rows, (int)dim, inner, ld_x, ld_out, out_group, out_group_extra, eps)));
+    }
     LICV_LAUNCH_CHECK();
     return LICV_OK;
 }
