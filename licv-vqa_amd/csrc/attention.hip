@@ -40,64 +40,75 @@ __device__ __forceinline__ bf16x4 lds_read_tr(const char* p) {
     return *reinterpret_cast<bf16x4*>(&r);
 }
 
-template <int DPK, int DPV>
-__global__ __launch_bounds__(256)
+template <int DPK, int DPV, int QT, int NW>   // NW waves per workgroup, QT 16-query sub-tiles per wave: QT*NW*16 queries
+__global__ __launch_bounds__(NW * 64, (NW == 8 ? 2 : 2))
 void attn_fwd_k(AttnP a) {
+    constexpr int NTHR = NW * 64;
+    constexpr int SLAB = NW * 16;               // queries per slab (one sub-tile of every wave)
     constexpr int KSTR = DPK * 2 + 16;          // K tile row stride in bytes (+16: spreads rows over banks)
     constexpr int VSTR = DPV * 2 + 16;
     constexpr int KCH = DPK / 8, VCH = DPV / 8; // 16-byte chunks per row
-    constexpr int KLD = (ATT_KB * KCH + 255) / 256, VLD = (ATT_KB * VCH + 255) / 256;
+    constexpr int KLD = (ATT_KB * KCH + NTHR - 1) / NTHR, VLD = (ATT_KB * VCH + NTHR - 1) / NTHR;
+    constexpr int QBLK = SLAB * QT;
     __shared__ __attribute__((aligned(16))) char sK[ATT_KB * KSTR];
     __shared__ __attribute__((aligned(16))) char sV[ATT_KB * VSTR];
     __shared__ __attribute__((aligned(16))) int sValid[ATT_KB];
-    __shared__ unsigned long long sImgUsed[4];
+    __shared__ unsigned long long sImgUsed[NW];
+    __shared__ int sAllValid;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, ql = lane & 15;
-    const int qtiles = (a.Sq + ATT_QB - 1) / ATT_QB;
+    const int qtiles = (a.Sq + QBLK - 1) / QBLK;
     int bid = blockIdx.x;
     const int qt = bid % qtiles; bid /= qtiles;
     const int head = bid % a.nh;
     const int b = bid / a.nh;
     const int kvh = head / (a.nh / a.nkv);
-    const int q0 = qt * ATT_QB;
-    const int qrow = q0 + wave * 16 + ql;                 // this lane's query
-    const bool qok = qrow < a.Sq;
+    const int q0 = qt * QBLK;
     const int coff = a.Sk - a.Sq;                          // causal offset (decode steps: Sq < Sk)
+    const float sc = a.scale * 1.4426950408889634f;        // softmax runs on exp2
 
-    // ---- Q fragments (B operand of S^T = K.Q^T): Q[qrow][ks*32 + 8g .. +7]
-    bf16x8 qf[DPK / 32];
-    {
+    // ---- Q fragments (B operand of S^T = K.Q^T): Q[qrow][ks*32 + 8g .. +7]; sub-tile qs covers rows
+    // q0 + qs*64 + wave*16 .. +15 (this lane: + ql)
+    bf16x8 qf[QT][DPK / 32];
+#pragma unroll
+    for (int qs = 0; qs < QT; ++qs) {
+        const int qrow = q0 + qs * SLAB + wave * 16 + ql;
         const bf16_t* qp = a.q + (int64_t)b * a.q_bs + (int64_t)qrow * a.q_rs + (int64_t)head * a.hd;
 #pragma unroll
         for (int ks = 0; ks < DPK / 32; ++ks) {
             const int d = ks * 32 + g * 8;
             u32x4 r = u32x4{0u, 0u, 0u, 0u};
-            if (qok && d < a.hd) r = *reinterpret_cast<const u32x4*>(qp + d);
-            qf[ks] = *reinterpret_cast<bf16x8*>(&r);
+            if (qrow < a.Sq && d < a.hd) r = *reinterpret_cast<const u32x4*>(qp + d);
+            qf[qs][ks] = *reinterpret_cast<bf16x8*>(&r);
         }
     }
 
     int kend = a.Sk;
-    if (a.mask_mode == 1) kend = min(a.Sk, q0 + ATT_QB + coff);      // keys beyond the last query's diagonal
+    if (a.mask_mode == 1) kend = min(a.Sk, min(q0 + QBLK, a.Sq) + coff);   // keys beyond the last query's diagonal
     const int ntiles = (kend + ATT_KB - 1) / ATT_KB;
-    const bool wave_active = (q0 + wave * 16) < a.Sq;      // waves past the last query only help with the loads
 
     // image-mask mode with whole tiles inside one image: a tile is visited only if some query of this
     // workgroup attends that image (a token attends ONE image of ~33: >95 % of the key tiles drop out)
-    const int32_t* imrow = (a.mask_mode == 3 && qok) ? a.img_mask + ((int64_t)b * a.Sq + qrow) * a.n_img : nullptr;
     const bool img_uniform = (a.mask_mode == 3) && (a.img_len % ATT_KB == 0);
     const bool img_skip = img_uniform && a.n_img <= 64;
     unsigned long long used = ~0ull;
     if (img_skip) {
         unsigned long long mine = 0;
-        for (int n = 0; n < a.n_img; ++n) {
-            const bool hit = imrow && imrow[n] != 0;
-            if (__any(hit)) mine |= 1ull << n;
+#pragma unroll
+        for (int qs = 0; qs < QT; ++qs) {
+            const int qrow = q0 + qs * SLAB + wave * 16 + ql;
+            const int32_t* imrow = a.img_mask + ((int64_t)b * a.Sq + qrow) * a.n_img;
+            for (int n = 0; n < a.n_img; ++n) {
+                const bool hit = qrow < a.Sq && imrow[n] != 0;
+                if (__any(hit)) mine |= 1ull << n;
+            }
         }
         if (lane == 0) sImgUsed[wave] = mine;
         __syncthreads();
-        used = sImgUsed[0] | sImgUsed[1] | sImgUsed[2] | sImgUsed[3];
+        used = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) used |= sImgUsed[w];
     }
     auto tile_live = [&](int t) -> bool { return !img_skip || ((used >> ((t * ATT_KB) / a.img_len)) & 1ull); };
     auto next_tile = [&](int t) -> int { while (t < ntiles && !tile_live(t)) ++t; return t; };
@@ -110,7 +121,7 @@ void attn_fwd_k(AttnP a) {
         const int key0 = t * ATT_KB;
 #pragma unroll
         for (int i = 0; i < KLD; ++i) {
-            const int c = tid + i * 256;
+            const int c = tid + i * NTHR;
             const int row = c / KCH, ch = c % KCH;
             u32x4 r = u32x4{0u, 0u, 0u, 0u};
             if (c < ATT_KB * KCH && key0 + row < a.Sk && ch * 8 < a.hd)
@@ -119,7 +130,7 @@ void attn_fwd_k(AttnP a) {
         }
 #pragma unroll
         for (int i = 0; i < VLD; ++i) {
-            const int c = tid + i * 256;
+            const int c = tid + i * NTHR;
             const int row = c / VCH, ch = c % VCH;
             u32x4 r = u32x4{0u, 0u, 0u, 0u};
             if (c < ATT_KB * VCH && key0 + row < a.Sk && ch * 8 < a.hd)
@@ -136,21 +147,29 @@ void attn_fwd_k(AttnP a) {
     auto store_tile = [&]() {
 #pragma unroll
         for (int i = 0; i < KLD; ++i) {
-            const int c = tid + i * 256;
+            const int c = tid + i * NTHR;
             if (c < ATT_KB * KCH) *reinterpret_cast<u32x4*>(sK + (c / KCH) * KSTR + (c % KCH) * 16) = rk[i];
         }
 #pragma unroll
         for (int i = 0; i < VLD; ++i) {
-            const int c = tid + i * 256;
+            const int c = tid + i * NTHR;
             if (c < ATT_KB * VCH) *reinterpret_cast<u32x4*>(sV + (c / VCH) * VSTR + (c % VCH) * 16) = rv[i];
         }
-        if (tid < ATT_KB) sValid[tid] = rvalid;
+        if (tid < ATT_KB) {
+            sValid[tid] = rvalid;
+            const bool all = __all(rvalid != 0);             // wave 0 holds all 64 keys of the tile
+            if (tid == 0) sAllValid = all ? 1 : 0;
+        }
     };
 
-    floatx4 oacc[DPV / 16];
+    floatx4 oacc[QT][DPV / 16];
+    float m_run[QT], l_run[QT];
 #pragma unroll
-    for (int i = 0; i < DPV / 16; ++i) oacc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY, l_run = 0.f;
+    for (int qs = 0; qs < QT; ++qs) {
+        m_run[qs] = -INFINITY; l_run[qs] = 0.f;
+#pragma unroll
+        for (int i = 0; i < DPV / 16; ++i) oacc[qs][i] = floatx4{0.f, 0.f, 0.f, 0.f};
+    }
 
     int t = next_tile(0);
     if (t < ntiles) { load_tile(t); store_tile(); }
@@ -161,81 +180,93 @@ void attn_fwd_k(AttnP a) {
         if (tn < ntiles) load_tile(tn);
         const int key0 = t * ATT_KB;
         const int nst = min(4, (min(a.Sk, kend) - key0 + 15) >> 4);      // 16-key sub-tiles that hold real keys
-        if (wave_active) {
+        const bool tile_all_valid = sAllValid != 0;
 
-        // ---- S^T tile: 4 sub-tiles of 16 keys; lane holds keys key0 + st*16 + 4g + r for query ql
-        floatx4 s[4];
 #pragma unroll
-        for (int st = 0; st < 4; ++st) {
-            s[st] = floatx4{0.f, 0.f, 0.f, 0.f};
-            if (st < nst) {
+        for (int qs = 0; qs < QT; ++qs) {
+            const int qw0 = q0 + qs * SLAB + wave * 16;          // first query of this wave's sub-tile (wave-uniform)
+            if (qw0 >= a.Sq) continue;                              // sub-tile past the last query: only helps loading
+            if (a.mask_mode == 1 && key0 > qw0 + 15 + coff) continue;   // tile entirely in this sub-tile's future
+            const int qrow = qw0 + ql;
+            const bool qok = qrow < a.Sq;
+            // ---- S^T tile: 4 sub-tiles of 16 keys; lane holds keys key0 + st*16 + 4g + r for query ql
+            floatx4 s[4];
 #pragma unroll
-                for (int ks = 0; ks < DPK / 32; ++ks) {
-                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (st * 16 + ql) * KSTR + (ks * 32 + g * 8) * 2);
-                    s[st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[st], 0, 0, 0);
+            for (int st = 0; st < 4; ++st) {
+                s[st] = floatx4{0.f, 0.f, 0.f, 0.f};
+                if (st < nst) {
+#pragma unroll
+                    for (int ks = 0; ks < DPK / 32; ++ks) {
+                        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (st * 16 + ql) * KSTR + (ks * 32 + g * 8) * 2);
+                        s[st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qs][ks], s[st], 0, 0, 0);
+                    }
+                }
+            }
+            // ---- mask (only tiles that need one) + online softmax in the log2 domain: p = exp2(s*c - m), c = scale*log2(e)
+            const int32_t* imrow = (a.mask_mode == 3 && qok) ? a.img_mask + ((int64_t)b * a.Sq + qrow) * a.n_img : nullptr;
+            bool need_mask = (key0 + ATT_KB > a.Sk) || (qw0 + 16 > a.Sq) || !tile_all_valid;
+            if (a.mask_mode == 1) need_mask = need_mask || (key0 + ATT_KB - 1 > qw0 + coff);
+            if (a.mask_mode == 3) need_mask = true;
+            if (need_mask) {
+                int img_ok_tile = 1;
+                if (img_uniform) img_ok_tile = imrow ? (imrow[key0 / a.img_len] != 0) : 0;
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    const int kl = st * 16 + g * 4;
+                    const int4 kv4 = *reinterpret_cast<const int4*>(&sValid[kl]);
+                    const int kvv[4] = {kv4.x, kv4.y, kv4.z, kv4.w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = key0 + kl + r;
+                        bool ok = qok && kvv[r] != 0;
+                        if (a.mask_mode == 1) ok = ok && (key <= qrow + coff);
+                        if (a.mask_mode == 3) {
+                            if (img_uniform) ok = ok && img_ok_tile;
+                            else ok = ok && imrow && (imrow[key / a.img_len] != 0);
+                        }
+                        s[st][r] = ok ? s[st][r] : -INFINITY;
+                    }
+                }
+            }
+            float tmax = fmaxf(fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3])), fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3])));
+            tmax = fmaxf(tmax, fmaxf(fmaxf(fmaxf(s[2][0], s[2][1]), fmaxf(s[2][2], s[2][3])), fmaxf(fmaxf(s[3][0], s[3][1]), fmaxf(s[3][2], s[3][3]))));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float m_new = fmaxf(m_run[qs], tmax * sc);      // running max of s*c  (c > 0 keeps the order)
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f(m_run[qs] - m_use);   // m_run = -inf -> 0
+            float psum = 0.f;
+            bf16x8 pf[2];
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[st][r], sc, -m_use));
+                    psum += p;
+                    pf[st >> 1][(st & 1) * 4 + r] = (__bf16)p;
+                }
+            }
+            l_run[qs] = l_run[qs] * alpha + psum;
+            m_run[qs] = m_new;
+#pragma unroll
+            for (int i = 0; i < DPV / 16; ++i) oacc[qs][i] *= alpha;
+
+            // ---- O^T += V^T . P^T : k-step s2 covers sub-tiles 2*s2, 2*s2+1
+#pragma unroll
+            for (int dt = 0; dt < DPV / 16; ++dt) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    if (2 * s2 >= nst) continue;             // both 16-key halves of this k-step are padding
+                    const char* p0 = sV + ((2 * s2) * 16 + g * 4 + (ql >> 2)) * VSTR + (dt * 16 + (ql & 3) * 4) * 2;
+                    const bf16x4 lo = lds_read_tr(p0);
+                    const bf16x4 hi = lds_read_tr(p0 + 16 * VSTR);
+                    bf16x8 vf;
+                    vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+                    vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+                    oacc[qs][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[s2], oacc[qs][dt], 0, 0, 0);
                 }
             }
         }
-        // ---- scale + mask
-        int img_ok_tile = 1;
-        if (img_uniform) img_ok_tile = imrow ? (imrow[key0 / a.img_len] != 0) : 0;
-        float tmax = -INFINITY;
-#pragma unroll
-        for (int st = 0; st < 4; ++st) {
-            const int kl = st * 16 + g * 4;
-            const int4 kv4 = *reinterpret_cast<const int4*>(&sValid[kl]);
-            const int kvv[4] = {kv4.x, kv4.y, kv4.z, kv4.w};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = key0 + kl + r;
-                bool ok = qok && kvv[r] != 0;
-                if (a.mask_mode == 1) ok = ok && (key <= qrow + coff);
-                if (a.mask_mode == 3) {
-                    if (img_uniform) ok = ok && img_ok_tile;
-                    else ok = ok && imrow && (imrow[key / a.img_len] != 0);
-                }
-                const float v = ok ? s[st][r] * a.scale : -INFINITY;
-                s[st][r] = v;
-                tmax = fmaxf(tmax, v);
-            }
-        }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float m_new = fmaxf(m_run, tmax);
-        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = __expf(m_run - m_use);           // m_run = -inf -> 0
-        float psum = 0.f;
-        bf16x8 pf[2];
-#pragma unroll
-        for (int st = 0; st < 4; ++st) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = __expf(s[st][r] - m_use);
-                psum += p;
-                pf[st >> 1][(st & 1) * 4 + r] = (__bf16)p;
-            }
-        }
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-#pragma unroll
-        for (int i = 0; i < DPV / 16; ++i) oacc[i] *= alpha;
-
-        // ---- O^T += V^T . P^T : k-step s2 covers sub-tiles 2*s2, 2*s2+1
-#pragma unroll
-        for (int dt = 0; dt < DPV / 16; ++dt) {
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                if (2 * s2 >= nst) continue;                 // both 16-key halves of this k-step are padding
-                const char* p0 = sV + ((2 * s2) * 16 + g * 4 + (ql >> 2)) * VSTR + (dt * 16 + (ql & 3) * 4) * 2;
-                const bf16x4 lo = lds_read_tr(p0);
-                const bf16x4 hi = lds_read_tr(p0 + 16 * VSTR);
-                bf16x8 vf;
-                vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
-                vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
-                oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[s2], oacc[dt], 0, 0, 0);
-            }
-        }
-        }   // wave_active
         __syncthreads();                                   // everyone done reading this tile
         if (tn < ntiles) store_tile();
         __syncthreads();
@@ -243,19 +274,24 @@ void attn_fwd_k(AttnP a) {
     }
 
     // ---- epilogue: O[b, qrow, head*hd + d], lane holds d = dt*16 + 4g + r
-    l_run += __shfl_xor(l_run, 16, 64);
-    l_run += __shfl_xor(l_run, 32, 64);
-    const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
-    if (qok) {
-        bf16_t* op = a.o + ((int64_t)b * a.Sq + qrow) * ((int64_t)a.nh * a.hd) + (int64_t)head * a.hd;
 #pragma unroll
-        for (int dt = 0; dt < DPV / 16; ++dt) {
-            const int d = dt * 16 + g * 4;
-            if (d < a.hd) {
-                uint2 u;
-                u.x = (uint32_t)f2bf(oacc[dt][0] * inv) | ((uint32_t)f2bf(oacc[dt][1] * inv) << 16);
-                u.y = (uint32_t)f2bf(oacc[dt][2] * inv) | ((uint32_t)f2bf(oacc[dt][3] * inv) << 16);
-                *reinterpret_cast<uint2*>(op + d) = u;
+    for (int qs = 0; qs < QT; ++qs) {
+        const int qrow = q0 + qs * SLAB + wave * 16 + ql;
+        float l = l_run[qs];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = l > 0.f ? 1.0f / l : 0.f;
+        if (qrow < a.Sq) {
+            bf16_t* op = a.o + ((int64_t)b * a.Sq + qrow) * ((int64_t)a.nh * a.hd) + (int64_t)head * a.hd;
+#pragma unroll
+            for (int dt = 0; dt < DPV / 16; ++dt) {
+                const int d = dt * 16 + g * 4;
+                if (d < a.hd) {
+                    uint2 u;
+                    u.x = (uint32_t)f2bf(oacc[qs][dt][0] * inv) | ((uint32_t)f2bf(oacc[qs][dt][1] * inv) << 16);
+                    u.y = (uint32_t)f2bf(oacc[qs][dt][2] * inv) | ((uint32_t)f2bf(oacc[qs][dt][3] * inv) << 16);
+                    *reinterpret_cast<uint2*>(op + d) = u;
+                }
             }
         }
     }
@@ -278,18 +314,24 @@ extern "C" int licv_attn_fwd(const licv_attn_args* x, void* stream) {
     p.B = (int)x->B; p.Sq = (int)x->Sq; p.Sk = (int)x->Sk; p.nh = (int)x->n_heads; p.nkv = (int)x->n_kv_heads; p.hd = (int)x->head_dim;
     p.scale = x->scale; p.mask_mode = x->mask_mode; p.key_valid = x->key_valid;
     p.img_mask = x->img_mask; p.n_img = (int)x->n_img; p.img_len = (int)x->img_len;
+    // 64 queries per 4-wave workgroup.  (The kernel also instantiates as QT slabs x NW waves per workgroup so a
+    // K/V tile is fetched once for up to QT*NW*16 queries; measured SLOWER here — 745 vs 590 us on the ViT shape —
+    // because this kernel is bound by softmax VALU + LDS, not by K/V loads, and fewer, fatter workgroups overlap
+    // MFMA and VALU phases less.)
+    const int hd = p.hd;
     const int64_t qtiles = (x->Sq + ATT_QB - 1) / ATT_QB;
     const int64_t nblk = x->B * x->n_heads * qtiles;
     LICV_CHECK_ARG(nblk < (1ll << 31), "attn_fwd: grid too large");
     const dim3 grid((unsigned)nblk), block(256);
     hipStream_t st = (hipStream_t)stream;
-    const int hd = p.hd;
-    if (hd <= 16)        attn_fwd_k<32, 16><<<grid, block, 0, st>>>(p);
-    else if (hd <= 32)   attn_fwd_k<32, 32><<<grid, block, 0, st>>>(p);
-    else if (hd <= 64)   attn_fwd_k<64, 64><<<grid, block, 0, st>>>(p);
-    else if (hd <= 80)   attn_fwd_k<96, 80><<<grid, block, 0, st>>>(p);
-    else if (hd <= 96)   attn_fwd_k<96, 96><<<grid, block, 0, st>>>(p);
-    else                 attn_fwd_k<128, 128><<<grid, block, 0, st>>>(p);
+#define ATT_LAUNCH(DK, DV) attn_fwd_k<DK, DV, 1, 4><<<grid, block, 0, st>>>(p)
+    if (hd <= 16)        ATT_LAUNCH(32, 16);
+    else if (hd <= 32)   ATT_LAUNCH(32, 32);
+    else if (hd <= 64)   ATT_LAUNCH(64, 64);
+    else if (hd <= 80)   ATT_LAUNCH(96, 80);
+    else if (hd <= 96)   ATT_LAUNCH(96, 96);
+    else                 ATT_LAUNCH(128, 128);
+#undef ATT_LAUNCH
     LICV_LAUNCH_CHECK();
     return LICV_OK;
 }
