@@ -125,6 +125,8 @@ typedef struct {
 } licv_attn_args;
 
 int licv_attn_fwd(const licv_attn_args* a, void* stream);
+/* tests / A-B timing: 1 = always the tiled kernel (never the resident-K/V variant used for short unmasked keys) */
+int licv_attn_select(int force_tiled);
 
 /* ---- small data-movement kernels ---- */
 /* hf:idefics/modeling_idefics.py:230-267 IdeficsDecoupledEmbedding (ids >= vocab -> additional table) */

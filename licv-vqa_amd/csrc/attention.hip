@@ -34,10 +34,97 @@ struct AttnP {
     const int32_t* img_mask; int n_img, img_len;
 };
 
+// LDS row stride (bytes) for a tile with `cols` bf16 columns: the smallest 16-byte multiple >= the row whose dword
+// count is 8 mod 16 — brute-forced conflict-free for both access shapes used here (ds_read_b128 of 16 rows x
+// 4 chunks, and ds_read_b64_tr_b16 of 8 rows x 4 column groups); e.g. 96 cols -> 224 B, 80 -> 160 B, 128 -> 288 B.
+__host__ __device__ constexpr int lds_stride(int cols) {
+    int dw = cols / 2;
+    while (dw % 16 != 8) dw += 4;
+    return dw * 4;
+}
+
 __device__ __forceinline__ bf16x4 lds_read_tr(const char* p) {
     typedef __attribute__((ext_vector_type(4))) short s4;
     s4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(p));
     return *reinterpret_cast<bf16x4*>(&r);
+}
+
+// One 64-key tile for one 16-query sub-tile of a wave: S^T = K.Q^T, (mask), online softmax in the log2 domain,
+// O^T += V^T.P^T.  NST (compile time) = 16-key sub-tiles that hold real keys, so the hot NST = 4 instance is one
+// branch-free region the compiler can software-pipeline (a run-time `if (st < nst)` around each MFMA serialised
+// every ds_read -> s_waitcnt -> v_mfma triple: 3800 cycles per tile instead of ~800).
+template <int DPK, int DPV, int NST, typename MaskF>
+__device__ __forceinline__ void attn_tile(const char* kt, const char* vt, const bf16x8 (&qf)[DPK / 32], floatx4 (&oacc)[DPV / 16],
+                                          float& m_run, float& l_run, float sc, int g, int ql, bool need_mask, MaskF&& allowed) {
+    constexpr int KSTR = lds_stride(DPK), VSTR = lds_stride(DPV);
+    floatx4 s[4];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+        if (st < NST) {
+            s[st] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < DPK / 32; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kt + (st * 16 + ql) * KSTR + (ks * 32 + g * 8) * 2);
+                s[st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[st], 0, 0, 0);
+            }
+        } else {
+            s[st] = floatx4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        }
+    }
+    if (need_mask) {
+#pragma unroll
+        for (int st = 0; st < NST; ++st)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (!allowed(st, r)) s[st][r] = -INFINITY;
+    }
+    float tmax = fmaxf(fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3])), fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3])));
+    tmax = fmaxf(tmax, fmaxf(fmaxf(fmaxf(s[2][0], s[2][1]), fmaxf(s[2][2], s[2][3])), fmaxf(fmaxf(s[3][0], s[3][1]), fmaxf(s[3][2], s[3][3]))));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m_run, tmax * sc);               // running max of s*c  (c > 0 keeps the order)
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_use); // m_run = -inf -> 0
+    float psum = 0.f;
+    bf16x8 pf[2];
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float p = (st < NST) ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[st][r], sc, -m_use)) : 0.f;
+            psum += p;
+            pf[st >> 1][(st & 1) * 4 + r] = (__bf16)p;
+        }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < DPV / 16; ++i) oacc[i] *= alpha;
+    // O^T += V^T . P^T : k-step s2 covers sub-tiles 2*s2, 2*s2+1
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        if (2 * s2 < NST) {
+#pragma unroll
+            for (int dt = 0; dt < DPV / 16; ++dt) {
+                const char* p0 = vt + ((2 * s2) * 16 + g * 4 + (ql >> 2)) * VSTR + (dt * 16 + (ql & 3) * 4) * 2;
+                const bf16x4 lo = lds_read_tr(p0);
+                const bf16x4 hi = lds_read_tr(p0 + 16 * VSTR);
+                bf16x8 vf;
+                vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+                vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+                oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[s2], oacc[dt], 0, 0, 0);
+            }
+        }
+    }
+}
+
+template <int DPK, int DPV, typename MaskF>
+__device__ __forceinline__ void attn_tile_n(int nst, const char* kt, const char* vt, const bf16x8 (&qf)[DPK / 32],
+                                            floatx4 (&oacc)[DPV / 16], float& m_run, float& l_run, float sc, int g, int ql,
+                                            bool need_mask, MaskF&& allowed) {
+    if (nst >= 4)      attn_tile<DPK, DPV, 4>(kt, vt, qf, oacc, m_run, l_run, sc, g, ql, need_mask, allowed);
+    else if (nst == 3) attn_tile<DPK, DPV, 3>(kt, vt, qf, oacc, m_run, l_run, sc, g, ql, need_mask, allowed);
+    else if (nst == 2) attn_tile<DPK, DPV, 2>(kt, vt, qf, oacc, m_run, l_run, sc, g, ql, need_mask, allowed);
+    else               attn_tile<DPK, DPV, 1>(kt, vt, qf, oacc, m_run, l_run, sc, g, ql, need_mask, allowed);
 }
 
 template <int DPK, int DPV, int QT, int NW>   // NW waves per workgroup, QT 16-query sub-tiles per wave: QT*NW*16 queries
@@ -45,8 +132,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 2 : 2))
 void attn_fwd_k(AttnP a) {
     constexpr int NTHR = NW * 64;
     constexpr int SLAB = NW * 16;               // queries per slab (one sub-tile of every wave)
-    constexpr int KSTR = DPK * 2 + 16;          // K tile row stride in bytes (+16: spreads rows over banks)
-    constexpr int VSTR = DPV * 2 + 16;
+    constexpr int KSTR = lds_stride(DPK), VSTR = lds_stride(DPV);   // conflict-free row strides
     constexpr int KCH = DPK / 8, VCH = DPV / 8; // 16-byte chunks per row
     constexpr int KLD = (ATT_KB * KCH + NTHR - 1) / NTHR, VLD = (ATT_KB * VCH + NTHR - 1) / NTHR;
     constexpr int QBLK = SLAB * QT;
@@ -189,83 +275,29 @@ void attn_fwd_k(AttnP a) {
             if (a.mask_mode == 1 && key0 > qw0 + 15 + coff) continue;   // tile entirely in this sub-tile's future
             const int qrow = qw0 + ql;
             const bool qok = qrow < a.Sq;
-            // ---- S^T tile: 4 sub-tiles of 16 keys; lane holds keys key0 + st*16 + 4g + r for query ql
-            floatx4 s[4];
-#pragma unroll
-            for (int st = 0; st < 4; ++st) {
-                s[st] = floatx4{0.f, 0.f, 0.f, 0.f};
-                if (st < nst) {
-#pragma unroll
-                    for (int ks = 0; ks < DPK / 32; ++ks) {
-                        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (st * 16 + ql) * KSTR + (ks * 32 + g * 8) * 2);
-                        s[st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qs][ks], s[st], 0, 0, 0);
-                    }
-                }
-            }
-            // ---- mask (only tiles that need one) + online softmax in the log2 domain: p = exp2(s*c - m), c = scale*log2(e)
             const int32_t* imrow = (a.mask_mode == 3 && qok) ? a.img_mask + ((int64_t)b * a.Sq + qrow) * a.n_img : nullptr;
             bool need_mask = (key0 + ATT_KB > a.Sk) || (qw0 + 16 > a.Sq) || !tile_all_valid;
             if (a.mask_mode == 1) need_mask = need_mask || (key0 + ATT_KB - 1 > qw0 + coff);
             if (a.mask_mode == 3) need_mask = true;
+            const int img_ok_tile = (img_uniform && imrow) ? (imrow[key0 / a.img_len] != 0) : 0;
+            int4 kvalid[4] = {int4{1, 1, 1, 1}, int4{1, 1, 1, 1}, int4{1, 1, 1, 1}, int4{1, 1, 1, 1}};
             if (need_mask) {
-                int img_ok_tile = 1;
-                if (img_uniform) img_ok_tile = imrow ? (imrow[key0 / a.img_len] != 0) : 0;
 #pragma unroll
-                for (int st = 0; st < 4; ++st) {
-                    const int kl = st * 16 + g * 4;
-                    const int4 kv4 = *reinterpret_cast<const int4*>(&sValid[kl]);
-                    const int kvv[4] = {kv4.x, kv4.y, kv4.z, kv4.w};
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int key = key0 + kl + r;
-                        bool ok = qok && kvv[r] != 0;
-                        if (a.mask_mode == 1) ok = ok && (key <= qrow + coff);
-                        if (a.mask_mode == 3) {
-                            if (img_uniform) ok = ok && img_ok_tile;
-                            else ok = ok && imrow && (imrow[key / a.img_len] != 0);
-                        }
-                        s[st][r] = ok ? s[st][r] : -INFINITY;
-                    }
-                }
+                for (int st = 0; st < 4; ++st) kvalid[st] = *reinterpret_cast<const int4*>(&sValid[st * 16 + g * 4]);
             }
-            float tmax = fmaxf(fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3])), fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3])));
-            tmax = fmaxf(tmax, fmaxf(fmaxf(fmaxf(s[2][0], s[2][1]), fmaxf(s[2][2], s[2][3])), fmaxf(fmaxf(s[3][0], s[3][1]), fmaxf(s[3][2], s[3][3]))));
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-            const float m_new = fmaxf(m_run[qs], tmax * sc);      // running max of s*c  (c > 0 keeps the order)
-            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = __builtin_amdgcn_exp2f(m_run[qs] - m_use);   // m_run = -inf -> 0
-            float psum = 0.f;
-            bf16x8 pf[2];
-#pragma unroll
-            for (int st = 0; st < 4; ++st) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[st][r], sc, -m_use));
-                    psum += p;
-                    pf[st >> 1][(st & 1) * 4 + r] = (__bf16)p;
+            auto allowed = [&](int st, int r) -> bool {
+                const int kl = st * 16 + g * 4 + r;
+                const int key = key0 + kl;
+                const int kv = r == 0 ? kvalid[st].x : (r == 1 ? kvalid[st].y : (r == 2 ? kvalid[st].z : kvalid[st].w));
+                bool ok = qok && kv != 0;
+                if (a.mask_mode == 1) ok = ok && (key <= qrow + coff);
+                if (a.mask_mode == 3) {
+                    if (img_uniform) ok = ok && img_ok_tile;
+                    else ok = ok && imrow && (imrow[key / a.img_len] != 0);
                 }
-            }
-            l_run[qs] = l_run[qs] * alpha + psum;
-            m_run[qs] = m_new;
-#pragma unroll
-            for (int i = 0; i < DPV / 16; ++i) oacc[qs][i] *= alpha;
-
-            // ---- O^T += V^T . P^T : k-step s2 covers sub-tiles 2*s2, 2*s2+1
-#pragma unroll
-            for (int dt = 0; dt < DPV / 16; ++dt) {
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    if (2 * s2 >= nst) continue;             // both 16-key halves of this k-step are padding
-                    const char* p0 = sV + ((2 * s2) * 16 + g * 4 + (ql >> 2)) * VSTR + (dt * 16 + (ql & 3) * 4) * 2;
-                    const bf16x4 lo = lds_read_tr(p0);
-                    const bf16x4 hi = lds_read_tr(p0 + 16 * VSTR);
-                    bf16x8 vf;
-                    vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
-                    vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
-                    oacc[qs][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[s2], oacc[qs][dt], 0, 0, 0);
-                }
-            }
+                return ok;
+            };
+            attn_tile_n<DPK, DPV>(nst, sK, sV, qf[qs], oacc[qs], m_run[qs], l_run[qs], sc, g, ql, need_mask, allowed);
         }
         __syncthreads();                                   // everyone done reading this tile
         if (tn < ntiles) store_tile();
@@ -297,6 +329,126 @@ void attn_fwd_k(AttnP a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Resident-K/V variant for SHORT key sequences without a mask (ViT: 257 tokens, perceiver: 321 keys): the whole
+// K and V of one (batch, head) are staged into LDS once (~100-140 KiB), after a single barrier the 8 waves walk
+// their 16-query sub-tiles over all key tiles with no further global loads and no barriers, so the two waves
+// of a SIMD drift apart and overlap MFMA with softmax VALU.  The tiled kernel above pays one global-load
+// latency per 64-key tile per 64-query workgroup: 487 us per ViT layer vs the ~60 us of MFMA work in it.
+// ------------------------------------------------------------------------------------------------
+template <int DPK, int DPV, int MAXI>   // MAXI: 16-byte chunks per thread per operand (>= skp * DPK/8 / 512)
+__global__ __launch_bounds__(512, 2)
+void attn_resident_k(AttnP a, int skp, int n_items) {
+    constexpr int KSTR = lds_stride(DPK), VSTR = lds_stride(DPV);
+    constexpr int KCH = DPK / 8, VCH = DPV / 8;
+    extern __shared__ __attribute__((aligned(16))) char rsm[];
+    char* sK = rsm;
+    char* sV = rsm + skp * KSTR;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, ql = lane & 15;
+    const float sc = a.scale * 1.4426950408889634f;
+    const int nq = (a.Sq + 15) >> 4;                        // 16-query sub-tiles
+    const int ntiles = (a.Sk + ATT_KB - 1) / ATT_KB;
+
+    // persistent over (batch, head) items: K/V of item i+1 travel global -> registers while item i is computed
+    u32x4 rk[MAXI], rv[MAXI];
+    auto fetch = [&](int item) {
+        const int hh = item % a.nh, bb = item / a.nh;
+        const int kvh = hh / (a.nh / a.nkv);
+        const bf16_t* kbase = a.k + (int64_t)bb * a.kv_bs + (int64_t)kvh * a.hd;
+        const bf16_t* vbase = a.v + (int64_t)bb * a.kv_bs + (int64_t)kvh * a.hd;
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+            const int c = tid + i * 512;
+            const int row = c / KCH, ch = c % KCH;
+            u32x4 r = u32x4{0u, 0u, 0u, 0u};
+            if (c < skp * KCH && row < a.Sk && ch * 8 < a.hd) r = *reinterpret_cast<const u32x4*>(kbase + (int64_t)row * a.kv_rs + ch * 8);
+            rk[i] = r;
+        }
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+            const int c = tid + i * 512;
+            const int row = c / VCH, ch = c % VCH;
+            u32x4 r = u32x4{0u, 0u, 0u, 0u};
+            if (c < skp * VCH && row < a.Sk && ch * 8 < a.hd) r = *reinterpret_cast<const u32x4*>(vbase + (int64_t)row * a.kv_rs + ch * 8);
+            rv[i] = r;
+        }
+    };
+    auto park = [&]() {
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+            const int c = tid + i * 512;
+            if (c < skp * KCH) *reinterpret_cast<u32x4*>(sK + (c / KCH) * KSTR + (c % KCH) * 16) = rk[i];
+        }
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+            const int c = tid + i * 512;
+            if (c < skp * VCH) *reinterpret_cast<u32x4*>(sV + (c / VCH) * VSTR + (c % VCH) * 16) = rv[i];
+        }
+    };
+
+    int item = blockIdx.x;
+    if (item < n_items) { fetch(item); park(); }
+    __syncthreads();
+    for (; item < n_items; item += gridDim.x) {
+    const int head = item % a.nh;
+    const int b = item / a.nh;
+    const int nxt = item + gridDim.x;
+    if (nxt < n_items) fetch(nxt);
+
+    for (int qsub = wave; qsub < nq; qsub += 8) {
+        const int qrow = qsub * 16 + ql;
+        const bool qok = qrow < a.Sq;
+        bf16x8 qf[DPK / 32];
+        {
+            const bf16_t* qp = a.q + (int64_t)b * a.q_bs + (int64_t)qrow * a.q_rs + (int64_t)head * a.hd;
+#pragma unroll
+            for (int ks = 0; ks < DPK / 32; ++ks) {
+                const int d = ks * 32 + g * 8;
+                u32x4 r = u32x4{0u, 0u, 0u, 0u};
+                if (qok && d < a.hd) r = *reinterpret_cast<const u32x4*>(qp + d);
+                qf[ks] = *reinterpret_cast<bf16x8*>(&r);
+            }
+        }
+        floatx4 oacc[DPV / 16];
+#pragma unroll
+        for (int i = 0; i < DPV / 16; ++i) oacc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+        float m_run = -INFINITY, l_run = 0.f;
+        for (int t = 0; t < ntiles; ++t) {
+            const int key0 = t * ATT_KB;
+            const int nst = min(4, (a.Sk - key0 + 15) >> 4);
+            const char* kt = sK + key0 * KSTR;
+            const char* vt = sV + key0 * VSTR;
+            const bool need_mask = key0 + ATT_KB > a.Sk;     // ragged last tile: keys past Sk never contribute
+            auto allowed = [&](int st, int r) -> bool { return key0 + st * 16 + g * 4 + r < a.Sk; };
+            attn_tile_n<DPK, DPV>(nst, kt, vt, qf, oacc, m_run, l_run, sc, g, ql, need_mask, allowed);
+        }
+        l_run += __shfl_xor(l_run, 16, 64);
+        l_run += __shfl_xor(l_run, 32, 64);
+        const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+        if (qok) {
+            bf16_t* op = a.o + ((int64_t)b * a.Sq + qrow) * ((int64_t)a.nh * a.hd) + (int64_t)head * a.hd;
+#pragma unroll
+            for (int dt = 0; dt < DPV / 16; ++dt) {
+                const int d = dt * 16 + g * 4;
+                if (d < a.hd) {
+                    uint2 u;
+                    u.x = (uint32_t)f2bf(oacc[dt][0] * inv) | ((uint32_t)f2bf(oacc[dt][1] * inv) << 16);
+                    u.y = (uint32_t)f2bf(oacc[dt][2] * inv) | ((uint32_t)f2bf(oacc[dt][3] * inv) << 16);
+                    *reinterpret_cast<uint2*>(op + d) = u;
+                }
+            }
+        }
+    }
+    __syncthreads();                            // every wave is done with this item's K/V
+    if (nxt < n_items) park();
+    __syncthreads();
+    }
+}
+
+static int g_attn_force_tiled = 0;      // tests / A-B timing: 1 = never use the resident-K/V variant
+extern "C" int licv_attn_select(int force_tiled) { g_attn_force_tiled = force_tiled; return LICV_OK; }
+
 extern "C" int licv_attn_fwd(const licv_attn_args* x, void* stream) {
     LICV_CHECK_ARG(x && x->q && x->k && x->v && x->o, "attn_fwd: null pointer");
     LICV_CHECK_ARG(x->B > 0 && x->Sq > 0 && x->Sk > 0 && x->n_heads > 0 && x->n_kv_heads > 0, "attn_fwd: bad shape");
@@ -314,6 +466,28 @@ extern "C" int licv_attn_fwd(const licv_attn_args* x, void* stream) {
     p.B = (int)x->B; p.Sq = (int)x->Sq; p.Sk = (int)x->Sk; p.nh = (int)x->n_heads; p.nkv = (int)x->n_kv_heads; p.hd = (int)x->head_dim;
     p.scale = x->scale; p.mask_mode = x->mask_mode; p.key_valid = x->key_valid;
     p.img_mask = x->img_mask; p.n_img = (int)x->n_img; p.img_len = (int)x->img_len;
+    const int hd0 = (int)x->head_dim;
+    if (x->mask_mode == 0 && !g_attn_force_tiled && hd0 > 32 && hd0 <= 96 && x->Sk >= 128 && x->Sq >= 64) {
+        // resident-K/V variant: needs skp * (KSTR + VSTR) bytes of LDS
+        const int skp = (int)((x->Sk + 15) / 16 * 16) + 16;       // the transposing V read touches one 16-row group past the last real one
+        const int dpk = hd0 <= 64 ? 64 : 96, dpv = hd0 <= 64 ? 64 : (hd0 <= 80 ? 80 : 96);
+        const int64_t lds = (int64_t)skp * (lds_stride(dpk) + lds_stride(dpv));
+        if (lds <= 160 * 1024 && (int64_t)skp * 12 <= 5120) {
+            const int n_items = (int)(x->B * x->n_heads);
+            const dim3 rgrid((unsigned)(n_items < 256 ? n_items : 256)), rblock(512);
+            hipStream_t rst = (hipStream_t)stream;
+            const bool small = (int64_t)skp * (dpk / 8) <= 8 * 512;
+#define RES_LAUNCH(DK, DV, MI) do { static bool attr_##DK##_##DV##_##MI = false; \
+                if (!attr_##DK##_##DV##_##MI) { hipFuncSetAttribute((const void*)attn_resident_k<DK, DV, MI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_##DK##_##DV##_##MI = true; } \
+                attn_resident_k<DK, DV, MI><<<rgrid, rblock, lds, rst>>>(p, skp, n_items); } while (0)
+            if (dpk == 64)      { if (small) RES_LAUNCH(64, 64, 8); else RES_LAUNCH(64, 64, 10); }
+            else if (dpv == 80) { if (small) RES_LAUNCH(96, 80, 8); else RES_LAUNCH(96, 80, 10); }
+            else                { if (small) RES_LAUNCH(96, 96, 8); else RES_LAUNCH(96, 96, 10); }
+#undef RES_LAUNCH
+            LICV_LAUNCH_CHECK();
+            return LICV_OK;
+        }
+    }
     // 64 queries per 4-wave workgroup.  (The kernel also instantiates as QT slabs x NW waves per workgroup so a
     // K/V tile is fetched once for up to QT*NW*16 queries; measured SLOWER here — 745 vs 590 us on the ViT shape —
     // because this kernel is bound by softmax VALU + LDS, not by K/V loads, and fewer, fatter workgroups overlap

@@ -302,6 +302,30 @@ def test_attention_self(hd, mode):
     assert err <= 2e-2 * ref.abs().max(), err
 
 
+@pytest.mark.parametrize("hd,S,Sq", [(80, 257, 257), (96, 321, 64), (64, 200, 130)])
+def test_attention_resident_kv_variant_matches_tiled_and_reference(hd, S, Sq):
+    """Short unmasked key sequences (ViT 257 tokens, perceiver 64 latents over 321 keys) take the resident-K/V
+    kernel; it must agree with the tiled kernel and the fp32 reference."""
+    from licv import _lib
+    B, nh = 3, 4
+    H = nh * hd
+    q = torch.randn(B, Sq, H, generator=g(52)).to(torch.bfloat16)
+    kv = torch.randn(B, S, 2 * H, generator=g(53)).to(torch.bfloat16)
+    ref = _ref_attn(q.view(B, Sq, nh, hd).transpose(1, 2), kv[..., :H].view(B, S, nh, hd).transpose(1, 2),
+                    kv[..., H:].view(B, S, nh, hd).transpose(1, 2), None, hd ** -0.5).transpose(1, 2).reshape(B, Sq, H)
+    dq, dkv = q.to(DEV), kv.to(DEV)
+    outs = []
+    try:
+        for force_tiled in (0, 1):
+            _lib.lib().licv_attn_select(force_tiled)
+            outs.append(ops().attention(dq, dkv, dkv.view(-1)[H:], B, Sq, S, nh, nh, hd, Sq * H, H, S * 2 * H, 2 * H, hd ** -0.5, 0).clone())
+    finally:
+        _lib.lib().licv_attn_select(0)
+    for o in outs:
+        assert (o.float().cpu() - ref).abs().max() <= 2e-2 * ref.abs().max()
+    assert (outs[0].float() - outs[1].float()).abs().max() <= 2 ** -7 * ref.abs().max()
+
+
 def test_attention_cross_image_mask_and_gqa_decode():
     # cross-attention with the per-token image mask (rows seeing no image -> zeros), general img_len
     B, Sq, nh, hd, n_img, img_len = 2, 70, 4, 128, 3, 8
