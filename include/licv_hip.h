@@ -101,6 +101,8 @@ int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void*
  * N >= 256 and K % 64 == 0; else the general 128x128 kernel), 1 = always the 128x128 kernel, 2 = the 256x256
  * kernel whenever K % 64 == 0.  Process-wide. */
 int licv_gemm_select(int which);
+/* A/B switch for the persistent kernel's per-XCD start stagger (default on). */
+int licv_gemm_stagger(int on);
 /* (2I x K) gate/up weights -> the 16-row interleaved layout the swiglu epilogue expects. */
 int licv_pack_gate_up(const void* gate_bf16, const void* up_bf16, void* packed_bf16,
                       int64_t inter, int64_t K, void* stream);

@@ -513,6 +513,145 @@ void gemm_bf16_pingpong_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_
 }
 
 // ------------------------------------------------------------------------------------------------
+// Persistent ping-pong kernel: one workgroup per CU walks its share of the tile grid.  Between two tiles the
+// LDS-DMA of the NEXT tile's first three K-stages is issued into ring slots 0-2 BEFORE the current tile's
+// epilogue runs, so the pipeline fill (~2-3 us of DMA latency per tile) hides under the epilogue instead of
+// following a workgroup relaunch; the epilogue's output image then lives in the two remaining slots (64 KiB)
+// and is produced in four 64-row passes.  Same main loop, same math, same results as gemm_bf16_pingpong_k.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2)
+void gemm_bf16_persist_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw,
+                         void* __restrict__ C, int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n, GemmEpi ep,
+                         int stagger_sleeps) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // [5 stages][A 16 KiB | W 16 KiB]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int ntiles = tiles_m * tiles_n;
+    // Equal tiles keep all 256 CUs in lockstep: every CU reaches its epilogue at once, the chip alternates
+    // between a pure-MFMA phase and a pure HBM-write burst (measured ~7-10 us per 256x256 tile).  Start the
+    // 8 XCD groups (workgroups b, b+8, ... share an XCD and keep sharing operand slices through their L2)
+    // an eighth of a tile apart so one group's write burst lands under the other groups' MFMAs.
+    for (int i = 0, n = (blockIdx.x & 7) * stagger_sleeps; i < n; ++i) __builtin_amdgcn_s_sleep(64);
+    const int ns = K / 32;                                   // >= 4
+    const int fo = ring_off(lane & 15, lane >> 4);
+    char* const ybase = smem + 3 * RING_STAGE_BYTES;         // output image region: ring slots 3 and 4
+    constexpr int YS = 256 * 2 + 16;
+
+    const bf16_t* srcA[2];
+    const bf16_t* srcW[2];
+    int m0 = 0, n0 = 0;
+    auto set_tile = [&](int t) {
+        int tm, tn;
+        tile_coords(t, tiles_m, tiles_n, tm, tn);
+        m0 = tm * 256; n0 = tn * 256;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = wave * 32 + i * 16 + (lane >> 2);
+            const int chunk = (lane & 3) ^ (((row >> 2) & 1) << 1);
+            srcA[i] = A + (int64_t)min(m0 + row, M - 1) * lda + chunk * 8;
+            srcW[i] = W + (int64_t)min(n0 + row, N - 1) * ldw + chunk * 8;
+        }
+    };
+    auto issue = [&](int s) {
+        char* sa = smem + (s % RING_STAGES) * RING_STAGE_BYTES + wave * 32 * 64;
+        char* sw = sa + 16384;
+        const int64_t koff = (int64_t)s * 32;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + koff),
+                                             (__attribute__((address_space(3))) void*)(sa + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[i] + koff),
+                                             (__attribute__((address_space(3))) void*)(sw + i * 1024), 16, 0, 0);
+        }
+    };
+
+    // tile ids are dealt so that the 32 workgroups of an XCD (ids b, b+8, ...) walk a contiguous run together
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    set_tile(tile);
+    issue(0); issue(1); issue(2);
+    for (;;) {
+        const int cm0 = m0, cn0 = n0;                        // coordinates of the tile being computed
+        floatx4 acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+        bf16x8 fa[8], fw[4];
+        issue(3);
+        wait_vmcnt(12);                                      // everything older than the 12 youngest ops: stage 0 is in
+        __builtin_amdgcn_s_barrier();
+        if (wm == 1) __builtin_amdgcn_s_barrier();           // trailing group starts half a stage later
+        for (int s = 0; s < ns; ++s) {
+            {
+                const char* sa = smem + (s % RING_STAGES) * RING_STAGE_BYTES + (wm * 128) * 64 + fo;
+                const char* sw = smem + (s % RING_STAGES) * RING_STAGE_BYTES + 16384 + (wn * 64) * 64 + fo;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fw[j] = *reinterpret_cast<const bf16x8*>(sw + j * 16 * 64);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 64);
+                if (s + 4 < ns) issue(s + 4);
+                wait_vmcnt(4 * max(0, min(3, ns - 2 - s)));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        }
+        if (wm == 0) __builtin_amdgcn_s_barrier();           // leading group: match the barrier count
+
+        // ---- next tile's pipeline fill goes out before this tile's epilogue
+        const int next = tile + gridDim.x;
+        const bool more = next < ntiles;
+        if (more) { set_tile(next); issue(0); issue(1); issue(2); }
+
+        // ---- epilogue in four 64-row passes through the 64 KiB output image
+        {
+            const int cq = (lane >> 4) * 4;
+            float bv[4][4];
+            static_for<0, 4>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                const int ncol = cn0 + wn * 64 + j * 16 + cq;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bv[j][r] = (ep.bias && ncol + r < N) ? bf2f(ep.bias[ncol + r]) : 0.f;
+            });
+            static_for<0, 4>([&](auto pc) {
+                constexpr int P = decltype(pc)::value;
+                if (wm == (P >> 1)) {
+                    static_for<0, 4>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
+                        constexpr int I = 4 * (P & 1) + i;
+                        static_for<0, 4>([&](auto jc) {
+                            constexpr int j = decltype(jc)::value;
+                            uint2 u;
+                            u.x = (uint32_t)f2bf(acc[I][j][0] + bv[j][0]) | ((uint32_t)f2bf(acc[I][j][1] + bv[j][1]) << 16);
+                            u.y = (uint32_t)f2bf(acc[I][j][2] + bv[j][2]) | ((uint32_t)f2bf(acc[I][j][3] + bv[j][3]) << 16);
+                            *reinterpret_cast<uint2*>(ybase + (i * 16 + (lane & 15)) * YS + (wn * 64 + j * 16 + cq) * 2) = u;
+                        });
+                    });
+                }
+                __syncthreads();
+                if (ep.out_dtype == LICV_F32) epilogue_rows<64, 256, 8, 4>(ep, C, ldc, M, N, cm0 + 64 * P, cn0, wave, lane, ybase);
+                else                          epilogue_rows<64, 256, 8, 8>(ep, C, ldc, M, N, cm0 + 64 * P, cn0, wave, lane, ybase);
+                __syncthreads();
+            });
+        }
+        if (!more) break;
+        tile = next;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // 128 x 128 x 64, 4 waves, register staged (general shapes)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2)
@@ -605,6 +744,9 @@ void pack_gate_up_k(const bf16_t* __restrict__ g, const bf16_t* __restrict__ u, 
     }
 }
 
+static int g_stagger = 0;        // per-XCD start stagger of the persistent kernel: measured slower, off
+extern "C" int licv_gemm_stagger(int on) { g_stagger = on; return LICV_OK; }
+static int g_num_cus = 256;        // persistent grid size (queried once)
 static int g_force_kernel = 0;     // 0 auto, 1 tile128, 2 tile256 (tests / A-B timing)
 extern "C" int licv_gemm_select(int which) { g_force_kernel = which; return LICV_OK; }
 
@@ -629,7 +771,11 @@ extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
     ep.use_scale = e->use_scale; ep.scale = e->scale; ep.out_dtype = e->out_dtype;
     static bool attr_set = false;
     if (!attr_set) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            g_num_cus = cus;
         hipFuncSetAttribute((const void*)gemm_bf16_tile128_k, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        hipFuncSetAttribute((const void*)gemm_bf16_persist_k, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
         hipFuncSetAttribute((const void*)gemm_bf16_pingpong_k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
         hipFuncSetAttribute((const void*)gemm_bf16_pingpong_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
         hipFuncSetAttribute((const void*)gemm_bf16_ring_k, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
@@ -656,7 +802,12 @@ extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
         else if (g_force_kernel == 6 && K >= 128)
             gemm_bf16_pingpong_k<0><<<grid, block, RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>(
                 (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep);
-        else if (g_force_kernel == 0 && K >= 128)
+        else if (g_force_kernel == 8 && K >= 128)        // measured: no faster than relaunching (kept for A/B)
+            gemm_bf16_persist_k<<<dim3(min(tiles_m * tiles_n, g_num_cus)), block, RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>(
+                (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep,
+                // one tile ~ K/32 stages x ~1300 cycles; s_sleep 64 = 4096 cycles; an eighth of a tile per XCD group
+                (tiles_m * tiles_n > g_num_cus && g_stagger) ? (int)((K / 32) * 1300 / 8 / 4096 + 1) : 0);
+        else if ((g_force_kernel == 0 || g_force_kernel == 9) && K >= 128)
             gemm_bf16_pingpong_k<0><<<grid, block, RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>(
                 (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep);
         else LAUNCH256(0);

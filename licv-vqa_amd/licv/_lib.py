@@ -68,6 +68,7 @@ def lib() -> C.CDLL:
             "licv_gemm_bf16": [P, I64, P, I64, P, I64, I64, I64, I64, C.POINTER(GemmEpilogue), P],
             "licv_pack_gate_up": [P, P, P, I64, I64, P],
             "licv_gemm_select": [I],
+            "licv_gemm_stagger": [I],
             "licv_attn_select": [I],
             "licv_attn_fwd": [C.POINTER(AttnArgs), P],
             "licv_embed_gather": [P, P, P, P, I64, I64, I64, I64, P],

@@ -8,8 +8,8 @@ for (M,N,K) in shapes:
     a=torch.randn(M,K,device='cuda').to(torch.bfloat16); w=(torch.randn(N,K,device='cuda')*0.02).to(torch.bfloat16)
     res={}
     outs={}
-    for which in (1,6,1,6):
-        lib.licv_gemm_select(which)
+    for which in (6,8,18,6,8,18):
+        lib.licv_gemm_select(8 if which==18 else which); lib.licv_gemm_stagger(0 if which==18 else 1)
         for _ in range(2): o=ops.linear(a,w)
         torch.cuda.synchronize()
         e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True)
@@ -20,8 +20,8 @@ for (M,N,K) in shapes:
         t=e0.elapsed_time(e1)/n*1e-3
         res.setdefault(which,[]).append(2*M*N*K/t/1e12)
         outs[which]=o
-    same=torch.equal(outs[1],outs[6])
+    same=torch.equal(outs[6],outs[8])
     ref=(a[:64].float()@w.float().t())
     err=float((outs[6][:64].float()-ref).abs().max()/ref.abs().max())
-    print(f"{M:6d} {N:6d} {K:6d}  tile128 {max(res[1]):7.1f} TF  pingpong {max(res[6]):7.1f} TF  same={same} relerr={err:.2e}", flush=True)
+    print(f"{M:6d} {N:6d} {K:6d}  pingpong {max(res[6]):7.1f} TF  persist+stagger {max(res[8]):7.1f}  persist-nostagger {max(res[18]):7.1f} TF  same={same} relerr={err:.2e}", flush=True)
 lib.licv_gemm_select(0)
