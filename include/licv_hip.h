@@ -148,6 +148,25 @@ int licv_tile_rows(const void* src_bf16, void* out_bf16, int64_t rows, int64_t d
 /* silu(g)*u for an un-fused (M, 2I) [gate | up] buffer (kept for tests / odd shapes). */
 int licv_swiglu(const void* gu_bf16, void* out_bf16, int64_t rows, int64_t inter, void* stream);
 
+/* ---- backward of the student pass (ref:icv_src/icv_module.py:97-98: hooked forward WITH grad; the LMM is frozen, so
+ * only d loss / d hidden-state is propagated; dense-layer input grads reuse licv_gemm_bf16 on transposed weights) ---- */
+/* RMSNorm backward (Idefics flavour forward): dx (+)= rs*(g - xhat*mean(g*xhat)), g = bf16(dy*w); rows addressed as forward */
+int licv_rmsnorm_bwd(const void* x, int x_dtype, const void* w_bf16, const void* dy, int dy_dtype, void* dx, int dx_dtype,
+                     int64_t rows, int64_t dim, int64_t inner, int64_t ld_x, int64_t ld_dy, int64_t ld_dx, float eps,
+                     int accumulate, void* stream);
+/* SwiGLU backward on the unfused (rows, 2I) [gate | up] buffer */
+int licv_swiglu_bwd(const void* gu_bf16, const void* dact_bf16, void* dgu_bf16, int64_t rows, int64_t inter, void* stream);
+/* grad entering a residual branch: out = bf16(bf16(dh)*scale), rows with row_gate == 0 zeroed (row_gate may be NULL) */
+int licv_branch_grad(const float* dh, void* out_bf16, int64_t rows, int64_t dim, float scale, int use_scale,
+                     const float* row_gate, void* stream);
+/* attention backward for short sequences (Sq*Sk <= 16384), same argument struct as the forward; dk/dv may be NULL */
+int licv_attn_bwd_small(const licv_attn_args* a, const void* dout_bf16, void* dq_bf16, int64_t dq_bs, int64_t dq_rs,
+                        void* dk_bf16, void* dv_bf16, int64_t dkv_bs, int64_t dkv_rs, void* stream);
+/* d loss / d student logits for the masked-KL rows: (n_rows, ld_grad >= vocab) bf16, scaled by upstream * T^2 / n_rows */
+int licv_kl_rows_bwd(const void* stu_logits, const void* tea_logits, int dtype, const int64_t* stu_rows, const int64_t* tea_rows,
+                     int64_t n_rows, int64_t vocab, int64_t ld_stu, int64_t ld_tea, float temperature, float eps, float upstream,
+                     void* grad_rows_bf16, int64_t ld_grad, void* stream);
+
 /* ---- loss + optimiser (ref:icv_src/icv_module.py:121-134, :171-209) ---- */
 /* per-row KL(teacher||student) with eps inside the log, rows gathered by index; out_rows fp32 (n_rows). */
 int licv_kl_rows_fwd(const void* stu_logits, const void* tea_logits, int dtype,

@@ -1,0 +1,345 @@
+// Backward kernels for the L-ICV student pass (ref:icv_src/icv_module.py:97-98 runs the hooked forward with grad;
+// only `icv` and `alpha` are trainable, so what is needed is d loss / d hidden-state through the frozen LMM).
+// Dense-layer input gradients reuse the forward MFMA GEMM on transposed weight copies; this file holds the
+// rest: RMSNorm, SwiGLU, rotary (inverse rotation = forward kernel with -sin), small-sequence attention, the
+// masked-KL rows, and the residual-branch cast.  The student sequence is the query only (tens of tokens), so
+// these kernels favour simplicity over peak throughput; fp32 maths, bf16 where the forward rounded.
+#include "common.h"
+
+#define BW_WAVES 4
+
+__device__ __forceinline__ floatx4 ld4(const void* p, int dt, int64_t i) {
+    if (dt == LICV_F32) return *reinterpret_cast<const floatx4*>(reinterpret_cast<const float*>(p) + i);
+    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(p) + i);
+    floatx4 r;
+    r[0] = __uint_as_float(u.x << 16); r[1] = __uint_as_float(u.x & 0xffff0000u);
+    r[2] = __uint_as_float(u.y << 16); r[3] = __uint_as_float(u.y & 0xffff0000u);
+    return r;
+}
+__device__ __forceinline__ void st4(void* p, int dt, int64_t i, floatx4 v) {
+    if (dt == LICV_F32) { *reinterpret_cast<floatx4*>(reinterpret_cast<float*>(p) + i) = v; return; }
+    uint2 u;
+    u.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+    u.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p) + i) = u;
+}
+
+// ------------------------------------------------------------------------------------------------
+// RMSNorm backward (hf:idefics/modeling_idefics.py:342-350 forward: y = w * bf16(x * rsqrt(mean(x^2)+eps))).
+// g = bf16(dy * w); dx = rs * (g - xhat * mean(g * xhat));  dx is ADDED to `dx_acc` when accumulate != 0.
+// Rows addressed like the forward kernel (inner / ld) so the per-head q norm works in place.
+// ------------------------------------------------------------------------------------------------
+template <int NCH>
+__global__ __launch_bounds__(64 * BW_WAVES)
+void rmsnorm_bwd_k(const void* __restrict__ x, int x_dt, const bf16_t* __restrict__ w, const void* __restrict__ dy, int dy_dt,
+                   void* __restrict__ dx, int dx_dt, int64_t rows, int dim, int64_t inner, int64_t ld_x, int64_t ld_dy,
+                   int64_t ld_dx, float eps, int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * BW_WAVES + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int64_t ro = row / inner, ri = row % inner;
+    const int64_t xb = ro * ld_x + ri * dim, yb = ro * ld_dy + ri * dim, db = ro * ld_dx + ri * dim;
+    floatx4 xv[NCH], gv[NCH];
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int i = (c * 64 + lane) * 4;
+        if (i < dim) {
+            xv[c] = ld4(x, x_dt, xb + i);
+            const floatx4 d = ld4(dy, dy_dt, yb + i);
+            const floatx4 wv = ld4(w, LICV_BF16, i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { ss += xv[c][j] * xv[c][j]; gv[c][j] = rbf(d[j] * wv[j]); }
+        }
+    }
+    ss = wave_sum(ss);
+    const float rs = rsqrtf(ss / (float)dim + eps);
+    float dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int i = (c * 64 + lane) * 4;
+        if (i < dim) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dot += gv[c][j] * xv[c][j] * rs;
+        }
+    }
+    dot = wave_sum(dot) / (float)dim;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int i = (c * 64 + lane) * 4;
+        if (i < dim) {
+            floatx4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = rs * (gv[c][j] - xv[c][j] * rs * dot);
+            if (accumulate) { const floatx4 a = ld4(dx, dx_dt, db + i);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] += a[j]; }
+            st4(dx, dx_dt, db + i, o);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// SwiGLU backward on the UNFUSED (rows, 2I) [gate | up] buffer: act = bf16(silu(g)) * u.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void swiglu_bwd_k(const bf16_t* __restrict__ gu, const bf16_t* __restrict__ dact, bf16_t* __restrict__ dgu, int64_t rows, int64_t inter) {
+    const int64_t total = rows * inter;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = idx / inter, c = idx % inter;
+        const float g = bf2f(gu[r * 2 * inter + c]);
+        const float u = bf2f(gu[r * 2 * inter + inter + c]);
+        const float d = bf2f(dact[idx]);
+        const float sig = 1.0f / (1.0f + __expf(-g));
+        const float s = rbf(g * sig);
+        const float ds = rbf(d * u);                                // grad wrt silu(g) (bf16 like the autograd product)
+        const float dsilu = sig * (1.0f + g * (1.0f - sig));
+        dgu[r * 2 * inter + c] = f2bf(ds * dsilu);
+        dgu[r * 2 * inter + inter + c] = f2bf(d * s);
+    }
+}
+
+// residual branch grad: out = bf16(bf16(dh) * scale), rows with gate == 0 zeroed (gated cross-attention / plain branch)
+__global__ __launch_bounds__(256)
+void branch_grad_k(const float* __restrict__ dh, bf16_t* __restrict__ out, int64_t rows, int64_t dim, float scale, int use_scale,
+                   const float* __restrict__ row_gate) {
+    const int64_t total = rows * dim;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = idx / dim;
+        float v = rbf(dh[idx]);
+        if (use_scale) v = rbf(v * scale);
+        if (row_gate && row_gate[r] == 0.0f) v = 0.0f;
+        out[idx] = f2bf(v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Attention backward for SHORT sequences (Sq * Sk <= 16384): one workgroup per (batch, head); P and dS live in
+// LDS as fp32 (Sq x Sk each).  Thread i owns query row i for P/dS/dQ, then thread j owns key j for dK/dV.
+// mask_mode as in the forward kernel (0 none, 1 causal + key_valid, 3 image mask).  want_dkv = 0 skips dK/dV
+// (cross-attention: K/V come from the frozen vision side).
+// ------------------------------------------------------------------------------------------------
+struct AttnBwdP {
+    const bf16_t* q; int64_t q_bs, q_rs;
+    const bf16_t* k; const bf16_t* v; int64_t kv_bs, kv_rs;
+    const bf16_t* dout;                 // (B, Sq, nh*hd) dense
+    bf16_t* dq; int64_t dq_bs, dq_rs;
+    bf16_t* dk; bf16_t* dv; int64_t dkv_bs, dkv_rs;
+    int B, Sq, Sk, nh, nkv, hd;
+    float scale;
+    int mask_mode;
+    const int32_t* key_valid;
+    const int32_t* img_mask; int n_img, img_len;
+    int want_dkv;
+};
+
+__global__ __launch_bounds__(256)
+void attn_bwd_small_k(AttnBwdP a) {
+    extern __shared__ float bsm[];
+    float* P = bsm;                          // Sq x Sk
+    float* dS = bsm + a.Sq * a.Sk;           // Sq x Sk
+    const int head = blockIdx.x % a.nh, b = blockIdx.x / a.nh;
+    const int kvh = head / (a.nh / a.nkv);
+    const int coff = a.Sk - a.Sq;
+    const bf16_t* qb = a.q + (int64_t)b * a.q_bs + (int64_t)head * a.hd;
+    const bf16_t* kb = a.k + (int64_t)b * a.kv_bs + (int64_t)kvh * a.hd;
+    const bf16_t* vb = a.v + (int64_t)b * a.kv_bs + (int64_t)kvh * a.hd;
+    const bf16_t* dob = a.dout + (int64_t)b * a.Sq * a.nh * a.hd + (int64_t)head * a.hd;
+    for (int i = threadIdx.x; i < a.Sq; i += blockDim.x) {
+        const bf16_t* qi = qb + (int64_t)i * a.q_rs;
+        const bf16_t* doi = dob + (int64_t)i * a.nh * a.hd;
+        const int32_t* imrow = a.mask_mode == 3 ? a.img_mask + ((int64_t)b * a.Sq + i) * a.n_img : nullptr;
+        float mx = -INFINITY;
+        for (int j = 0; j < a.Sk; ++j) {
+            bool ok = true;
+            if (a.mask_mode == 1) ok = (j <= i + coff) && (!a.key_valid || a.key_valid[(int64_t)b * a.Sk + j] != 0);
+            else if (a.mask_mode == 2) ok = !a.key_valid || a.key_valid[(int64_t)b * a.Sk + j] != 0;
+            else if (a.mask_mode == 3) ok = imrow[j / a.img_len] != 0;
+            float s = -INFINITY;
+            if (ok) {
+                const bf16_t* kj = kb + (int64_t)j * a.kv_rs;
+                float acc = 0.f;
+                for (int d = 0; d < a.hd; ++d) acc += bf2f(qi[d]) * bf2f(kj[d]);
+                s = acc * a.scale;
+            }
+            P[i * a.Sk + j] = s;
+            mx = fmaxf(mx, s);
+        }
+        float sum = 0.f;
+        for (int j = 0; j < a.Sk; ++j) {
+            const float s = P[i * a.Sk + j];
+            const float e = (s == -INFINITY) ? 0.f : __expf(s - mx);
+            P[i * a.Sk + j] = e;
+            sum += e;
+        }
+        const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+        float D = 0.f;                           // sum_j p_ij dP_ij
+        for (int j = 0; j < a.Sk; ++j) {
+            const float p = rbf(P[i * a.Sk + j] * inv);           // forward rounds the probabilities to bf16
+            P[i * a.Sk + j] = p;
+            float dp = 0.f;
+            if (p != 0.f) {
+                const bf16_t* vj = vb + (int64_t)j * a.kv_rs;
+                for (int d = 0; d < a.hd; ++d) dp += bf2f(doi[d]) * bf2f(vj[d]);
+            }
+            dS[i * a.Sk + j] = dp;
+            D += p * dp;
+        }
+        for (int j = 0; j < a.Sk; ++j) dS[i * a.Sk + j] = P[i * a.Sk + j] * (dS[i * a.Sk + j] - D) * a.scale;
+        // dQ_i = sum_j dS_ij K_j
+        bf16_t* dqi = a.dq + (int64_t)b * a.dq_bs + (int64_t)i * a.dq_rs + (int64_t)head * a.hd;
+        for (int d = 0; d < a.hd; ++d) {
+            float acc = 0.f;
+            for (int j = 0; j < a.Sk; ++j) {
+                const float ds = dS[i * a.Sk + j];
+                if (ds != 0.f) acc += ds * bf2f(kb[(int64_t)j * a.kv_rs + d]);
+            }
+            dqi[d] = f2bf(acc);
+        }
+    }
+    if (!a.want_dkv) return;
+    __syncthreads();
+    // dK_j = sum_i dS_ij Q_i ; dV_j = sum_i P_ij dO_i.  GQA: several query heads share a kv head -> the caller passes
+    // n_kv_heads == n_heads layouts only (asserted on the host) so each (b, head) owns its dK/dV slice.
+    for (int j = threadIdx.x; j < a.Sk; j += blockDim.x) {
+        bf16_t* dkj = a.dk + (int64_t)b * a.dkv_bs + (int64_t)j * a.dkv_rs + (int64_t)head * a.hd;
+        bf16_t* dvj = a.dv + (int64_t)b * a.dkv_bs + (int64_t)j * a.dkv_rs + (int64_t)head * a.hd;
+        for (int d = 0; d < a.hd; ++d) {
+            float ak = 0.f, av = 0.f;
+            for (int i = 0; i < a.Sq; ++i) {
+                ak += dS[i * a.Sk + j] * bf2f(qb[(int64_t)i * a.q_rs + d]);
+                av += P[i * a.Sk + j] * bf2f(dob[(int64_t)i * a.nh * a.hd + d]);
+            }
+            dkj[d] = f2bf(ak);
+            dvj[d] = f2bf(av);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// d/d student-logits of  mean_rows( sum_v p (log(p+eps) - log(q+eps)) ) * T^2   (ref:icv_src/icv_module.py:121-134)
+// grad rows are written densely: (n_rows, vocab) bf16.  upstream = d loss / d kl (normally 1).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float blk_reduce(float v, bool is_max, float* red) {
+    v = is_max ? wave_max(v) : wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float r = red[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = is_max ? fmaxf(r, red[w]) : r + red[w];
+    return r;
+}
+
+template <bool BF>
+__global__ __launch_bounds__(256)
+void kl_rows_bwd_k(const void* __restrict__ stu, const void* __restrict__ tea, const int64_t* __restrict__ srows,
+                   const int64_t* __restrict__ trows, int64_t vocab, int64_t ld_s, int64_t ld_t, float T, float eps,
+                   float coef, bf16_t* __restrict__ grad, int64_t ld_g) {
+    __shared__ float red[8];
+    const int64_t row = blockIdx.x;
+    const int64_t sb = srows[row] * ld_s, tb = trows[row] * ld_t;
+    auto ld = [&](const void* p, int64_t i) -> float {
+        return BF ? bf2f(reinterpret_cast<const bf16_t*>(p)[i]) : reinterpret_cast<const float*>(p)[i];
+    };
+    float ms = -INFINITY, mt = -INFINITY;
+    for (int64_t i = threadIdx.x; i < vocab; i += blockDim.x) { ms = fmaxf(ms, ld(stu, sb + i) / T); mt = fmaxf(mt, ld(tea, tb + i) / T); }
+    ms = blk_reduce(ms, true, red); mt = blk_reduce(mt, true, red);
+    float zs = 0.f, zt = 0.f;
+    for (int64_t i = threadIdx.x; i < vocab; i += blockDim.x) { zs += __expf(ld(stu, sb + i) / T - ms); zt += __expf(ld(tea, tb + i) / T - mt); }
+    zs = blk_reduce(zs, false, red); zt = blk_reduce(zt, false, red);
+    // g_v = d kl_row / d q_v = -p_v / (q_v + eps);  d kl_row / d z_u = (1/T) q_u (g_u - sum_v q_v g_v)
+    float qg = 0.f;
+    for (int64_t i = threadIdx.x; i < vocab; i += blockDim.x) {
+        const float q = __expf(ld(stu, sb + i) / T - ms) / zs;
+        const float p = __expf(ld(tea, tb + i) / T - mt) / zt;
+        qg += q * (-p / (q + eps));
+    }
+    qg = blk_reduce(qg, false, red);
+    for (int64_t i = threadIdx.x; i < vocab; i += blockDim.x) {
+        const float q = __expf(ld(stu, sb + i) / T - ms) / zs;
+        const float p = __expf(ld(tea, tb + i) / T - mt) / zt;
+        const float gz = q * ((-p / (q + eps)) - qg) / T;
+        grad[row * ld_g + i] = f2bf(gz * coef);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host launchers
+// ------------------------------------------------------------------------------------------------
+static inline int nch_for(int64_t dim) { for (int n = 1; n <= 32; n <<= 1) if ((int64_t)n * 256 >= dim) return n; return 0; }
+static inline int flat_grid(int64_t total) { int64_t b = (total + 255) / 256; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
+
+extern "C" int licv_rmsnorm_bwd(const void* x, int x_dtype, const void* w_bf16, const void* dy, int dy_dtype, void* dx, int dx_dtype,
+                                int64_t rows, int64_t dim, int64_t inner, int64_t ld_x, int64_t ld_dy, int64_t ld_dx, float eps,
+                                int accumulate, void* stream) {
+    LICV_CHECK_ARG(x && w_bf16 && dy && dx, "rmsnorm_bwd: null pointer");
+    LICV_CHECK_ARG(dim > 0 && dim % 4 == 0 && inner >= 1 && ld_x % 4 == 0 && ld_dy % 4 == 0 && ld_dx % 4 == 0, "rmsnorm_bwd: dims must be multiples of 4");
+    if (rows <= 0) return LICV_OK;
+    const int nch = nch_for(dim);
+    LICV_CHECK_ARG(nch > 0 && nch <= 16, "rmsnorm_bwd: row length %lld unsupported", (long long)dim);
+    const dim3 grid((unsigned)((rows + BW_WAVES - 1) / BW_WAVES)), block(64 * BW_WAVES);
+    hipStream_t st = (hipStream_t)stream;
+#define L(NC) rmsnorm_bwd_k<NC><<<grid, block, 0, st>>>(x, x_dtype, (const bf16_t*)w_bf16, dy, dy_dtype, dx, dx_dtype, rows, (int)dim, inner, ld_x, ld_dy, ld_dx, eps, accumulate)
+    switch (nch) { case 1: L(1); break; case 2: L(2); break; case 4: L(4); break; case 8: L(8); break; default: L(16); break; }
+#undef L
+    LICV_LAUNCH_CHECK();
+    return LICV_OK;
+}
+
+extern "C" int licv_swiglu_bwd(const void* gu_bf16, const void* dact_bf16, void* dgu_bf16, int64_t rows, int64_t inter, void* stream) {
+    LICV_CHECK_ARG(gu_bf16 && dact_bf16 && dgu_bf16 && inter > 0, "swiglu_bwd: bad argument");
+    if (rows <= 0) return LICV_OK;
+    swiglu_bwd_k<<<flat_grid(rows * inter), 256, 0, (hipStream_t)stream>>>((const bf16_t*)gu_bf16, (const bf16_t*)dact_bf16, (bf16_t*)dgu_bf16, rows, inter);
+    LICV_LAUNCH_CHECK();
+    return LICV_OK;
+}
+
+extern "C" int licv_branch_grad(const float* dh, void* out_bf16, int64_t rows, int64_t dim, float scale, int use_scale,
+                                const float* row_gate, void* stream) {
+    LICV_CHECK_ARG(dh && out_bf16 && dim > 0, "branch_grad: bad argument");
+    if (rows <= 0) return LICV_OK;
+    branch_grad_k<<<flat_grid(rows * dim), 256, 0, (hipStream_t)stream>>>(dh, (bf16_t*)out_bf16, rows, dim, scale, use_scale, row_gate);
+    LICV_LAUNCH_CHECK();
+    return LICV_OK;
+}
+
+extern "C" int licv_attn_bwd_small(const licv_attn_args* x, const void* dout, void* dq, int64_t dq_bs, int64_t dq_rs,
+                                   void* dk, void* dv, int64_t dkv_bs, int64_t dkv_rs, void* stream) {
+    LICV_CHECK_ARG(x && x->q && x->k && x->v && dout && dq, "attn_bwd_small: null pointer");
+    LICV_CHECK_ARG(x->Sq > 0 && x->Sk > 0 && x->Sq * x->Sk <= 16384, "attn_bwd_small: Sq*Sk = %lld exceeds the short-sequence limit 16384",
+                   (long long)(x->Sq * x->Sk));
+    LICV_CHECK_ARG(x->mask_mode >= 0 && x->mask_mode <= 3, "attn_bwd_small: bad mask mode");
+    LICV_CHECK_ARG(x->mask_mode != 3 || (x->img_mask && x->n_img > 0 && x->img_len > 0), "attn_bwd_small: image mask arguments missing");
+    const int want = (dk && dv) ? 1 : 0;
+    LICV_CHECK_ARG(!want || x->n_heads == x->n_kv_heads, "attn_bwd_small: dK/dV need n_kv_heads == n_heads");
+    AttnBwdP p;
+    p.q = (const bf16_t*)x->q; p.q_bs = x->q_bs; p.q_rs = x->q_rs;
+    p.k = (const bf16_t*)x->k; p.v = (const bf16_t*)x->v; p.kv_bs = x->kv_bs; p.kv_rs = x->kv_rs;
+    p.dout = (const bf16_t*)dout; p.dq = (bf16_t*)dq; p.dq_bs = dq_bs; p.dq_rs = dq_rs;
+    p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv; p.dkv_bs = dkv_bs; p.dkv_rs = dkv_rs;
+    p.B = (int)x->B; p.Sq = (int)x->Sq; p.Sk = (int)x->Sk; p.nh = (int)x->n_heads; p.nkv = (int)x->n_kv_heads; p.hd = (int)x->head_dim;
+    p.scale = x->scale; p.mask_mode = x->mask_mode; p.key_valid = x->key_valid; p.img_mask = x->img_mask;
+    p.n_img = (int)x->n_img; p.img_len = (int)x->img_len; p.want_dkv = want;
+    const size_t lds = (size_t)2 * x->Sq * x->Sk * sizeof(float);
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute((const void*)attn_bwd_small_k, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); attr = true; }
+    attn_bwd_small_k<<<(unsigned)(x->B * x->n_heads), 256, lds, (hipStream_t)stream>>>(p);
+    LICV_LAUNCH_CHECK();
+    return LICV_OK;
+}
+
+extern "C" int licv_kl_rows_bwd(const void* stu_logits, const void* tea_logits, int dtype, const int64_t* stu_rows, const int64_t* tea_rows,
+                                int64_t n_rows, int64_t vocab, int64_t ld_stu, int64_t ld_tea, float temperature, float eps, float upstream,
+                                void* grad_rows_bf16, int64_t ld_grad, void* stream) {
+    LICV_CHECK_ARG(stu_logits && tea_logits && stu_rows && tea_rows && grad_rows_bf16, "kl_rows_bwd: null pointer");
+    LICV_CHECK_ARG(dtype == LICV_BF16 || dtype == LICV_F32, "kl_rows_bwd: bad dtype");
+    LICV_CHECK_ARG(ld_grad >= vocab, "kl_rows_bwd: ld_grad smaller than vocab");
+    if (n_rows <= 0) return LICV_OK;
+    const float coef = upstream * temperature * temperature / (float)n_rows;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == LICV_BF16) kl_rows_bwd_k<true><<<(unsigned)n_rows, 256, 0, st>>>(stu_logits, tea_logits, stu_rows, tea_rows, vocab, ld_stu, ld_tea, temperature, eps, coef, (bf16_t*)grad_rows_bf16, ld_grad);
+    else                    kl_rows_bwd_k<false><<<(unsigned)n_rows, 256, 0, st>>>(stu_logits, tea_logits, stu_rows, tea_rows, vocab, ld_stu, ld_tea, temperature, eps, coef, (bf16_t*)grad_rows_bf16, ld_grad);
+    LICV_LAUNCH_CHECK();
+    return LICV_OK;
+}

@@ -76,6 +76,11 @@ def lib() -> C.CDLL:
             "licv_vit_embed_ln": [P, P, P, P, P, P, I64, I64, I64, F, P],
             "licv_tile_rows": [P, P, I64, I64, I64, P],
             "licv_swiglu": [P, P, I64, I64, P],
+            "licv_rmsnorm_bwd": [P, I, P, P, I, P, I, I64, I64, I64, I64, I64, I64, F, I, P],
+            "licv_swiglu_bwd": [P, P, P, I64, I64, P],
+            "licv_branch_grad": [P, P, I64, I64, F, I, P, P],
+            "licv_attn_bwd_small": [C.POINTER(AttnArgs), P, P, I64, I64, P, P, I64, I64, P],
+            "licv_kl_rows_bwd": [P, P, I, P, P, I64, I64, I64, I64, F, F, F, P, I64, P],
             "licv_kl_rows_fwd": [P, P, I, P, P, I64, I64, I64, I64, F, F, P, P],
             "licv_adamw_step": [P, P, P, P, I64, I64, F, F, F, F, F, F, I64, F, P],
         }

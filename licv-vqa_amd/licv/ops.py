@@ -268,3 +268,61 @@ def adamw_step_(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tens
     check(_lib.lib().licv_adamw_step(_p(p), _p(g), _p(m), _p(v), p.numel(), n_group0, lr0, lr1, beta1, beta2, eps,
                                      weight_decay, step, grad_scale, _stream(p)))
     return p
+
+
+# ------------------------------------------------------------------------------------------ backward (student pass)
+def rmsnorm_bwd(x: torch.Tensor, w: torch.Tensor, dy: torch.Tensor, dx: torch.Tensor, eps: float, accumulate: bool,
+                inner: int = 1, ld_x: Optional[int] = None, ld_dy: Optional[int] = None, ld_dx: Optional[int] = None,
+                rows: Optional[int] = None, dim: Optional[int] = None):
+    dim = x.shape[-1] if dim is None else dim
+    rows = x.numel() // dim if rows is None else rows
+    ld_x = dim * inner if ld_x is None else ld_x
+    ld_dy = dim * inner if ld_dy is None else ld_dy
+    ld_dx = dim * inner if ld_dx is None else ld_dx
+    check(_lib.lib().licv_rmsnorm_bwd(_p(x), _dt(x), _p(w), _p(dy), _dt(dy), _p(dx), _dt(dx), rows, dim, inner, ld_x, ld_dy, ld_dx,
+                                      float(eps), 1 if accumulate else 0, _stream(x)))
+    return dx
+
+
+def swiglu_bwd(gu: torch.Tensor, dact: torch.Tensor) -> torch.Tensor:
+    rows, two_i = gu.shape
+    out = torch.empty_like(gu)
+    check(_lib.lib().licv_swiglu_bwd(_p(gu), _p(dact), _p(out), rows, two_i // 2, _stream(gu)))
+    return out
+
+
+def branch_grad(dh: torch.Tensor, scale: Optional[float] = None, row_gate: Optional[torch.Tensor] = None) -> torch.Tensor:
+    assert dh.dtype == torch.float32 and dh.is_contiguous()
+    rows, dim = dh.shape
+    out = torch.empty((rows, dim), dtype=torch.bfloat16, device=dh.device)
+    check(_lib.lib().licv_branch_grad(_p(dh), _p(out), rows, dim, 0.0 if scale is None else float(scale), 0 if scale is None else 1,
+                                      _p(row_gate), _stream(dh)))
+    return out
+
+
+def attention_bwd_small(q, k, v, dout, B, Sq, Sk, n_heads, n_kv_heads, head_dim, q_bs, q_rs, kv_bs, kv_rs, scale, mask_mode,
+                        dq, dq_bs, dq_rs, dk=None, dv=None, dkv_bs=0, dkv_rs=0, key_valid=None, img_mask=None, img_len=0):
+    a = AttnArgs()
+    a.q, a.q_bs, a.q_rs = q.data_ptr(), q_bs, q_rs
+    a.k, a.v, a.kv_bs, a.kv_rs = k.data_ptr(), v.data_ptr(), kv_bs, kv_rs
+    a.o = None
+    a.B, a.Sq, a.Sk, a.n_heads, a.n_kv_heads, a.head_dim = B, Sq, Sk, n_heads, n_kv_heads, head_dim
+    a.scale, a.mask_mode = float(scale), mask_mode
+    a.key_valid = key_valid.data_ptr() if key_valid is not None else None
+    if img_mask is not None:
+        a.img_mask, a.n_img, a.img_len = img_mask.data_ptr(), img_mask.shape[-1], img_len
+    else:
+        a.img_mask, a.n_img, a.img_len = None, 0, 0
+    assert dout.is_contiguous() and dout.dtype == torch.bfloat16
+    check(_lib.lib().licv_attn_bwd_small(C.byref(a), _p(dout), _p(dq), dq_bs, dq_rs, _p(dk), _p(dv), dkv_bs, dkv_rs, _stream(q)))
+    return dq
+
+
+def kl_rows_bwd(stu, tea, stu_rows, tea_rows, vocab, temperature, eps, upstream=1.0) -> torch.Tensor:
+    """Returns (n_rows, vocab_padded_to_8) bf16 with zero pad columns (so it can feed the head's dgrad GEMM directly)."""
+    n = stu_rows.numel()
+    ld = (vocab + 7) // 8 * 8
+    grad = torch.zeros((n, ld), dtype=torch.bfloat16, device=stu.device)
+    check(_lib.lib().licv_kl_rows_bwd(_p(stu), _p(tea), _dt(stu), _p(stu_rows), _p(tea_rows), n, vocab, stu.stride(0), tea.stride(0),
+                                      float(temperature), float(eps), float(upstream), _p(grad), ld, _stream(stu)))
+    return grad

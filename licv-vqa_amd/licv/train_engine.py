@@ -1,0 +1,195 @@
+"""Student pass WITH gradient for L-ICV training (ref:icv_src/icv_module.py:71-119).
+
+Only ``icv`` and ``alpha`` are trainable and the LMM is frozen, so the backward needs exactly one thing:
+d loss / d hidden-state propagated from the masked-KL rows down through the language stack, with the hook's
+backward kernel peeling off d loss / d (alpha*icv) at every hooked layer.  The vision side, the embeddings
+and the cross-attention K/V never receive gradient (they do not depend on the ICV).
+
+Forward = the inference engine's layer loop with the MLP gate/up left unfused so the backward has g and u,
+every tensor the backward reads kept (the student sequence is the query only: tens of tokens).
+Backward = explicit, layer by layer, every step a HIP kernel: dense-layer input gradients are the forward
+MFMA GEMM on transposed weight copies (built once by ``TrainWeights``).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import ops
+from .idefics_engine import IdeficsEngine, IdeficsWeights
+
+
+def _t(w: torch.Tensor) -> torch.Tensor:
+    return w.t().contiguous()
+
+
+class TrainWeights:
+    """Transposed / unfused copies of the language-stack weights needed by the backward (built lazily, once)."""
+
+    def __init__(self, w: IdeficsWeights, sd: Dict[str, torch.Tensor]):
+        dev = w.device
+        g = lambda k: sd[k].detach().to(device=dev, dtype=torch.bfloat16).contiguous()
+        self.dec, self.xat = [], []
+        for i, D in enumerate(w.dec):
+            p = f"model.layers.{i}."
+            gu = torch.cat([g(p + "mlp.gate_proj.weight"), g(p + "mlp.up_proj.weight")]).contiguous()      # (2I, H) gate | up
+            self.dec.append(dict(gu=gu, gu_T=_t(gu), down_T=_t(D.down_w), o_T=_t(D.o_w), qkv_T=_t(D.qkv_w)))
+        for j, X in enumerate(w.xat):
+            p = f"model.gated_cross_attn_layers.{j}."
+            gu = torch.cat([g(p + "mlp.gate_proj.weight"), g(p + "mlp.up_proj.weight")]).contiguous()
+            self.xat.append(dict(gu=gu, gu_T=_t(gu), down_T=_t(X.down_w), o_T=_t(X.o_w), q_T=_t(X.q_w)))
+        V = w.lm_head.shape[0]
+        head_T = torch.zeros((w.lm_head.shape[1], (V + 7) // 8 * 8), dtype=torch.bfloat16, device=dev)     # (H, V padded to 8)
+        head_T[:, :V] = w.lm_head.t()
+        self.head_T = head_T
+        self.neg_sin = (-w.sin.float()).to(torch.bfloat16).contiguous()
+
+
+class StudentPass:
+    """One hooked forward that keeps what the backward needs, and its backward."""
+
+    def __init__(self, engine: IdeficsEngine, tw: TrainWeights):
+        self.e, self.tw = engine, tw
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, input_ids, attention_mask, pixel_values, image_attention_mask, icv: torch.Tensor,
+                hook_layers: Sequence[int], alpha: Optional[torch.Tensor], logits_rows: torch.Tensor):
+        """icv (1,n,H) fp32 and alpha (1,n) fp32 as in IdeficsEngine.forward; logits only for `logits_rows`
+        (flat b*S+t indices of the answer tokens).  Returns (logits_rows (R, V) bf16 view, saved state)."""
+        e, a, w, tw = self.e, self.e.arch, self.e.w, self.tw
+        dev = w.device
+        B, S = input_ids.shape
+        M, H, nh, hd = B * S, a.hidden_size, a.num_heads, a.head_dim
+        with torch.no_grad():
+            image_states = e.encode_images(pixel_values)
+        Nk, E = image_states.shape[1], image_states.shape[2]
+        img_len = a.image_seq_len
+        img_mask = image_attention_mask.to(torch.int32).contiguous()
+        gate = (img_mask != 0).any(-1).to(torch.float32).reshape(-1).contiguous()
+        key_valid = attention_mask.to(torch.int32).contiguous()
+        pos = e._position_ids(attention_mask, S).reshape(-1)
+        idx_of = {int(l): i for i, l in enumerate(hook_layers)}
+        icv = icv.detach().to(device=dev, dtype=torch.float32).contiguous()
+        alpha = alpha.detach().to(device=dev, dtype=torch.float32).contiguous() if alpha is not None else None
+        img2d = image_states.reshape(B * Nk, E)
+
+        st = dict(B=B, S=S, Nk=Nk, img_len=img_len, img_mask=img_mask, gate=gate, key_valid=key_valid, pos=pos, icv=icv, alpha=alpha,
+                  idx_of=idx_of, layers=[], logits_rows=logits_rows)
+        h = ops.embed_gather(input_ids.contiguous(), w.embed, w.embed_extra, a.vocab_size).view(M, H)
+        for l in range(a.num_layers):
+            rec = {}
+            if l % a.cross_layer_interval == 0:
+                j = l // a.cross_layer_interval
+                X, T = w.xat[j], tw.xat[j]
+                x = {"h_in": h}
+                xn = ops.rmsnorm(h, X.in_ln, a.rms_eps)
+                q = ops.linear(xn, X.q_w)
+                kv = ops.linear(img2d, X.kv_w)
+                x["q_pre"] = q.clone() if X.qn_w is not None else None
+                if X.qn_w is not None:
+                    ops.rmsnorm(q, X.qn_w, a.rms_eps, out=q, inner=nh, ld_x=H, ld_out=H, rows=M * nh, dim=hd)
+                    ops.rmsnorm(kv, X.kn_w, a.rms_eps, out=kv, inner=nh, ld_x=2 * H, ld_out=2 * H, rows=B * Nk * nh, dim=hd)
+                x["q"], x["kv"] = q, kv
+                o = ops.attention(q, kv, kv.view(-1)[H:], B, S, Nk, nh, nh, hd, S * H, H, Nk * 2 * H, 2 * H, hd ** -0.5, 3,
+                                  img_mask=img_mask, img_len=img_len)
+                h = ops.linear(o.view(M, H), X.o_w, row_gate=gate, scale=X.gate_attn, residual=h)
+                x["h_mid"] = h
+                xn = ops.rmsnorm(h, X.post_ln, a.rms_eps)
+                gu = ops.linear(xn, T["gu"])
+                act = ops.swiglu(gu)
+                x["gu"] = gu
+                h = ops.linear(act, X.down_w, scale=X.gate_dense, residual=h)
+                rec["x"] = x
+            D, T = w.dec[l], tw.dec[l]
+            rec["h_in"] = h
+            xn = ops.rmsnorm(h, D.in_ln, a.rms_eps)
+            qkv = ops.linear(xn, D.qkv_w)
+            ops.rotary_(qkv, w.cos, w.sin, pos, M, nh, hd, 3 * H, H, 2)
+            rec["qkv"] = qkv
+            o = ops.attention(qkv, qkv.view(-1)[H:], qkv.view(-1)[2 * H:], B, S, S, nh, nh, hd, S * 3 * H, 3 * H, S * 3 * H, 3 * H,
+                              hd ** -0.5, 1, key_valid=key_valid)
+            h = ops.linear(o.view(M, H), D.o_w, residual=h)
+            rec["h_mid"] = h
+            xn = ops.rmsnorm(h, D.post_ln, a.rms_eps)
+            gu = ops.linear(xn, T["gu"])
+            rec["gu"] = gu
+            act = ops.swiglu(gu)
+            h = ops.linear(act, D.down_w, residual=h)
+            if l in idx_of:
+                i = idx_of[l]
+                rec["h_pre_hook"] = h
+                al = alpha[0, i:i + 1] if alpha is not None else None
+                h = ops.inject_renorm(h, icv[0, i], alpha=al)
+            st["layers"].append(rec)
+        st["h_final"] = h
+        xf = ops.rmsnorm(h, w.final_ln, a.rms_eps)
+        logits = ops.linear(xf.index_select(0, logits_rows), w.lm_head)
+        return logits, st
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, st: dict, dlogits_rows: torch.Tensor) -> torch.Tensor:
+        """dlogits_rows: (R, V) bf16 grad wrt the logits returned by forward.  Returns d loss / d v_l for every hooked
+        layer as (1, n_hooked, H) fp32, where v_l = alpha_l * icv_l is what the hook added."""
+        e, a, w, tw = self.e, self.e.arch, self.e.w, self.tw
+        B, S, Nk = st["B"], st["S"], st["Nk"]
+        M, H, nh, hd, I = B * S, a.hidden_size, a.num_heads, a.head_dim, a.intermediate_size
+        dev = w.device
+        V = w.lm_head.shape[0]
+        n_hooked = len(st["idx_of"])
+        grad_v = torch.zeros((1, n_hooked, H), dtype=torch.float32, device=dev)
+        # head + final norm
+        assert dlogits_rows.shape[1] == tw.head_T.shape[1] and dlogits_rows.is_contiguous(), "pass the padded grad from ops.kl_rows_bwd"
+        d_xf_rows = ops.linear(dlogits_rows, tw.head_T)                                              # (R, H) bf16
+        d_xf = torch.zeros((M, H), dtype=torch.bfloat16, device=dev)
+        d_xf.index_copy_(0, st["logits_rows"], d_xf_rows)
+        dh = torch.empty((M, H), dtype=torch.float32, device=dev)
+        ops.rmsnorm_bwd(st["h_final"], w.final_ln, d_xf, dh, a.rms_eps, accumulate=False)
+        for l in reversed(range(a.num_layers)):
+            rec = st["layers"][l]
+            D, T = w.dec[l], tw.dec[l]
+            if l in st["idx_of"]:
+                i = st["idx_of"][l]
+                al = st["alpha"][0, i:i + 1] if st["alpha"] is not None else None
+                dh, gv = ops.inject_renorm_bwd(rec["h_pre_hook"], st["icv"][0, i], al, dh)
+                grad_v[0, i] = gv
+            # MLP branch
+            d_out = ops.branch_grad(dh)
+            d_act = ops.linear(d_out, T["down_T"])
+            d_gu = ops.swiglu_bwd(rec["gu"], d_act)
+            d_x = ops.linear(d_gu, T["gu_T"])
+            ops.rmsnorm_bwd(rec["h_mid"], D.post_ln, d_x, dh, a.rms_eps, accumulate=True)
+            # attention branch
+            d_o = ops.branch_grad(dh)
+            d_attn = ops.linear(d_o, T["o_T"])
+            qkv = rec["qkv"]
+            dqkv = torch.empty_like(qkv)
+            ops.attention_bwd_small(qkv, qkv.view(-1)[H:], qkv.view(-1)[2 * H:], d_attn, B, S, S, nh, nh, hd, S * 3 * H, 3 * H,
+                                    S * 3 * H, 3 * H, hd ** -0.5, 1, dqkv, S * 3 * H, 3 * H, dk=dqkv.view(-1)[H:], dv=dqkv.view(-1)[2 * H:],
+                                    dkv_bs=S * 3 * H, dkv_rs=3 * H, key_valid=st["key_valid"])
+            ops.rotary_(dqkv, w.cos, tw.neg_sin, st["pos"], M, nh, hd, 3 * H, H, 2)                 # inverse rotation
+            d_x = ops.linear(dqkv, T["qkv_T"])
+            ops.rmsnorm_bwd(rec["h_in"], D.in_ln, d_x, dh, a.rms_eps, accumulate=True)
+            if "x" in rec:
+                x = rec["x"]
+                j = l // a.cross_layer_interval
+                X, TX = w.xat[j], tw.xat[j]
+                d_out = ops.branch_grad(dh, scale=X.gate_dense)
+                d_act = ops.linear(d_out, TX["down_T"])
+                d_gu = ops.swiglu_bwd(x["gu"], d_act)
+                d_x = ops.linear(d_gu, TX["gu_T"])
+                ops.rmsnorm_bwd(x["h_mid"], X.post_ln, d_x, dh, a.rms_eps, accumulate=True)
+                d_o = ops.branch_grad(dh, scale=X.gate_attn, row_gate=st["gate"])
+                d_attn = ops.linear(d_o, TX["o_T"])
+                dq = torch.empty((M, H), dtype=torch.bfloat16, device=dev)
+                kv = x["kv"]
+                ops.attention_bwd_small(x["q"], kv, kv.view(-1)[H:], d_attn, B, S, Nk, nh, nh, hd, S * H, H, Nk * 2 * H, 2 * H,
+                                        hd ** -0.5, 3, dq, S * H, H, img_mask=st["img_mask"], img_len=st["img_len"])
+                if X.qn_w is not None:
+                    dq_pre = torch.empty_like(dq)
+                    ops.rmsnorm_bwd(x["q_pre"], X.qn_w, dq, dq_pre, a.rms_eps, accumulate=False, inner=nh, ld_x=H, ld_dy=H, ld_dx=H,
+                                    rows=M * nh, dim=hd)
+                    dq = dq_pre
+                d_x = ops.linear(dq, TX["q_T"])
+                ops.rmsnorm_bwd(x["h_in"], X.in_ln, d_x, dh, a.rms_eps, accumulate=True)
+        return grad_v

@@ -1,0 +1,122 @@
+"""Data-parallel L-ICV trainer (replaces Lightning + DDP / DeepSpeed ZeRO-2 for the 131 104 trainable floats;
+ref:icv_src/icv_module.py:160-209, ref:config/trainer/*.yaml).
+
+One process per GPU, a full frozen replica each.  Per optimiser step the only exchange is ONE all-reduce (RCCL
+over xGMI, `torch.distributed` backend "nccl") of a single flat fp32 buffer
+``[alpha.grad | icv.grad | kl_loss]`` (524 KiB): latency-bound, issued after the last micro-batch of the
+accumulation window.  Then every rank applies the same global-norm clip and the same fused AdamW kernel.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+
+from . import ops
+from .train_engine import StudentPass, TrainWeights
+
+
+def shard_indices(n: int, rank: int, world: int, drop_last: bool = True):
+    """DistributedSampler-equivalent round-robin shard of range(n)."""
+    per = n // world if drop_last else math.ceil(n / world)
+    return [i for i in range(rank, per * world if drop_last else n, world)][:per]
+
+
+def allreduce_mean_(flat: torch.Tensor, group=None) -> torch.Tensor:
+    """In-place mean over ranks of one flat buffer (no-op without an initialised process group)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat.div_(dist.get_world_size(group))
+    return flat
+
+
+class ICVTrainer:
+    def __init__(self, module, state_dict: Dict[str, torch.Tensor], total_steps: int, accumulate_grad_batches: int = 1,
+                 grad_clip: float = 1.0, group=None):
+        """module: icv_src.icv_module.VQAICVModule on a native interface; state_dict: the HF-named LMM weights
+        (needed once for the transposed copies the backward GEMMs use)."""
+        self.m = module
+        if module.module_cfg.hard_loss_weight:
+            raise NotImplementedError("the native backward covers the KL objective (hard_loss_weight = 0, the reference default)")
+        eng = module.interface.engine
+        self.student = StudentPass(eng, TrainWeights(eng.w, state_dict))
+        self.accum, self.clip, self.group = accumulate_grad_batches, grad_clip, group
+        spec = module.optimizer_spec(total_steps)
+        self.spec = spec
+        enc = module.icv_encoder
+        dev = enc.icv.device
+        self.n_alpha = enc.alpha.numel()
+        self.flat_p = torch.cat([enc.alpha.detach().reshape(-1), enc.icv.detach().reshape(-1)]).to(torch.float32).contiguous()
+        self.flat_m = torch.zeros_like(self.flat_p)
+        self.flat_v = torch.zeros_like(self.flat_p)
+        self.opt_step = 0
+        self.micro = 0
+        self.layers = list(module.icv_model.intervention_layers)
+        self._kl_sum = torch.zeros((), device=dev)
+
+    def micro_batch(self, query_inputs, inputs, query_x_length, in_context_length):
+        """One micro-batch of the accumulation window; returns the step's log dict when it closes the window."""
+        kl = self.loss_and_backward(query_inputs, inputs, query_x_length, in_context_length, upstream=1.0 / self.accum)
+        self._kl_sum += kl.detach() / self.accum
+        self.micro += 1
+        if self.micro % self.accum == 0:
+            return self.optimizer_step()
+        return None
+
+    # ---- teacher rows, student rows, KL value, backward into the encoder's .grad (accumulating)
+    def loss_and_backward(self, query_inputs, inputs, query_x_length, in_context_length, upstream: float = 1.0):
+        m = self.m
+        iface, eng = m.interface, m.interface.engine
+        dev = eng.w.device
+        q = {k: v.to(dev) for k, v in query_inputs.items() if k != "labels"}
+        t = {k: v.to(dev) for k, v in inputs.items() if k != "labels"}
+        s_rows = m.get_mask(q, query_x_length.to(dev)).reshape(-1).nonzero().squeeze(1)
+        t_rows = m.get_mask(t, in_context_length.to(dev)).reshape(-1).nonzero().squeeze(1)
+        assert s_rows.numel() == t_rows.numel(), "student and teacher must mask the same number of answer tokens"
+        enc_out = m.icv_encoder()
+        with torch.no_grad():
+            tea = eng.forward(t["input_ids"], t["attention_mask"], t["pixel_values"], t["image_attention_mask"], logits_rows=t_rows)
+        stu, st = self.student.forward(q["input_ids"], q["attention_mask"], q["pixel_values"], q["image_attention_mask"],
+                                       icv=enc_out.in_context_vector, hook_layers=self.layers, alpha=enc_out.alpha,
+                                       logits_rows=s_rows)
+        V = eng.w.lm_head.shape[0]
+        idx = torch.arange(s_rows.numel(), device=dev)
+        T, eps = float(m.temperature), float(m.module_cfg.kl_eps)
+        stu2 = stu if stu.stride(1) == 1 else stu.contiguous()
+        tea2 = tea if tea.stride(1) == 1 else tea.contiguous()
+        kl = ops.kl_rows(stu2, tea2, idx, idx, V, T, eps).mean() * T * T
+        dlogits = ops.kl_rows_bwd(stu2, tea2, idx, idx, V, T, eps, upstream=upstream)
+        grad_v = self.student.backward(st, dlogits)                       # d loss / d (alpha*icv), (1, n, H)
+        icv_eff = enc_out.alpha.unsqueeze(dim=-1) * enc_out.in_context_vector
+        icv_eff.backward(grad_v)                                           # tiny torch graph: sigmoid, product (131 k floats)
+        return kl
+
+    def optimizer_step(self):
+        m = self.m
+        enc = m.icv_encoder
+        ga = enc.alpha.grad if enc.alpha.grad is not None else torch.zeros_like(enc.alpha)
+        flat_g = torch.cat([ga.reshape(-1), enc.icv.grad.reshape(-1), self._kl_sum.reshape(1)]).to(torch.float32).contiguous()
+        allreduce_mean_(flat_g, self.group)                                # the ONE collective of the step
+        kl = float(flat_g[-1])
+        g = flat_g[:-1].contiguous()
+        norm = float(g.norm())
+        scale = min(1.0, self.clip / (norm + 1e-6)) if self.clip else 1.0
+        lam = m.lr_lambda(self.opt_step, self.spec["warm_steps"], self.spec["total_steps"])
+        self.opt_step += 1
+        n0 = self.n_alpha if enc.alpha.requires_grad else 0
+        lr_alpha = self.spec["alpha_lr"] * lam if enc.alpha.requires_grad else 0.0
+        ops.adamw_step_(self.flat_p, g, self.flat_m, self.flat_v, self.n_alpha, lr_alpha, self.spec["icv_lr"] * lam, self.opt_step,
+                        weight_decay=self.spec["weight_decay"] , grad_scale=scale)
+        with torch.no_grad():
+            if enc.alpha.requires_grad:
+                enc.alpha.copy_(self.flat_p[: self.n_alpha].view_as(enc.alpha))
+            else:
+                self.flat_p[: self.n_alpha] = enc.alpha.reshape(-1)
+            enc.icv.copy_(self.flat_p[self.n_alpha:].view_as(enc.icv))
+        enc.alpha.grad = None
+        enc.icv.grad = None
+        self._kl_sum.zero_()
+        m.global_step = self.opt_step
+        return {"kl_loss": kl, "loss": kl, "grad_norm": norm, "lr_scale": lam}

@@ -1,0 +1,91 @@
+"""Training step on the GPU: gradients of the reference's objective w.r.t. icv / alpha through the native backward
+(HIP kernels) against the fixture produced by the reference's own VQAICVModule.forward + torch autograd (g6), then
+the optimiser step against the oracle's AdamW."""
+import numpy as np
+import pytest
+import torch
+
+from licv.config import IDEFICS_TINY
+from licv.synthetic import synth_idefics_weights
+from oracle import icv_ref as O
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+DEV = "cuda"
+FMT = "model.model.layers.<LAYER_NUM>"
+
+
+def _module(temp, sd):
+    from icv_src.icv_module import VQAICVModule
+    from lmm_icl_interface import IdeficsInterface
+    arch = IDEFICS_TINY
+    iface = IdeficsInterface(state_dict=sd, arch=arch, device=DEV)
+    mod_cfg = dict(hard_loss_weight=0.0, only_hard_loss=False, kl_eps=1e-6, init_temperature=temp, learnable_t=False,
+                   decay_ratio=-1, decay_per_step=-1, min_tmeprature=1.0, alpha_lr=1e-2, icv_lr=1e-4, weight_decay=1e-3,
+                   warm_steps=0.1, icv_encoder=dict(use_sigmoid=True, alpha_learnable=True, alpha_init_value=0.3))
+    lmm_cfg = dict(intervention_layer=-1, layer_format=FMT, total_layers=arch.num_layers, hidden_size=arch.hidden_size)
+    return VQAICVModule(iface, mod_cfg, lmm_cfg).to(DEV)
+
+
+def _batch(z, prefix):
+    return {k: T(z[f"{prefix}{k}"]) for k in ("input_ids", "attention_mask", "pixel_values", "image_attention_mask")}
+
+
+@pytest.mark.parametrize("temp", [1.0, 2.0])
+def test_native_backward_matches_reference_autograd(golden, temp):
+    from licv.trainer import ICVTrainer
+    z = golden("g6_loss")
+    sd = synth_idefics_weights(IDEFICS_TINY, seed=31, dtype=torch.float32)
+    mod = _module(temp, sd)
+    with torch.no_grad():
+        mod.icv_encoder.icv.copy_(T(z["enc_icv"]))
+        mod.icv_encoder.alpha.copy_(T(z["enc_alpha_param"]))
+    tr = ICVTrainer(mod, sd, total_steps=20, accumulate_grad_batches=1, grad_clip=1.0)
+    kl = tr.loss_and_backward(_batch(z, "stu_"), _batch(z, "tea_"), T(z["query_x_length"]), T(z["in_context_length"]))
+    key = f"T{int(temp)}"
+    kl16, kl32 = float(z[f"bf16_{key}_kl"]), float(z[f"f32_{key}_kl"])
+    assert abs(float(kl) - kl32) <= 1.5 * abs(kl16 - kl32) + 0.05 * kl32
+    for name, got in (("grad_icv", mod.icv_encoder.icv.grad), ("grad_alpha", mod.icv_encoder.alpha.grad)):
+        g32, g16 = T(z[f"f32_{key}_{name}"]), T(z[f"bf16_{key}_{name}"])
+        spread = (g16 - g32).abs().max()
+        err = (got.cpu() - g32).abs().max()
+        scale = g32.abs().max()
+        # held to the reference's own bf16-vs-fp32 gradient spread (plus 2 % of the gradient scale)
+        assert err <= 1.5 * spread + 0.02 * scale, f"{name}: err {err:.3e} spread {spread:.3e} scale {scale:.3e}"
+        cos = torch.nn.functional.cosine_similarity(got.cpu().reshape(1, -1), g32.reshape(1, -1)).item()
+        assert cos > 0.99, f"{name}: cosine {cos}"
+
+
+def test_trainer_step_applies_clipped_adamw_like_the_oracle(golden):
+    from licv.trainer import ICVTrainer
+    z = golden("g6_loss")
+    sd = synth_idefics_weights(IDEFICS_TINY, seed=31, dtype=torch.float32)
+    mod = _module(1.0, sd)
+    with torch.no_grad():
+        mod.icv_encoder.icv.copy_(T(z["enc_icv"]))
+        mod.icv_encoder.alpha.copy_(T(z["enc_alpha_param"]))
+    tr = ICVTrainer(mod, sd, total_steps=20, accumulate_grad_batches=2, grad_clip=1.0)
+    p0 = torch.cat([mod.icv_encoder.alpha.detach().reshape(-1), mod.icv_encoder.icv.detach().reshape(-1)]).cpu()
+    args = (_batch(z, "stu_"), _batch(z, "tea_"), T(z["query_x_length"]), T(z["in_context_length"]))
+    assert tr.micro_batch(*args) is None                      # first micro-batch of the window: no optimiser step
+    g_acc = torch.cat([mod.icv_encoder.alpha.grad.reshape(-1), mod.icv_encoder.icv.grad.reshape(-1)]).cpu().clone()
+    log = tr.micro_batch(*args)                               # closes the window
+    assert log is not None and set(log) >= {"kl_loss", "loss", "grad_norm"}
+    # same micro-batch twice with upstream 1/2 each -> accumulated grad == 2 * first half
+    g = 2 * g_acc
+    (gc,), norm = O.clip_grad_norm([g], 1.0)
+    assert abs(norm - log["grad_norm"]) <= 1e-3 * norm
+    # step 0 of the cosine warm-up has lr 0 (LambdaLR): parameters unchanged, like torch's scheduler
+    p1 = torch.cat([mod.icv_encoder.alpha.detach().reshape(-1), mod.icv_encoder.icv.detach().reshape(-1)]).cpu()
+    assert torch.equal(p0, p1) and log["lr_scale"] == 0.0
+    for _ in range(2):
+        log = tr.micro_batch(*args)
+    lam = O.cosine_warmup_lambda(1, 2.0, 20)
+    assert abs(log["lr_scale"] - lam) < 1e-12 and lam == 0.5
+    p2 = torch.cat([mod.icv_encoder.alpha.detach().reshape(-1), mod.icv_encoder.icv.detach().reshape(-1)]).cpu()
+    assert (p2 - p1).abs().max() > 0
+    # first real AdamW step: |delta| ~ lr * (1 / (1 + eps')) per coordinate with non-zero grad, sign opposite to the grad
+    n_a = mod.icv_encoder.alpha.numel()
+    moved = (p2 - p1)[n_a:]
+    nz = g[n_a:].abs() > 1e-9
+    assert (torch.sign(moved[nz]) == -torch.sign(g[n_a:][nz])).float().mean() > 0.99
