@@ -32,6 +32,10 @@ WORKLOADS = {
     "idefics9b_32shot_bs8": ("idefics-9b", 8, 800, 33, 720),
     "idefics9b_student_bs8": ("idefics-9b", 8, 32, 1, 24),
     "idefics_mid_debug": ("idefics-mid", 4, 96, 5, 80),
+    # BASELINE configs[2]: L-ICV training step = teacher (32-shot, no grad) + student (query only, with grad) + KL +
+    # backward + [every 2nd micro-batch] all-reduce + clipped AdamW.  (arch, B, S_teacher, n_img_teacher, min_len)
+    "idefics9b_train_bs8": ("idefics-9b", 8, 800, 33, 720),
+    "idefics_mid_train_debug": ("idefics-mid", 4, 96, 5, 80),
 }
 
 
@@ -90,6 +94,33 @@ def cpu_baseline(arch, S, n_img):
     }
 
 
+def build_trainer(arch, sd, dev, B, S, n_img, min_len, rank):
+    """VQAICVModule + ICVTrainer on synthetic teacher/student batches obeying the collator contract (same answer span
+    at the tail of both rows, ref:icv_src/icv_datamodule.py:73-130)."""
+    from icv_src.icv_module import VQAICVModule
+    from licv.synthetic import synth_vqa_batch
+    from licv.trainer import ICVTrainer
+    from lmm_icl_interface import IdeficsInterface
+    iface = IdeficsInterface(state_dict=sd, arch=arch, device=dev)
+    mod_cfg = dict(hard_loss_weight=0.0, only_hard_loss=False, kl_eps=1e-6, init_temperature=1.0, learnable_t=False, decay_ratio=-1,
+                   decay_per_step=-1, min_tmeprature=1.0, alpha_lr=1e-2, icv_lr=1e-4, weight_decay=1e-3, warm_steps=0.1,
+                   icv_encoder=dict(use_sigmoid=True, alpha_learnable=True, alpha_init_value=0.0))
+    lmm_cfg = dict(intervention_layer=-1, layer_format="model.model.layers.<LAYER_NUM>", total_layers=arch.num_layers,
+                   hidden_size=arch.hidden_size)
+    torch.manual_seed(426)
+    mod = VQAICVModule(iface, mod_cfg, lmm_cfg).to(dev)
+    ans = 4                                                           # answer span = last 4 real tokens (SURVEY §8d "TR")
+    Sq = 32 if S >= 256 else 16
+    tea = synth_vqa_batch(arch, B, S, n_img, seed=426 + rank, min_len=min_len, dtype=torch.bfloat16)
+    stu = synth_vqa_batch(arch, B, Sq, 1, seed=1426 + rank, min_len=Sq - 8, dtype=torch.bfloat16)
+    tl, sl = tea["attention_mask"].sum(1), stu["attention_mask"].sum(1)
+    for b in range(B):
+        stu["input_ids"][b, sl[b] - ans: sl[b]] = tea["input_ids"][b, tl[b] - ans: tl[b]]
+    trainer = ICVTrainer(mod, sd, total_steps=1000, accumulate_grad_batches=2, grad_clip=1.0)
+    to = lambda d: {k: v.to(dev) for k, v in d.items()}
+    return trainer, (to(stu), to(tea), (sl - ans).to(dev), (tl - ans).to(dev))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -121,7 +152,13 @@ def main():
     preset, B, S, n_img, min_len = WORKLOADS[args.workload]
     arch = idefics_arch(preset)
     sd = synth_idefics_weights(arch, seed=426, dtype=torch.bfloat16, device=dev)       # full replica per GPU
-    eng = IdeficsEngine(IdeficsWeights(sd, arch, dev))
+    training = "train" in args.workload
+    trainer = None
+    if training:
+        trainer, train_args = build_trainer(arch, sd, dev, B, S, n_img, min_len, rank)
+        eng = trainer.m.interface.engine
+    else:
+        eng = IdeficsEngine(IdeficsWeights(sd, arch, dev))
     del sd
     torch.cuda.empty_cache()
     batch = synth_vqa_batch(arch, B, S, n_img, seed=426 + rank, min_len=min_len, dtype=torch.bfloat16, device=dev)
@@ -130,6 +167,8 @@ def main():
     hooks = {} if args.no_hooks else dict(icv=icv, alpha=alpha, hook_layers=layers)
 
     def step():
+        if training:
+            return trainer.micro_batch(*train_args)
         return eng.forward(**batch, **hooks)
 
     def fence():
@@ -170,7 +209,8 @@ def main():
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic (random-init Idefics-9B weights, seeded image+text batches)",
         "config": {"workload": args.workload, "arch": preset, "questions_per_gpu": B, "seq_len": S, "images_per_question": n_img,
-                   "hooked_layers": 0 if args.no_hooks else arch.num_layers, "parallelism": f"dp{world}"},
+                   "hooked_layers": 0 if args.no_hooks else arch.num_layers, "parallelism": f"dp{world}",
+                   **({"train": "teacher fwd + student fwd/bwd + KL; accumulate 2; 1 all-reduce of 131 105 fp32 + AdamW per optimiser step"} if training else {})},
         "roofline": {"bound": "mfma", "kernel": "gemm_bf16_pingpong_k (256x256 LDS-DMA ring; small shapes: gemm_bf16_tile128_k)", "achieved": fl / tg / 1e12 if tg else None,
                      "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": (fl / tg / 1e12) / PEAK_BF16_TFLOPS if tg else None,
                      "traffic": None, "launches_per_step": ng // max(args.steps, 1),

@@ -38,6 +38,13 @@ int licv_inject_renorm_fwd(const void* h, int h_dtype, const float* icv_row, con
                            float* out, int64_t rows, int64_t hidden,
                            const void* norm_w, void* xn_out, float norm_eps, void* stream);
 
+/* Idefics2 hook site = a residual BRANCH (`layers.N.mlp`, ref:config/lmm/idefics2-8B-base.yaml:8): the edit is applied to the
+ * branch output and the stream becomes  out = residual + edit(branch)  (fp32).  norm_flavour selects the RMSNorm fused
+ * on `out` (0 Idefics, 1 Mistral: single rounding on an fp32 stream). */
+int licv_inject_renorm_add_fwd(const void* branch, int branch_dtype, const float* icv_row, const float* alpha,
+                               const void* residual, int residual_dtype, float* out, int64_t rows, int64_t hidden,
+                               const void* norm_w, void* xn_out, float norm_eps, int norm_flavour, void* stream);
+
 /* backward of the hook for training (gradients reach icv and alpha only through here;
  * ref:icv_src/icv_module.py:97-98 runs the student pass with grad).  grad_h may be NULL.
  * grad_v_partial: (n_partials, hidden) fp32 workspace, fully overwritten; the caller sums over
@@ -145,6 +152,8 @@ int licv_vit_embed_ln(const void* patches_bf16, const void* cls_bf16, const void
                       int64_t n_img, int64_t n_patch, int64_t dim, float eps, void* stream);
 /* out[r, :] = src[r % period, :]  (latents.repeat, hf:idefics/perceiver.py:96) */
 int licv_tile_rows(const void* src_bf16, void* out_bf16, int64_t rows, int64_t dim, int64_t period, void* stream);
+/* out[idx[i], :] = src[i, :] (hf:idefics2/modeling_idefics2.py:789-815 inputs_merger) */
+int licv_scatter_rows(const void* src_bf16, const int64_t* idx, void* out_bf16, int64_t n, int64_t dim, void* stream);
 /* silu(g)*u for an un-fused (M, 2I) [gate | up] buffer (kept for tests / odd shapes). */
 int licv_swiglu(const void* gu_bf16, void* out_bf16, int64_t rows, int64_t inter, void* stream);
 

@@ -37,7 +37,8 @@ template <int DT, int NCH, bool FUSE_NORM>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK)
 void inject_renorm_fwd_k(const void* __restrict__ h, const float* __restrict__ icv, const float* __restrict__ alpha,
                          float* __restrict__ out, int64_t rows, int hidden,
-                         const bf16_t* __restrict__ norm_w, bf16_t* __restrict__ xn, float eps) {
+                         const bf16_t* __restrict__ norm_w, bf16_t* __restrict__ xn, float eps,
+                         const void* __restrict__ res, int res_dt, int norm_flavour) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -72,10 +73,14 @@ void inject_renorm_fwd_k(const void* __restrict__ h, const float* __restrict__ i
         const int i = (c * 64 + lane) * 4;
         if (i < hidden) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                x[c][j] = x[c][j] / ns * nh;
-                q2 += x[c][j] * x[c][j];
+            for (int j = 0; j < 4; ++j) x[c][j] = x[c][j] / ns * nh;
+            if (res) {                                   // hooked BRANCH output (Idefics2 `.mlp`): stream = residual + edited branch
+                const floatx4 rv = res_dt == LICV_F32 ? RowIO<LICV_F32>::load4(res, base + i) : RowIO<LICV_BF16>::load4(res, base + i);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x[c][j] = rv[j] + x[c][j];
             }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) q2 += x[c][j] * x[c][j];
             *reinterpret_cast<floatx4*>(out + base + i) = x[c];
         }
     }
@@ -89,7 +94,7 @@ void inject_renorm_fwd_k(const void* __restrict__ h, const float* __restrict__ i
                 const floatx4 w = RowIO<LICV_BF16>::load4(norm_w, i);
                 floatx4 y;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) y[j] = w[j] * rbf(x[c][j] * rs);
+                for (int j = 0; j < 4; ++j) y[j] = w[j] * (norm_flavour == 1 ? x[c][j] * rs : rbf(x[c][j] * rs));
                 store4_bf16(xn, base + i, y);
             }
         }
@@ -446,6 +451,18 @@ void tile_rows_k(const bf16_t* __restrict__ src, bf16_t* __restrict__ out, int64
     }
 }
 
+// out[idx[i], :] = src[i, :]   (hf:idefics2/modeling_idefics2.py:789-815 inputs_merger: image states into <image> slots)
+__global__ __launch_bounds__(256)
+void scatter_rows_k(const bf16_t* __restrict__ src, const int64_t* __restrict__ idx, bf16_t* __restrict__ out, int64_t n, int dim) {
+    const int vec = dim >> 3;
+    const int64_t total = n * vec;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / vec;
+        const int c = (int)(i % vec);
+        reinterpret_cast<uint4*>(out + idx[r] * dim)[c] = reinterpret_cast<const uint4*>(src + r * dim)[c];
+    }
+}
+
 __global__ __launch_bounds__(256)
 void swiglu_k(const bf16_t* __restrict__ gu, bf16_t* __restrict__ out, int64_t rows, int64_t inter) {
     const int64_t total = rows * inter;
@@ -477,9 +494,27 @@ static inline int flat_blocks(int64_t total) {
     case 16: { constexpr int N = 16; CALL; } break; case 32: { constexpr int N = 32; CALL; } break; \
     default: return licv_set_error(LICV_E_UNSUPPORTED, "row length %lld too large", (long long)dim_); }
 
+static int inject_fwd_impl(const void* h, int h_dtype, const float* icv_row, const float* alpha, float* out, int64_t rows, int64_t hidden,
+                           const void* norm_w, void* xn_out, float norm_eps, const void* res, int res_dt, int norm_flavour, void* stream);
+
 extern "C" int licv_inject_renorm_fwd(const void* h, int h_dtype, const float* icv_row, const float* alpha,
                                       float* out, int64_t rows, int64_t hidden,
                                       const void* norm_w, void* xn_out, float norm_eps, void* stream) {
+    return inject_fwd_impl(h, h_dtype, icv_row, alpha, out, rows, hidden, norm_w, xn_out, norm_eps, nullptr, 0, 0, stream);
+}
+
+extern "C" int licv_inject_renorm_add_fwd(const void* branch, int branch_dtype, const float* icv_row, const float* alpha,
+                                          const void* residual, int residual_dtype, float* out, int64_t rows, int64_t hidden,
+                                          const void* norm_w, void* xn_out, float norm_eps, int norm_flavour, void* stream) {
+    LICV_CHECK_ARG(residual, "inject_renorm_add_fwd: null residual");
+    LICV_CHECK_ARG(residual_dtype == LICV_BF16 || residual_dtype == LICV_F32, "inject_renorm_add_fwd: bad residual dtype");
+    LICV_CHECK_ARG(norm_flavour == 0 || norm_flavour == 1, "inject_renorm_add_fwd: bad norm flavour");
+    return inject_fwd_impl(branch, branch_dtype, icv_row, alpha, out, rows, hidden, norm_w, xn_out, norm_eps, residual, residual_dtype,
+                           norm_flavour, stream);
+}
+
+static int inject_fwd_impl(const void* h, int h_dtype, const float* icv_row, const float* alpha, float* out, int64_t rows, int64_t hidden,
+                           const void* norm_w, void* xn_out, float norm_eps, const void* res, int res_dt, int norm_flavour, void* stream) {
     LICV_CHECK_ARG(h && icv_row && out, "inject_renorm_fwd: null pointer");
     LICV_CHECK_ARG(hidden > 0 && hidden % 4 == 0, "inject_renorm_fwd: hidden (%lld) must be a positive multiple of 4", (long long)hidden);
     LICV_CHECK_ARG(h_dtype == LICV_BF16 || h_dtype == LICV_F32, "inject_renorm_fwd: bad dtype %d", h_dtype);
@@ -491,7 +526,7 @@ extern "C" int licv_inject_renorm_fwd(const void* h, int h_dtype, const float* i
     const dim3 grid(row_blocks(rows)), block(64 * WAVES_PER_BLOCK);
     const bool fuse = norm_w != nullptr;
 #define LAUNCH_INJ(DTV, FUSE) inject_renorm_fwd_k<DTV, N, FUSE><<<grid, block, 0, st>>>( \
-        h, icv_row, alpha, out, rows, (int)hidden, (const bf16_t*)norm_w, (bf16_t*)xn_out, norm_eps)
+        h, icv_row, alpha, out, rows, (int)hidden, (const bf16_t*)norm_w, (bf16_t*)xn_out, norm_eps, res, res_dt, norm_flavour)
     if (h_dtype == LICV_F32) { if (fuse) { DISPATCH_NCH(nch, LAUNCH_INJ(LICV_F32, true)); } else { DISPATCH_NCH(nch, LAUNCH_INJ(LICV_F32, false)); } }
     else                     { if (fuse) { DISPATCH_NCH(nch, LAUNCH_INJ(LICV_BF16, true)); } else { DISPATCH_NCH(nch, LAUNCH_INJ(LICV_BF16, false)); } }
 #undef LAUNCH_INJ
@@ -612,7 +647,7 @@ extern "C" int licv_embed_gather(const int64_t* ids, const void* table, const vo
 extern "C" int licv_im2col_patches(const void* pix, void* out, int64_t n_img, int64_t height, int64_t width, int64_t patch,
                                    int64_t ld_out, void* stream) {
     LICV_CHECK_ARG(pix && out, "im2col_patches: null pointer");
-    LICV_CHECK_ARG(patch > 0 && height % patch == 0 && width % patch == 0, "im2col_patches: image not a multiple of the patch");
+    LICV_CHECK_ARG(patch > 0 && height >= patch && width >= patch, "im2col_patches: image smaller than one patch");   // a ragged edge is dropped like a stride-P conv does
     LICV_CHECK_ARG(ld_out >= 3 * patch * patch, "im2col_patches: ld_out too small");
     const int64_t total = n_img * (height / patch) * (width / patch) * ld_out;
     if (total <= 0) return LICV_OK;
@@ -627,6 +662,15 @@ extern "C" int licv_tile_rows(const void* src, void* out, int64_t rows, int64_t 
     LICV_CHECK_ARG(dim > 0 && dim % 8 == 0, "tile_rows: dim must be a multiple of 8");
     if (rows <= 0) return LICV_OK;
     tile_rows_k<<<flat_blocks(rows * (dim / 8)), 256, 0, (hipStream_t)stream>>>((const bf16_t*)src, (bf16_t*)out, rows, (int)dim, period);
+    LICV_LAUNCH_CHECK();
+    return LICV_OK;
+}
+
+extern "C" int licv_scatter_rows(const void* src, const int64_t* idx, void* out, int64_t n, int64_t dim, void* stream) {
+    LICV_CHECK_ARG(src && idx && out, "scatter_rows: null pointer");
+    LICV_CHECK_ARG(dim > 0 && dim % 8 == 0, "scatter_rows: dim must be a multiple of 8");
+    if (n <= 0) return LICV_OK;
+    scatter_rows_k<<<flat_blocks(n * (dim / 8)), 256, 0, (hipStream_t)stream>>>((const bf16_t*)src, idx, (bf16_t*)out, n, (int)dim);
     LICV_LAUNCH_CHECK();
     return LICV_OK;
 }

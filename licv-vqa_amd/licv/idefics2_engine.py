@@ -1,0 +1,268 @@
+"""Native Idefics2 forward for MI355X with the ICV hook on every text layer's MLP branch.
+
+Replaces, for the hot path, ``Idefics2ForConditionalGeneration.forward`` (hf:idefics2/modeling_idefics2.py:817-1010;
+text model hf:mistral/modeling_mistral.py) run under ``torch.autocast(bf16)`` as the reference does for this model
+(ref:icv_src/icv_module.py:36-56), plus the baukit hook on ``model.model.text_model.layers.N.mlp``
+(ref:config/lmm/idefics2-8B-base.yaml:8).  Arithmetic = HIP kernels behind the C-ABI; torch supplies memory, the stream
+and the integer plumbing of the NaViT tower (which images are padding, patch validity, bucketised position ids).
+
+Layout in HBM: tokens flattened to rows.  Vision tokens (n_real_images * T, 1152) with T = (H/14)*(W/14) of the padded
+batch resolution and a per-image key-valid mask; connector context (n*T, 4096); latents (n*64, 4096); the K/V input of a
+perceiver layer is ONE (n, T+64, 4096) buffer the two RMSNorms write into directly.  Text side: fused QKV projection
+((32+8+8)*128 x 4096, GQA heads read through strides), gate|up interleaved for the SwiGLU epilogue; the residual stream
+is bf16 until the first hooked layer and fp32 after it (the hook's fp32 output promotes it, exactly as under autocast).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import ops
+from .config import Idefics2Arch
+from .idefics_engine import _bf, _pad_cols
+
+
+@dataclass
+class _SigLayer:
+    ln1_w: torch.Tensor; ln1_b: torch.Tensor; qkv_w: torch.Tensor; qkv_b: torch.Tensor
+    out_w: torch.Tensor; out_b: torch.Tensor; ln2_w: torch.Tensor; ln2_b: torch.Tensor
+    fc1_w: torch.Tensor; fc1_b: torch.Tensor; fc2_w: torch.Tensor; fc2_b: torch.Tensor
+
+
+@dataclass
+class _PercLayer:
+    lat_ln: torch.Tensor; ctx_ln: torch.Tensor; q_w: torch.Tensor; kv_w: torch.Tensor; o_w: torch.Tensor
+    post_ln: torch.Tensor; gu_w: torch.Tensor; down_w: torch.Tensor
+
+
+@dataclass
+class _TextLayer:
+    in_ln: torch.Tensor; qkv_w: torch.Tensor; o_w: torch.Tensor; post_ln: torch.Tensor
+    gu_w: torch.Tensor; down_w: torch.Tensor
+
+
+class Idefics2Weights:
+    """Engine-layout weights from an HF-named ``Idefics2ForConditionalGeneration`` state dict (bf16)."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], arch: Idefics2Arch, device="cuda", max_positions: int = 4096):
+        a, dev = arch, torch.device(device)
+        self.arch, self.device = arch, dev
+        g = lambda k: _bf(sd[k], dev)
+        cat = lambda p, names, suf: torch.cat([g(p + f"{n}.{suf}") for n in names]).contiguous()
+        vp = "model.vision_model."
+        self.patch_ld = (3 * a.v_patch * a.v_patch + 63) // 64 * 64
+        self.patch_w = _pad_cols(g(vp + "embeddings.patch_embedding.weight").flatten(1), self.patch_ld)
+        self.patch_b = g(vp + "embeddings.patch_embedding.bias")
+        self.pos = g(vp + "embeddings.position_embedding.weight")
+        self.vit: List[_SigLayer] = []
+        for i in range(a.v_layers):
+            p = f"{vp}encoder.layers.{i}."
+            qkv = ("q_proj", "k_proj", "v_proj")
+            self.vit.append(_SigLayer(g(p + "layer_norm1.weight"), g(p + "layer_norm1.bias"),
+                                      cat(p + "self_attn.", qkv, "weight"), cat(p + "self_attn.", qkv, "bias"),
+                                      g(p + "self_attn.out_proj.weight"), g(p + "self_attn.out_proj.bias"),
+                                      g(p + "layer_norm2.weight"), g(p + "layer_norm2.bias"),
+                                      g(p + "mlp.fc1.weight"), g(p + "mlp.fc1.bias"), g(p + "mlp.fc2.weight"), g(p + "mlp.fc2.bias")))
+        self.post_ln_w, self.post_ln_b = g(vp + "post_layernorm.weight"), g(vp + "post_layernorm.bias")
+        cp = "model.connector."
+        mp = cp + "modality_projection."
+        self.mp_gu = ops.pack_gate_up(g(mp + "gate_proj.weight"), g(mp + "up_proj.weight"))
+        self.mp_down = g(mp + "down_proj.weight")
+        rp = cp + "perceiver_resampler."
+        self.latents = g(rp + "latents")
+        self.perc: List[_PercLayer] = []
+        for i in range(a.r_depth):
+            p = f"{rp}layers.{i}."
+            self.perc.append(_PercLayer(g(p + "input_latents_norm.weight"), g(p + "input_context_norm.weight"),
+                                        g(p + "self_attn.q_proj.weight"), cat(p + "self_attn.", ("k_proj", "v_proj"), "weight"),
+                                        g(p + "self_attn.o_proj.weight"), g(p + "post_attention_layernorm.weight"),
+                                        ops.pack_gate_up(g(p + "mlp.gate_proj.weight"), g(p + "mlp.up_proj.weight")),
+                                        g(p + "mlp.down_proj.weight")))
+        self.perc_ln = g(rp + "norm.weight")
+        tp = "model.text_model."
+        self.embed = g(tp + "embed_tokens.weight")
+        self.text: List[_TextLayer] = []
+        for i in range(a.num_layers):
+            p = f"{tp}layers.{i}."
+            self.text.append(_TextLayer(g(p + "input_layernorm.weight"), cat(p + "self_attn.", ("q_proj", "k_proj", "v_proj"), "weight"),
+                                        g(p + "self_attn.o_proj.weight"), g(p + "post_attention_layernorm.weight"),
+                                        ops.pack_gate_up(g(p + "mlp.gate_proj.weight"), g(p + "mlp.up_proj.weight")),
+                                        g(p + "mlp.down_proj.weight")))
+        self.final_ln = g(tp + "norm.weight")
+        self.lm_head = g("lm_head.weight")
+        # rotary tables: fp32 inv_freq and angles, cast to the model dtype (hf:mistral/modeling_mistral.py MistralRotaryEmbedding)
+        hd = a.head_dim
+        inv = 1.0 / (a.rope_base ** (torch.arange(0, hd, 2, dtype=torch.float) / hd))
+        emb = torch.cat((torch.outer(torch.arange(max_positions, dtype=torch.float), inv),) * 2, dim=-1)
+        self.cos, self.sin = _bf(emb.cos(), dev), _bf(emb.sin(), dev)
+        self.max_positions = max_positions
+
+
+def navit_position_ids(patch_mask: torch.Tensor, n_side: int) -> torch.Tensor:
+    """hf:idefics2/modeling_idefics2.py:136-170 — fractional patch coordinates bucketised into the n_side x n_side
+    position table.  Tiny integer/host arithmetic on the (n, gh, gw) bool patch mask; runs on the CPU so that the
+    bucket boundaries are the same fp32 values the HF module builds."""
+    pm = patch_mask.cpu()
+    n, gh, gw = pm.shape
+    boundaries = torch.arange(1 / n_side, 1.0, 1 / n_side)
+    nb_h = pm[:, :, 0].sum(dim=1)
+    nb_w = pm[:, 0, :].sum(dim=1)
+    fh = torch.clamp(torch.arange(gh, dtype=torch.float32)[None, :] * (1.0 / nb_h)[:, None], max=1.0 - 1e-6)
+    fw = torch.clamp(torch.arange(gw, dtype=torch.float32)[None, :] * (1.0 / nb_w)[:, None], max=1.0 - 1e-6)
+    bh = torch.bucketize(fh.to(torch.bfloat16), boundaries, right=True)     # HF evaluates them in the pixel dtype (bf16)
+    bw = torch.bucketize(fw.to(torch.bfloat16), boundaries, right=True)
+    pos = (bh[:, :, None] * n_side + bw[:, None, :]).reshape(n, -1)
+    return torch.where(pm.view(n, -1), pos, torch.zeros_like(pos)).to(torch.int64)
+
+
+class Idefics2Engine:
+    def __init__(self, weights: Idefics2Weights, fuse_hook_norm: bool = True):
+        self.w, self.arch = weights, weights.arch
+        self.fuse_hook_norm = fuse_hook_norm
+
+    # ----------------------------------------------------------------------------------- vision + connector
+    def encode_images(self, pixel_values: torch.Tensor, pixel_attention_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """(B, N, 3, H, W) [+ (B, N, H, W) bool] -> (n_real_images * r_latents, hidden) bf16
+        (hf:idefics2/modeling_idefics2.py:817-862: all-zero padding images are dropped)."""
+        a, w = self.arch, self.w
+        dev = w.device
+        B, N = pixel_values.shape[:2]
+        pv = pixel_values.to(device=dev, dtype=torch.bfloat16).reshape(B * N, *pixel_values.shape[2:])
+        real = (pv == 0.0).sum(dim=(-1, -2, -3)) != pv.shape[1:].numel()
+        pv = pv[real].contiguous()
+        n = pv.shape[0]
+        Hh, Ww = pv.shape[-2:]
+        P = a.v_patch
+        gh, gw = Hh // P, Ww // P
+        T = gh * gw
+        if pixel_attention_mask is None:
+            pmask = torch.ones((n, gh, gw), dtype=torch.bool, device=dev)
+        else:
+            pam = pixel_attention_mask.to(dev).reshape(B * N, Hh, Ww)[real]
+            sub = pam[:, :gh * P, :gw * P].reshape(n, gh, P, gw, P)
+            pmask = sub.sum(dim=(2, 4)) == P * P
+        valid = pmask.view(n, T).to(torch.int32).contiguous()
+        all_valid = bool(pmask.all())
+        pos_ids = navit_position_ids(pmask, a.v_image // P).to(dev).reshape(-1).contiguous()
+
+        E, nh, hd = a.v_hidden, a.v_heads, a.v_head_dim
+        cols = ops.im2col_patches(pv, P, w.patch_ld)
+        pos_rows = ops.embed_gather(pos_ids, w.pos, None, w.pos.shape[0])
+        x = ops.linear(cols, w.patch_w, bias=w.patch_b, residual=pos_rows)
+        del cols, pos_rows
+        act = "gelu_tanh" if a.v_act == "gelu_pytorch_tanh" else "gelu"
+        mode, kvld = (0, None) if all_valid else (2, valid)
+        for L in w.vit:
+            y = ops.layernorm(x, L.ln1_w, L.ln1_b, a.v_ln_eps)
+            qkv = ops.linear(y, L.qkv_w, bias=L.qkv_b)
+            o = ops.attention(qkv, qkv.view(-1)[E:], qkv.view(-1)[2 * E:], n, T, T, nh, nh, hd, T * 3 * E, 3 * E, T * 3 * E, 3 * E,
+                              hd ** -0.5, mode, key_valid=kvld)
+            del qkv
+            ops.linear(o.view(n * T, E), L.out_w, bias=L.out_b, residual=x, out=x)
+            y = ops.layernorm(x, L.ln2_w, L.ln2_b, a.v_ln_eps)
+            y = ops.linear(y, L.fc1_w, bias=L.fc1_b, act=act)
+            ops.linear(y, L.fc2_w, bias=L.fc2_b, residual=x, out=x)
+            del y, o
+        x = ops.layernorm(x, w.post_ln_w, w.post_ln_b, a.v_ln_eps)
+        return self._connector(x, valid, n, T)
+
+    def _connector(self, x: torch.Tensor, valid: torch.Tensor, n: int, T: int) -> torch.Tensor:
+        """hf:idefics2/modeling_idefics2.py:757-760 (modality projection) + :708-743 (perceiver resampler, GQA)."""
+        a, w = self.arch, self.w
+        H, Lq, nh, nkv, hd = a.hidden_size, a.r_latents, a.r_heads, a.r_kv_heads, a.r_head_dim
+        ctx = ops.linear(ops.linear(x, w.mp_gu, swiglu=True), w.mp_down)            # (n*T, H)
+        lat = ops.tile_rows(w.latents, n * Lq)
+        kvalid = torch.cat([valid, torch.ones((n, Lq), dtype=torch.int32, device=valid.device)], dim=1).contiguous()
+        Sk = T + Lq
+        kvin = torch.empty((n, Sk, H), dtype=torch.bfloat16, device=x.device)
+        kdim = nkv * hd
+        for P in w.perc:
+            # both norms write straight into the concatenated [context ; latents] K/V input
+            ops.rmsnorm(ctx, P.ctx_ln, a.rms_eps, 1, out=kvin, inner=T, ld_x=T * H, ld_out=Sk * H, rows=n * T, dim=H)
+            ops.rmsnorm(lat, P.lat_ln, a.rms_eps, 1, out=kvin.view(-1)[T * H:], inner=Lq, ld_x=Lq * H, ld_out=Sk * H, rows=n * Lq, dim=H)
+            latn = ops.rmsnorm(lat, P.lat_ln, a.rms_eps, 1)
+            q = ops.linear(latn, P.q_w)
+            kv = ops.linear(kvin.view(n * Sk, H), P.kv_w)
+            o = ops.attention(q, kv, kv.view(-1)[kdim:], n, Lq, Sk, nh, nkv, hd, Lq * nh * hd, nh * hd, Sk * 2 * kdim, 2 * kdim,
+                              hd ** -0.5, 2, key_valid=kvalid)
+            ops.linear(o.view(n * Lq, nh * hd), P.o_w, residual=lat, out=lat)
+            y = ops.rmsnorm(lat, P.post_ln, a.rms_eps, 1)
+            ops.linear(ops.linear(y, P.gu_w, swiglu=True), P.down_w, residual=lat, out=lat)
+        return ops.rmsnorm(lat, w.perc_ln, a.rms_eps, 1)
+
+    # ----------------------------------------------------------------------------------- text side
+    def forward(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
+                pixel_values: Optional[torch.Tensor] = None, pixel_attention_mask: Optional[torch.Tensor] = None,
+                image_hidden_states: Optional[torch.Tensor] = None, icv: Optional[torch.Tensor] = None,
+                hook_layers: Optional[Sequence[int]] = None, alpha: Optional[torch.Tensor] = None,
+                capture: Optional[dict] = None, logits_rows: Optional[torch.Tensor] = None):
+        """Returns logits (B, S, V) bf16.  icv (1, n_hooked, H) fp32 — already alpha-scaled when ``alpha`` is None;
+        hook_layers: text-layer ids whose MLP OUTPUT (before the residual add) is edited."""
+        a, w = self.arch, self.w
+        dev = w.device
+        B, S = input_ids.shape
+        assert S <= w.max_positions, "sequence longer than the rotary table"
+        M, H, nh, nkv, hd = B * S, a.hidden_size, a.num_heads, a.num_kv_heads, a.head_dim
+        if attention_mask is None:
+            attention_mask = torch.ones((B, S), dtype=torch.long, device=dev)
+        ids = input_ids.to(dev).contiguous()
+        if image_hidden_states is None and pixel_values is not None:
+            image_hidden_states = self.encode_images(pixel_values, pixel_attention_mask)
+        h = ops.embed_gather(ids, w.embed, None, w.embed.shape[0]).view(M, H)
+        if image_hidden_states is not None:
+            slots = (ids.view(-1) == a.image_token_id).nonzero().view(-1).contiguous()
+            img = image_hidden_states.reshape(-1, H)
+            if slots.numel() != img.shape[0]:
+                raise ValueError(f"{slots.numel()} <image> tokens in input_ids but {img.shape[0]} image hidden states")
+            ops.scatter_rows_(h, slots, img.contiguous())
+        key_valid = attention_mask.to(device=dev, dtype=torch.int32).contiguous()
+        pos = torch.arange(S, device=dev, dtype=torch.int64).repeat(B).contiguous()       # position_ids = arange (MistralModel.forward)
+        idx_of = {int(l): i for i, l in enumerate(hook_layers)} if (icv is not None and hook_layers is not None) else {}
+        if icv is not None:
+            icv = icv.to(device=dev, dtype=torch.float32).contiguous()
+            if alpha is not None:
+                alpha = alpha.to(device=dev, dtype=torch.float32).contiguous()
+        qd, kd = nh * hd, nkv * hd
+        ldq = qd + 2 * kd
+        xn = None
+        for l, L in enumerate(w.text):
+            x = xn if xn is not None else ops.rmsnorm(h, L.in_ln, a.rms_eps, 1)
+            xn = None
+            qkv = ops.linear(x, L.qkv_w)
+            ops.rotary_(qkv, w.cos, w.sin, pos, M, nh, hd, ldq, qd, 1)
+            ops.rotary_(qkv.view(-1)[qd:], w.cos, w.sin, pos, M, nkv, hd, ldq, kd, 1)
+            o = ops.attention(qkv, qkv.view(-1)[qd:], qkv.view(-1)[qd + kd:], B, S, S, nh, nkv, hd, S * ldq, ldq, S * ldq, ldq,
+                              hd ** -0.5, 1, key_valid=key_valid)
+            ops.linear(o.view(M, qd), L.o_w, residual=h, out=h)
+            x = ops.rmsnorm(h, L.post_ln, a.rms_eps, 1)
+            act = ops.linear(x, L.gu_w, swiglu=True)
+            del qkv, o, x
+            if l in idx_of:
+                i = idx_of[l]
+                m = ops.linear(act, L.down_w)                                              # raw MLP branch (bf16)
+                if capture is not None:
+                    capture.setdefault("mlp_raw", []).append(m.view(B, S, H).clone())
+                al = alpha[0, i:i + 1] if alpha is not None else None
+                nw = w.text[l + 1].in_ln if l + 1 < a.num_layers else w.final_ln
+                if self.fuse_hook_norm:
+                    h, xn = ops.inject_renorm_add(m, icv[0, i], h, alpha=al, norm_weight=nw, norm_eps=a.rms_eps, norm_flavour=1)
+                else:
+                    h = ops.inject_renorm_add(m, icv[0, i], h, alpha=al)
+                del m
+            else:
+                if capture is not None:
+                    capture.setdefault("mlp_raw", []).append(ops.linear(act, L.down_w).view(B, S, H).clone())
+                ops.linear(act, L.down_w, residual=h, out=h)
+            del act
+            if capture is not None:
+                capture.setdefault("layer_out", []).append(h.view(B, S, H).clone())
+        x = xn if xn is not None else ops.rmsnorm(h, w.final_ln, a.rms_eps, 1)
+        if capture is not None:
+            capture["image_hidden_states"] = image_hidden_states
+        if logits_rows is not None:
+            return ops.linear(x.index_select(0, logits_rows), w.lm_head)
+        logits = ops.linear(x, w.lm_head)
+        V = logits.shape[-1]
+        return logits.view(B, S, V) if logits.is_contiguous() else logits.as_strided((B, S, V), (S * logits.stride(0), logits.stride(0), 1))

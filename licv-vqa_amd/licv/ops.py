@@ -78,6 +78,27 @@ def inject_renorm(h: torch.Tensor, icv_row: torch.Tensor, alpha: Optional[torch.
     return (out, xn) if norm_weight is not None else out
 
 
+def inject_renorm_add(branch: torch.Tensor, icv_row: torch.Tensor, residual: torch.Tensor, alpha: Optional[torch.Tensor] = None,
+                      norm_weight: Optional[torch.Tensor] = None, norm_eps: float = 1e-6, norm_flavour: int = 1):
+    """Hook on a residual branch: out = residual + (b+v)/||b+v||*||b|| (fp32); optional fused RMSNorm of `out`."""
+    H = branch.shape[-1]
+    assert branch.is_contiguous() and residual.is_contiguous() and residual.shape == branch.shape
+    rows = branch.numel() // H
+    out = torch.empty(branch.shape, dtype=torch.float32, device=branch.device)
+    xn = torch.empty(branch.shape, dtype=torch.bfloat16, device=branch.device) if norm_weight is not None else None
+    nbytes = rows * H * (branch.element_size() + residual.element_size() + 4 + (2 if norm_weight is not None else 0))
+    _timed("inject", float(nbytes), lambda: check(_lib.lib().licv_inject_renorm_add_fwd(
+        _p(branch), _dt(branch), _p(icv_row), _p(alpha), _p(residual), _dt(residual), _p(out), rows, H, _p(norm_weight), _p(xn),
+        float(norm_eps), norm_flavour, _stream(branch))))
+    return (out, xn) if norm_weight is not None else out
+
+
+def scatter_rows_(out: torch.Tensor, idx: torch.Tensor, src: torch.Tensor):
+    assert idx.dtype == torch.int64 and idx.is_contiguous() and src.is_contiguous() and out.is_contiguous()
+    check(_lib.lib().licv_scatter_rows(_p(src), _p(idx), _p(out), idx.numel(), src.shape[-1], _stream(out)))
+    return out
+
+
 def inject_renorm_bwd(h: torch.Tensor, icv_row: torch.Tensor, alpha: Optional[torch.Tensor], grad_out: torch.Tensor,
                       need_grad_h: bool = True):
     """Returns (grad_h fp32 or None, grad_v (H,) fp32) with v = alpha*icv_row."""

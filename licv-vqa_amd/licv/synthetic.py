@@ -14,7 +14,7 @@ from typing import Dict, Optional
 
 import torch
 
-from .config import IdeficsArch
+from .config import Idefics2Arch, IdeficsArch
 
 
 def _randn(shape, std, gen, device, dtype, mean=0.0):
@@ -201,3 +201,115 @@ def synth_icv(n_layers: int, hidden: int, seed: int = 426, alpha: float = 0.1, d
     icv = torch.randn(1, n_layers, hidden, generator=g) * 0.01
     al = torch.full((1, n_layers), float(alpha))
     return icv.to(device), al.to(device)
+
+
+# ------------------------------------------------------------------------------------------ Idefics2
+def synth_idefics2_weights(arch: Idefics2Arch, seed: int = 426, dtype=torch.bfloat16, device="cpu") -> Dict[str, torch.Tensor]:
+    """Random-init state dict with the HF key names of ``Idefics2ForConditionalGeneration``
+    (hf:idefics2/modeling_idefics2.py; text model = hf:mistral/modeling_mistral.py)."""
+    dev = torch.device(device)
+    gen = torch.Generator(device=dev if dev.type == "cuda" else "cpu")
+    gen.manual_seed(seed)
+    sd: Dict[str, torch.Tensor] = {}
+    a = arch
+
+    def lin(name, out_f, in_f, bias=False):
+        sd[name + ".weight"] = _randn((out_f, in_f), 0.02, gen, dev, dtype)
+        if bias:
+            sd[name + ".bias"] = _randn((out_f,), 0.02, gen, dev, dtype)
+
+    def norm(name, dim, bias=False):
+        sd[name + ".weight"] = _randn((dim,), 0.1, gen, dev, dtype, mean=1.0)
+        if bias:
+            sd[name + ".bias"] = _randn((dim,), 0.02, gen, dev, dtype)
+
+    vp = "model.vision_model."
+    sd[vp + "embeddings.patch_embedding.weight"] = _randn((a.v_hidden, 3, a.v_patch, a.v_patch), 0.02, gen, dev, dtype)
+    sd[vp + "embeddings.patch_embedding.bias"] = _randn((a.v_hidden,), 0.02, gen, dev, dtype)
+    sd[vp + "embeddings.position_embedding.weight"] = _randn(((a.v_image // a.v_patch) ** 2, a.v_hidden), 0.02, gen, dev, dtype)
+    for i in range(a.v_layers):
+        p = f"{vp}encoder.layers.{i}."
+        for n in ("k_proj", "v_proj", "q_proj", "out_proj"):
+            lin(p + "self_attn." + n, a.v_hidden, a.v_hidden, True)
+        norm(p + "layer_norm1", a.v_hidden, True)
+        lin(p + "mlp.fc1", a.v_inter, a.v_hidden, True)
+        lin(p + "mlp.fc2", a.v_hidden, a.v_inter, True)
+        norm(p + "layer_norm2", a.v_hidden, True)
+    norm(vp + "post_layernorm", a.v_hidden, True)
+    cp = "model.connector."
+    lin(cp + "modality_projection.gate_proj", a.intermediate_size, a.v_hidden)
+    lin(cp + "modality_projection.up_proj", a.intermediate_size, a.v_hidden)
+    lin(cp + "modality_projection.down_proj", a.hidden_size, a.intermediate_size)
+    rp = cp + "perceiver_resampler."
+    sd[rp + "latents"] = _randn((a.r_latents, a.hidden_size), 0.5, gen, dev, dtype, mean=1.0)
+    for i in range(a.r_depth):
+        p = f"{rp}layers.{i}."
+        norm(p + "input_latents_norm", a.hidden_size)
+        norm(p + "input_context_norm", a.hidden_size)
+        lin(p + "self_attn.q_proj", a.r_heads * a.r_head_dim, a.hidden_size)
+        lin(p + "self_attn.k_proj", a.r_kv_heads * a.r_head_dim, a.hidden_size)
+        lin(p + "self_attn.v_proj", a.r_kv_heads * a.r_head_dim, a.hidden_size)
+        lin(p + "self_attn.o_proj", a.hidden_size, a.r_heads * a.r_head_dim)
+        norm(p + "post_attention_layernorm", a.hidden_size)
+        lin(p + "mlp.gate_proj", 4 * a.hidden_size, a.hidden_size)
+        lin(p + "mlp.up_proj", 4 * a.hidden_size, a.hidden_size)
+        lin(p + "mlp.down_proj", a.hidden_size, 4 * a.hidden_size)
+    norm(rp + "norm", a.hidden_size)
+    tp = "model.text_model."
+    sd[tp + "embed_tokens.weight"] = _randn((a.vocab_size, a.hidden_size), 0.02, gen, dev, dtype)
+    hd = a.head_dim
+    for i in range(a.num_layers):
+        p = f"{tp}layers.{i}."
+        lin(p + "self_attn.q_proj", a.num_heads * hd, a.hidden_size)
+        lin(p + "self_attn.k_proj", a.num_kv_heads * hd, a.hidden_size)
+        lin(p + "self_attn.v_proj", a.num_kv_heads * hd, a.hidden_size)
+        lin(p + "self_attn.o_proj", a.hidden_size, a.num_heads * hd)
+        lin(p + "mlp.gate_proj", a.intermediate_size, a.hidden_size)
+        lin(p + "mlp.up_proj", a.intermediate_size, a.hidden_size)
+        lin(p + "mlp.down_proj", a.hidden_size, a.intermediate_size)
+        norm(p + "input_layernorm", a.hidden_size)
+        norm(p + "post_attention_layernorm", a.hidden_size)
+    norm(tp + "norm", a.hidden_size)
+    lin("lm_head", a.vocab_size, a.hidden_size)
+    return sd
+
+
+def synth_vqa_batch_idefics2(arch: Idefics2Arch, batch: int, seq_len: int, n_images: int, img_h: int, img_w: int, seed: int = 426,
+                             min_len: Optional[int] = None, dtype=torch.bfloat16, device="cpu", ragged: bool = True,
+                             drop_last_image_of_row0: bool = False) -> Dict[str, torch.Tensor]:
+    """input_ids with ``r_latents`` `<image>` tokens per image (hf:idefics2/processing_idefics2.py:129), right padded;
+    pixel_values (B, N, 3, H, W) with per-image valid regions given by pixel_attention_mask (ragged NaViT images:
+    the valid height/width are multiples of the patch size); optionally one all-zero padding image."""
+    g = torch.Generator().manual_seed(seed)
+    a = arch
+    min_len = seq_len if min_len is None else min_len
+    ids = torch.randint(3, a.image_token_id - 1, (batch, seq_len), generator=g)
+    lengths = torch.randint(min_len, seq_len + 1, (batch,), generator=g)
+    ids[:, 0] = a.bos_token_id
+    need = n_images * (a.r_latents + 2)
+    assert int(lengths.min()) - 2 >= need, "sequence too short for the requested images"
+    n_img_row = [n_images] * batch
+    if drop_last_image_of_row0 and n_images > 1:
+        n_img_row[0] = n_images - 1
+    for b in range(batch):
+        p = 1
+        for k in range(n_img_row[b]):
+            ids[b, p + 1: p + 1 + a.r_latents] = a.image_token_id
+            p += a.r_latents + 2
+    att = (torch.arange(seq_len).unsqueeze(0) < lengths.unsqueeze(1)).long()
+    ids = torch.where(att.bool(), ids, torch.full_like(ids, a.pad_token_id))
+    pix = torch.randn(batch, n_images, 3, img_h, img_w, generator=g)
+    pam = torch.zeros(batch, n_images, img_h, img_w, dtype=torch.bool)
+    P = a.v_patch
+    for b in range(batch):
+        for k in range(n_images):
+            if k >= n_img_row[b]:
+                pix[b, k] = 0.0                     # padding image: all zeros (removed by the model)
+                continue
+            hh = img_h if not ragged else P * int(torch.randint(max(1, img_h // P // 2), img_h // P + 1, (1,), generator=g))
+            ww = img_w if not ragged else P * int(torch.randint(max(1, img_w // P // 2), img_w // P + 1, (1,), generator=g))
+            pam[b, k, :hh, :ww] = True
+            pix[b, k, :, hh:, :] = 0.0
+            pix[b, k, :, :, ww:] = 0.0
+    return {"input_ids": ids.to(device), "attention_mask": att.to(device), "pixel_values": pix.to(dtype).to(device),
+            "pixel_attention_mask": pam.to(device)}

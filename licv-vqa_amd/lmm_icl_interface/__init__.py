@@ -7,5 +7,5 @@ the reference touches (``.model .tokenizer .processor .device .input_ids_field_n
 templating and tokenisation need tokenizer files that do not exist offline; ``LMMPromptManager`` /
 ``LMMPromptProcessor`` are thin and delegate to a transformers processor when one is supplied.
 """
-from .interface import IdeficsInterface, LMMInterface, LMMOutput  # noqa: F401
+from .interface import Idefics2Interface, IdeficsInterface, LMMInterface, LMMOutput  # noqa: F401
 from .prompt import LMMPromptManager, LMMPromptProcessor  # noqa: F401

@@ -7,9 +7,10 @@ from typing import Dict, List, Optional
 
 import torch
 
-from licv.config import IdeficsArch
+from licv.config import Idefics2Arch, IdeficsArch
 from licv.generation import generate as native_generate
 from licv.idefics_engine import IdeficsEngine, IdeficsWeights
+from licv.idefics2_engine import Idefics2Engine, Idefics2Weights
 
 
 class LMMOutput(dict):
@@ -20,9 +21,9 @@ class LMMOutput(dict):
 class _NativeModel(torch.nn.Module):
     """What ``interface.model`` exposes to the reference (ref:icv_src/icv_module.py:29-30)."""
 
-    def __init__(self, arch: IdeficsArch):
+    def __init__(self, arch, model_type: str = "idefics"):
         super().__init__()
-        self.config = types.SimpleNamespace(**arch.to_dict(), model_type="idefics")
+        self.config = types.SimpleNamespace(**arch.to_dict(), model_type=model_type)
 
     def gradient_checkpointing_enable(self, *a, **k):      # the native engine recomputes instead
         return None
@@ -62,12 +63,12 @@ class IdeficsInterface(LMMInterface):
         self.processor = processor
 
     @staticmethod
-    def _load_checkpoint(path: Path, tokenizer, processor):
+    def _load_checkpoint(path: Path, tokenizer, processor, arch_cls=IdeficsArch):
         from safetensors.torch import load_file
         from transformers import AutoConfig
         if not path.is_dir():
             raise FileNotFoundError(f"{path} is not a local checkpoint directory (no network access to fetch one)")
-        arch = IdeficsArch.from_hf(AutoConfig.from_pretrained(path))
+        arch = arch_cls.from_hf(AutoConfig.from_pretrained(path))
         sd = {}
         for f in sorted(path.glob("*.safetensors")):
             sd.update(load_file(str(f)))
@@ -134,3 +135,50 @@ class IdeficsInterface(LMMInterface):
                                eos_token_id=eos_token_id if eos_token_id is not None else getattr(self.tokenizer, "eos_token_id", None),
                                pad_token_id=pad_token_id if pad_token_id is not None else getattr(self.tokenizer, "pad_token_id", None),
                                **self._hooks())
+
+
+class Idefics2Interface(IdeficsInterface):
+    """Idefics2Interface(model_name_or_path, precision, device, prompt_manager, instruction, image_field, label_field)
+    (ref:utils.py:68-78).  Hook sites are the text layers' MLP branches (ref:config/lmm/idefics2-8B-base.yaml:8)."""
+
+    HOOK_SITE = re.compile(r"^model\.model\.text_model\.layers\.(\d+)\.mlp$")
+
+    def __init__(self, model_name_or_path=None, precision="bf16", device="cuda", prompt_manager=None, instruction="",
+                 image_field="image", label_field="answer", *, state_dict: Optional[Dict[str, torch.Tensor]] = None,
+                 arch: Optional[Idefics2Arch] = None, tokenizer=None, processor=None):
+        LMMInterface.__init__(self)
+        if str(precision) not in ("bf16", "bfloat16", "torch.bfloat16"):
+            raise ValueError(f"the native Idefics2 path computes in bf16 only (got precision={precision!r})")
+        if state_dict is None:
+            state_dict, arch, tokenizer, processor = self._load_checkpoint(Path(model_name_or_path), tokenizer, processor, Idefics2Arch)
+        self.arch = arch
+        self._device = torch.device(device)
+        self.engine = Idefics2Engine(Idefics2Weights(state_dict, arch, self._device))
+        self.model = _NativeModel(arch, "idefics2")
+        self.prompt_manager, self.instruction = prompt_manager, instruction
+        self.image_field, self.label_field = image_field, label_field
+        self.tokenizer = tokenizer if tokenizer is not None else types.SimpleNamespace(
+            pad_token_id=arch.pad_token_id, bos_token_id=arch.bos_token_id, eos_token_id=arch.eos_token_id, padding_side="right")
+        self.processor = processor
+
+    def install_intervention(self, layer_names: List[str], layer_to_icv_index: Dict[int, int], icv: torch.Tensor):
+        try:
+            super().install_intervention(layer_names, layer_to_icv_index, icv)
+        except LookupError as e:
+            raise LookupError(str(e).replace("model.model.layers.<", "model.model.text_model.layers.<").replace(">)", ">.mlp)")
+                              .replace("Idefics engine", "Idefics2 engine")) from None
+
+    def forward(self, input_ids=None, attention_mask=None, pixel_values=None, pixel_attention_mask=None, labels=None, **_):
+        dev = self._device
+        logits = self.engine.forward(input_ids.to(dev), attention_mask.to(dev) if attention_mask is not None else None,
+                                     pixel_values.to(dev) if pixel_values is not None else None,
+                                     pixel_attention_mask.to(dev) if pixel_attention_mask is not None else None, **self._hooks())
+        out = LMMOutput(logits=logits)
+        if labels is not None:
+            # hf:idefics2/modeling_idefics2.py ForConditionalGeneration loss: plain shifted CE, ignore_index=-100
+            out["loss"] = torch.nn.functional.cross_entropy(logits[:, :-1].float().reshape(-1, logits.shape[-1]),
+                                                            labels[:, 1:].to(dev).reshape(-1), ignore_index=-100)
+        return out
+
+    def generate(self, *a, **k):
+        raise NotImplementedError("hooked generate for Idefics2 is not built yet (DESIGN.md §6); Idefics generate is")

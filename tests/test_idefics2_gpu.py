@@ -1,0 +1,107 @@
+"""Parity of the native Idefics2 engine (HIP, through the C-ABI) with HF Idefics2 driven by the reference's wrapper
+(fixtures g4_*, hook on every text layer's ``.mlp`` branch, bf16 autocast regime).  Same bar as tests/test_engine_gpu.py:
+  (i)  max|hip - bf16_gold| <= 1.5e-2 * max|gold|;
+  (ii) max|hip - f32_gold| <= 1.5 * max|bf16_gold - f32_gold| + 1e-3 * scale.
+"""
+import pytest
+import torch
+
+from licv.config import IDEFICS2_MID, IDEFICS2_TINY
+from licv.synthetic import synth_idefics2_weights
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+DEV = "cuda"
+
+
+def _engine(arch, seed, fuse=True):
+    from licv.idefics2_engine import Idefics2Engine, Idefics2Weights
+    sd = synth_idefics2_weights(arch, seed=seed, dtype=torch.float32)
+    return Idefics2Engine(Idefics2Weights(sd, arch, DEV), fuse_hook_norm=fuse), sd
+
+
+def _check(hip, gold_bf16, gold_f32, what):
+    hip = hip.float().cpu().reshape(gold_bf16.shape)
+    scale = float(gold_f32.abs().max())
+    e_gold = float((hip - gold_bf16).abs().max())
+    e_true = float((hip - gold_f32).abs().max())
+    spread = float((gold_bf16 - gold_f32).abs().max())
+    assert e_gold <= 1.5e-2 * scale, f"{what}: |hip-bf16 gold| {e_gold:.3e} vs scale {scale:.3e}"
+    assert e_true <= 1.5 * spread + 1e-3 * scale, f"{what}: |hip-f32 gold| {e_true:.3e} vs reference spread {spread:.3e}"
+
+
+def _inputs(z):
+    return dict(input_ids=T(z["in_input_ids"]).to(DEV), attention_mask=T(z["in_attention_mask"]).to(DEV),
+                pixel_values=T(z["in_pixel_values"]).to(DEV), pixel_attention_mask=T(z["in_pixel_attention_mask"]).to(DEV))
+
+
+@pytest.mark.parametrize("tag,arch", [("g4_idefics2_tiny", IDEFICS2_TINY), ("g4_idefics2_mid", IDEFICS2_MID)])
+def test_idefics2_engine_matches_reference_fixtures(golden, tag, arch):
+    z = golden(tag)
+    eng, _ = _engine(arch, int(z["meta"][0]))
+    ins = _inputs(z)
+    cap = {}
+    off = eng.forward(**ins, capture=cap)
+    _check(cap["image_hidden_states"], T(z["bf16_image_hidden_states"]), T(z["f32_image_hidden_states"]), "connector output")
+    _check(off, T(z["bf16_logits_off"]), T(z["f32_logits_off"]), "logits (hooks off)")
+    assert cap["layer_out"][-1].dtype == torch.bfloat16            # no hook -> the stream stays bf16
+    layers = list(range(arch.num_layers))
+    cap = {}
+    lg = eng.forward(**ins, icv=T(z["icv_full"]).to(DEV), hook_layers=layers, capture=cap)
+    _check(torch.stack([t.float() for t in cap["mlp_raw"]]), T(z["bf16_all_mlp_raw"]), T(z["f32_all_mlp_raw"]), "MLP branch (pre-hook)")
+    _check(torch.stack([t.float() for t in cap["layer_out"]]), T(z["bf16_all_layer_out"]), T(z["f32_all_layer_out"]), "layer outputs")
+    _check(lg, T(z["bf16_all_logits"]), T(z["f32_all_logits"]), "logits (hooks on)")
+    assert all(t.dtype == torch.float32 for t in cap["layer_out"])  # the hooked branch promotes the stream
+    # the hook is live: logits move
+    assert (lg.float() - off.float()).abs().max() > 1e-3
+
+
+def test_idefics2_fused_hook_norm_is_bitwise_the_unfused_path(golden):
+    z = golden("g4_idefics2_mid")
+    arch = IDEFICS2_MID
+    e1, _ = _engine(arch, int(z["meta"][0]), fuse=True)
+    from licv.idefics2_engine import Idefics2Engine
+    e2 = Idefics2Engine(e1.w, fuse_hook_norm=False)
+    ins = _inputs(z)
+    icv = T(z["icv_full"]).to(DEV)
+    layers = list(range(arch.num_layers))
+    a = e1.forward(**ins, icv=icv, hook_layers=layers)
+    b = e2.forward(**ins, icv=icv, hook_layers=layers)
+    assert torch.equal(a, b)
+    # alpha folded into the kernel == alpha pre-multiplied on the host (ref:icv_src/icv_module.py:89-92)
+    al = torch.full((1, arch.num_layers), 0.25, device=DEV)
+    c = e1.forward(**ins, icv=icv, hook_layers=layers, alpha=al)
+    d = e1.forward(**ins, icv=al.unsqueeze(-1) * icv, hook_layers=layers)
+    assert (c.float() - d.float()).abs().max() <= 2e-2 * d.float().abs().max()
+
+
+def test_idefics2_subset_of_layers_and_interface(golden):
+    """Drop-in surface: Idefics2Interface + the reference's hook-site names; a subset of layers leaves the others bf16."""
+    from lmm_icl_interface import Idefics2Interface
+    z = golden("g4_idefics2_tiny")
+    arch = IDEFICS2_TINY
+    sd = synth_idefics2_weights(arch, seed=int(z["meta"][0]), dtype=torch.float32)
+    itf = Idefics2Interface(state_dict=sd, arch=arch, device=DEV)
+    ins = _inputs(z)
+    off = itf(**ins)["logits"]
+    _check(off, T(z["bf16_logits_off"]), T(z["f32_logits_off"]), "interface logits (hooks off)")
+    names = [f"model.model.text_model.layers.{l}.mlp" for l in range(arch.num_layers)]
+    itf.install_intervention(names, {l: l for l in range(arch.num_layers)}, T(z["icv_full"]).to(DEV))
+    on = itf(**ins)["logits"]
+    _check(on, T(z["bf16_all_logits"]), T(z["f32_all_logits"]), "interface logits (hooks on)")
+    itf.remove_intervention()
+    assert torch.equal(itf(**ins)["logits"], off)
+    with pytest.raises(LookupError):
+        itf.install_intervention(["model.model.layers.0"], {0: 0}, T(z["icv_full"]).to(DEV))
+    # subset: only layer 1 hooked -> layer 0 output bf16, later fp32; matches the CPU oracle
+    import oracle.idefics2_ref as R2
+    cap = {}
+    icv1 = T(z["icv_full"])[:, 1:2]
+    lg = itf.engine.forward(**ins, icv=icv1.to(DEV), hook_layers=[1], capture=cap)
+    assert cap["layer_out"][0].dtype == torch.bfloat16 and cap["layer_out"][1].dtype == torch.float32
+    sdb = {k: v.to(torch.bfloat16) for k, v in sd.items()}
+    cpu_ins = {k: v.cpu() for k, v in ins.items()}
+    cpu_ins["pixel_values"] = cpu_ins["pixel_values"].to(torch.bfloat16)
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+        ref = R2.forward(sdb, arch, **cpu_ins, icv=icv1, hook_layers=[1])
+    assert (lg.float().cpu() - ref.float()).abs().max() <= 1.5e-2 * ref.float().abs().max()

@@ -3,10 +3,11 @@ import numpy as np
 import pytest
 import torch
 
-from licv.config import IDEFICS_MID, IDEFICS_TINY
-from licv.synthetic import synth_idefics_weights, weights_checksum
+from licv.config import IDEFICS2_MID, IDEFICS2_TINY, IDEFICS_MID, IDEFICS_TINY
+from licv.synthetic import synth_idefics2_weights, synth_idefics_weights, weights_checksum
 from oracle import icv_ref as O
 from oracle import idefics_ref as R
+from oracle import idefics2_ref as R2
 
 T = torch.from_numpy
 
@@ -83,6 +84,35 @@ def test_g3_idefics_forward(golden, tag, arch, dn, dt):
             assert (ed - T(z[f"{dn}_{hs}_edited"])).abs().max() <= tol
             # fp32 icv promotes the residual stream to fp32 from the first hooked layer on
             assert cap["edited"][-1].dtype == torch.float32
+
+
+@pytest.mark.parametrize("tag,arch", [("g4_idefics2_tiny", IDEFICS2_TINY), ("g4_idefics2_mid", IDEFICS2_MID)])
+@pytest.mark.parametrize("dn,dt", [("f32", torch.float32), ("bf16", torch.bfloat16)])
+def test_g4_idefics2_forward(golden, tag, arch, dn, dt):
+    """Idefics2 (hook on every text layer's MLP branch) against HF driven by the reference's wrapper.  bf16 = the
+    reference's autocast regime; the oracle runs inside the same autocast context."""
+    import contextlib
+    z = golden(tag)
+    sd32 = synth_idefics2_weights(arch, seed=int(z["meta"][0]), dtype=torch.float32)
+    assert weights_checksum(sd32) == float(z["weights_checksum"]), "seeded weight generator drifted"
+    sd = {k: v.to(dt) for k, v in sd32.items()}
+    ins = dict(input_ids=T(z["in_input_ids"]), attention_mask=T(z["in_attention_mask"]),
+               pixel_values=T(z["in_pixel_values"]).to(dt), pixel_attention_mask=T(z["in_pixel_attention_mask"]))
+    tol = 1e-5 if dn == "f32" else 0.0
+    ctx = torch.autocast("cpu", dtype=torch.bfloat16) if dn == "bf16" else contextlib.nullcontext()
+    layers = list(range(arch.num_layers))
+    with torch.no_grad(), ctx:
+        cap = {}
+        off = R2.forward(sd, arch, **ins, capture=cap)
+        assert (off.float() - T(z[f"{dn}_logits_off"])).abs().max() <= tol
+        assert (cap["image_hidden_states"].float() - T(z[f"{dn}_image_hidden_states"]).reshape(cap["image_hidden_states"].shape)).abs().max() <= tol
+        cap = {}
+        lg = R2.forward(sd, arch, **ins, icv=T(z["icv_full"]), hook_layers=layers, capture=cap)
+        assert (lg.float() - T(z[f"{dn}_all_logits"])).abs().max() <= tol
+        assert (torch.stack([t.float() for t in cap["mlp_raw"]]) - T(z[f"{dn}_all_mlp_raw"])).abs().max() <= tol
+        assert (torch.stack([t.float() for t in cap["layer_out"]]) - T(z[f"{dn}_all_layer_out"])).abs().max() <= tol
+        assert cap["layer_out"][0].dtype == torch.float32          # the hooked branch promotes the stream to fp32
+        assert bool(z[f"{dn}_layer_out_is_f32"])
 
 
 def _g6_setup(golden, dt):

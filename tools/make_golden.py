@@ -35,8 +35,9 @@ sys.path.insert(0, str(ROOT))
 REF = Path("/root/reference")
 OUT = ROOT / "tests" / "golden"
 
-from licv.config import IDEFICS_TINY, IDEFICS_MID, IdeficsArch  # noqa: E402
-from licv.synthetic import synth_idefics_weights, synth_vqa_batch, weights_checksum  # noqa: E402
+from licv.config import IDEFICS_TINY, IDEFICS_MID, IDEFICS2_TINY, IDEFICS2_MID, IdeficsArch  # noqa: E402
+from licv.synthetic import (synth_idefics_weights, synth_vqa_batch, weights_checksum, synth_idefics2_weights,  # noqa: E402
+                            synth_vqa_batch_idefics2)
 
 # The build's own drop-in package is also called ``icv_src``; make sure the name resolves to the
 # REFERENCE here: drop the build's package dir from the path now that ``licv`` is imported.
@@ -274,6 +275,80 @@ def g3_idefics():
     _run_idefics(IDEFICS_MID, "g3_idefics_mid", 12, B=2, S=24, N=3, min_len=18, hook_sets={"all": -1})
 
 
+def hf_idefics2(arch, sd, dtype):
+    from transformers import Idefics2Config, Idefics2ForConditionalGeneration
+    cfg = Idefics2Config(
+        vision_config=dict(hidden_size=arch.v_hidden, intermediate_size=arch.v_inter, num_hidden_layers=arch.v_layers,
+                           num_attention_heads=arch.v_heads, image_size=arch.v_image, patch_size=arch.v_patch,
+                           hidden_act=arch.v_act, layer_norm_eps=arch.v_ln_eps),
+        perceiver_config=dict(hidden_size=arch.hidden_size, resampler_n_latents=arch.r_latents, resampler_depth=arch.r_depth,
+                              resampler_n_heads=arch.r_heads, resampler_head_dim=arch.r_head_dim,
+                              num_key_value_heads=arch.r_kv_heads, hidden_act="silu", rms_norm_eps=arch.rms_eps),
+        text_config=dict(model_type="mistral", vocab_size=arch.vocab_size, hidden_size=arch.hidden_size,
+                         intermediate_size=arch.intermediate_size, num_hidden_layers=arch.num_layers,
+                         num_attention_heads=arch.num_heads, num_key_value_heads=arch.num_kv_heads, rms_norm_eps=arch.rms_eps,
+                         max_position_embeddings=4096, sliding_window=4096, pad_token_id=arch.pad_token_id,
+                         rope_parameters=dict(rope_type="default", rope_theta=arch.rope_base)),
+        image_token_id=arch.image_token_id, attn_implementation="eager")
+    m = Idefics2ForConditionalGeneration(cfg)
+    missing, unexpected = m.load_state_dict({k: v.float() for k, v in sd.items()}, strict=False)
+    assert not unexpected and not missing, (missing, unexpected)
+    m = m.to(dtype).eval()
+    # `.to(bf16)` also rounds the rotary inv_freq BUFFER, which a checkpoint loaded with torch_dtype=bf16 never does
+    # (the buffer is created in fp32 at init): restore it so the fixture reflects real usage
+    rot = m.model.text_model.rotary_emb
+    hd = arch.hidden_size // arch.num_heads
+    rot.inv_freq = 1.0 / (arch.rope_base ** (torch.arange(0, hd, 2, dtype=torch.float) / hd))
+    rot.original_inv_freq = rot.inv_freq.clone()
+    return m
+
+
+def g4_idefics2():
+    """Idefics2 tiny/mid: ragged NaViT images + one padding image, GQA, hook on `.mlp` (ref:config/lmm/idefics2-8B-base.yaml:8)
+    through the reference wrapper; bf16 runs under autocast (the only way HF runs with the fp32-promoted stream)."""
+    from icv_src.icv_model.icv_intervention import LearnableICVInterventionLMM
+    fmt = "model.model.text_model.layers.<LAYER_NUM>.mlp"
+    for tag, arch, seed, (B, S, N, ih, iw, mn) in (("g4_idefics2_tiny", IDEFICS2_TINY, 41, (2, 20, 2, 56, 42, 16)),
+                                                    ("g4_idefics2_mid", IDEFICS2_MID, 42, (2, 40, 2, 84, 70, 30))):
+        out = {}
+        sd32 = synth_idefics2_weights(arch, seed=seed, dtype=torch.float32)
+        out["weights_checksum"] = np.array(weights_checksum(sd32))
+        out["meta"] = np.array([seed, B, S, N, ih, iw, mn])
+        batch = synth_vqa_batch_idefics2(arch, B, S, N, ih, iw, seed=seed, min_len=mn, dtype=torch.float32,
+                                         drop_last_image_of_row0=True)
+        for k, v in batch.items():
+            out["in_" + k] = np_(v)
+        g = torch.Generator().manual_seed(seed + 1)
+        icv = torch.randn(1, arch.num_layers, arch.hidden_size, generator=g) * 0.05
+        out["icv_full"] = np_(icv)
+        for dt_name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+            model = hf_idefics2(arch, sd32, dt)
+            iface = Interface(model, arch.pad_token_id)
+            kw = dict(batch)
+            kw["pixel_values"] = batch["pixel_values"].to(dt)
+            ctx = torch.autocast("cpu", dtype=torch.bfloat16) if dt == torch.bfloat16 else contextlib.nullcontext()
+            with torch.no_grad(), ctx:
+                base = model(**kw)
+                out[f"{dt_name}_logits_off"] = np_(base.logits)
+                out[f"{dt_name}_image_hidden_states"] = np_(base.image_hidden_states)
+                w = LearnableICVInterventionLMM(iface, True, -1, fmt, arch.num_layers)
+                raw, outs, handles = [], [], []
+                for blk in model.model.text_model.layers:
+                    handles.append(blk.mlp.register_forward_hook(lambda m, i, o, raw=raw: raw.append(o.detach().clone())))
+                    handles.append(blk.register_forward_hook(lambda m, i, o, outs=outs: outs.append(o.detach().clone())))
+                res = w(icv=icv, **kw)
+                for h_ in handles:
+                    h_.remove()
+                out[f"{dt_name}_all_logits"] = np_(res.logits)
+                out[f"{dt_name}_all_mlp_raw"] = np.stack([np_(t) for t in raw])
+                out[f"{dt_name}_all_layer_out"] = np.stack([np_(t) for t in outs])
+                out[f"{dt_name}_layer_out_is_f32"] = np.array(outs[-1].dtype == torch.float32)
+                w.toggle_intervention(False)
+                off = w(icv=icv, **kw)
+                assert torch.equal(off.logits, base.logits)
+        np.savez_compressed(OUT / f"{tag}.npz", **out)
+
+
 def g5_generate():
     """Hooked beam-search generate ids (beams=3, 5 new tokens, length_penalty 0 —
     ref:config/inference.yaml:26-30) + greedy, additional_vocab_size=0 (HF 5.15 beam search
@@ -420,8 +495,8 @@ def main():
     import icv_src.icv_model.icv_intervention as _ri
     assert _ri.__file__.startswith(str(REF)), _ri.__file__
     torch.set_num_threads(4)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g5", "g6", "g7"]
-    fns = dict(g1=g1_encoder, g2=g2_intervention, g3=g3_idefics, g5=g5_generate, g6=g6_loss, g7=g7_optim)
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    fns = dict(g1=g1_encoder, g2=g2_intervention, g3=g3_idefics, g4=g4_idefics2, g5=g5_generate, g6=g6_loss, g7=g7_optim)
     for w in which:
         print("generating", w, flush=True)
         fns[w]()
