@@ -36,7 +36,12 @@ WORKLOADS = {
     # backward + [every 2nd micro-batch] all-reduce + clipped AdamW.  (arch, B, S_teacher, n_img_teacher, min_len)
     "idefics9b_train_bs8": ("idefics-9b", 8, 800, 33, 720),
     "idefics_mid_train_debug": ("idefics-mid", 4, 96, 5, 80),
+    # BASELINE configs[3]: Idefics2-8B-base 1-shot (1 demo + query image per question, 64 <image> tokens each),
+    # COCO-sized 480x640 images (processor keeps them: shortest edge >= 378, longest <= 980), hook on all 32 MLP branches
+    "idefics2_8b_1shot_bs8": ("idefics2-8b", 8, 192, 2, 176),
+    "idefics2_mid_debug": ("idefics2-mid", 2, 40, 2, 30),
 }
+IDEFICS2_IMAGE = {"idefics2-8b": (480, 640), "idefics2-mid": (84, 70)}
 
 
 def _host_cores() -> int:
@@ -92,6 +97,42 @@ def cpu_baseline(arch, S, n_img):
                    + f"; scaled by layer counts ({arch.v_layers} ViT, {arch.r_depth} perceiver, {arch.num_cross_layers} x-attn, "
                    f"{arch.num_layers} decoder) = {full:.1f} s/question"),
     }
+
+
+def cpu_baseline_idefics2(arch, S, n_img, hw):
+    """Same bounded sample for Idefics2: one question through one SigLIP layer, the modality projection + one perceiver
+    layer, one hooked Mistral layer and the LM head in the CPU oracle under bf16 autocast; scaled by the layer counts."""
+    from licv.synthetic import synth_idefics2_weights, synth_vqa_batch_idefics2
+    from oracle import idefics2_ref as R2
+    cores = _host_cores()
+    torch.set_num_threads(cores)
+    tm = {}
+
+    def run(small, tag):
+        sd = synth_idefics2_weights(small, seed=1, dtype=torch.bfloat16)
+        b = synth_vqa_batch_idefics2(small, 1, S, n_img, hw[0] // small.v_patch * small.v_patch, hw[1] // small.v_patch * small.v_patch,
+                                     seed=2, min_len=S, dtype=torch.bfloat16, ragged=False)
+        icv = torch.randn(1, small.num_layers, arch.hidden_size) * 0.01
+        best = float("inf")
+        with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+            for _ in range(3):                                   # min of 3: the per-layer figures are differences of these
+                t0 = time.perf_counter()
+                R2.forward(sd, small, **b, icv=icv, hook_layers=list(range(small.num_layers)))
+                best = min(best, time.perf_counter() - t0)
+        tm[tag] = best
+
+    run(arch.with_(v_layers=1, r_depth=1, num_layers=1), "1v+1p+1t")
+    run(arch.with_(v_layers=2, r_depth=1, num_layers=1), "2v+1p+1t")
+    run(arch.with_(v_layers=1, r_depth=2, num_layers=1), "1v+2p+1t")
+    run(arch.with_(v_layers=1, r_depth=1, num_layers=2), "1v+1p+2t")
+    base = tm["1v+1p+1t"]
+    dv, dp, dt_ = (max(tm[k] - base, 0.0) for k in ("2v+1p+1t", "1v+2p+1t", "1v+1p+2t"))
+    full = base + dv * (arch.v_layers - 1) + dp * (arch.r_depth - 1) + dt_ * (arch.num_layers - 1)
+    return {"value": 1.0 / full, "unit": "questions/s", "cores": cores, "kind": "port",
+            "sample": (f"1 question (S={S}, {n_img} images {hw[0]}x{hw[1]}) through the CPU oracle (bf16 autocast) truncated to 1-2 layers "
+                       f"of each kind: " + ", ".join(f"{k} {v:.2f}s" for k, v in tm.items())
+                       + f"; per-layer differences scaled to {arch.v_layers} SigLIP / {arch.r_depth} perceiver / {arch.num_layers} text layers "
+                       f"= {full:.1f} s/question")}
 
 
 def build_trainer(arch, sd, dev, B, S, n_img, min_len, rank):
@@ -151,17 +192,31 @@ def main():
 
     preset, B, S, n_img, min_len = WORKLOADS[args.workload]
     arch = idefics_arch(preset)
-    sd = synth_idefics_weights(arch, seed=426, dtype=torch.bfloat16, device=dev)       # full replica per GPU
+    is2 = preset.startswith("idefics2")
     training = "train" in args.workload
     trainer = None
-    if training:
+    if is2:
+        from licv.idefics2_engine import Idefics2Engine, Idefics2Weights
+        from licv.synthetic import synth_idefics2_weights, synth_vqa_batch_idefics2
+        sd = synth_idefics2_weights(arch, seed=426, dtype=torch.bfloat16, device=dev)
+        eng = Idefics2Engine(Idefics2Weights(sd, arch, dev))
+    else:
+        sd = synth_idefics_weights(arch, seed=426, dtype=torch.bfloat16, device=dev)       # full replica per GPU
+    if is2:
+        pass
+    elif training:
         trainer, train_args = build_trainer(arch, sd, dev, B, S, n_img, min_len, rank)
         eng = trainer.m.interface.engine
     else:
         eng = IdeficsEngine(IdeficsWeights(sd, arch, dev))
     del sd
     torch.cuda.empty_cache()
-    batch = synth_vqa_batch(arch, B, S, n_img, seed=426 + rank, min_len=min_len, dtype=torch.bfloat16, device=dev)
+    if is2:
+        ih, iw = IDEFICS2_IMAGE[preset]
+        batch = synth_vqa_batch_idefics2(arch, B, S, n_img, ih, iw, seed=426 + rank, min_len=min_len, dtype=torch.bfloat16, device=dev,
+                                         ragged=False)
+    else:
+        batch = synth_vqa_batch(arch, B, S, n_img, seed=426 + rank, min_len=min_len, dtype=torch.bfloat16, device=dev)
     icv, alpha = synth_icv(arch.num_layers, arch.hidden_size, seed=426, alpha=0.1, device=dev)
     layers = list(range(arch.num_layers))
     hooks = {} if args.no_hooks else dict(icv=icv, alpha=alpha, hook_layers=layers)
@@ -202,12 +257,13 @@ def main():
         return sum(t for t, _ in ev), sum(w for _, w in ev), len(ev)
     tg, fl, ng = agg("gemm")
     ti, by, ni = agg("inject")
-    fq = flops_per_question(arch, S, n_img)
+    fq = {"total": fl / max(args.steps, 1) / B} if is2 else flops_per_question(arch, S, n_img)   # Idefics2: GEMM flops as launched
     res = {
-        "metric": "VQA questions/sec (whole node), Idefics-9B 32-shot ICV forward",
+        "metric": ("VQA questions/sec (whole node), Idefics2-8B-base 1-shot ICV forward" if is2 else
+                   "VQA questions/sec (whole node), Idefics-9B 32-shot ICV forward"),
         "value": qps, "unit": "questions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic (random-init Idefics-9B weights, seeded image+text batches)",
+        "dtype": "bf16", "data": f"synthetic (random-init {preset} weights, seeded image+text batches)",
         "config": {"workload": args.workload, "arch": preset, "questions_per_gpu": B, "seq_len": S, "images_per_question": n_img,
                    "hooked_layers": 0 if args.no_hooks else arch.num_layers, "parallelism": f"dp{world}",
                    **({"train": "teacher fwd + student fwd/bwd + KL; accumulate 2; 1 all-reduce of 131 105 fp32 + AdamW per optimiser step"} if training else {})},
@@ -222,9 +278,9 @@ def main():
         res["hook_kernel"] = {"bound": "hbm", "kernel": "inject_renorm_fwd_k (+fused RMSNorm)", "achieved": by / ti / 1e9,
                               "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": by / ti / 1e9 / PEAK_HBM_GBS,
                               "launches_per_step": ni // max(args.steps, 1), "avg_launch_us": 1e6 * ti / ni,
-                              "algorithmic_MB_per_question": inject_bytes_per_question(arch, S, arch.num_layers) / 1e6}
+                              "algorithmic_MB_per_question": by / max(args.steps, 1) / B / 1e6}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline(arch, S, n_img)
+        res["cpu_baseline"] = cpu_baseline_idefics2(arch, S, n_img, IDEFICS2_IMAGE[preset]) if is2 else cpu_baseline(arch, S, n_img)
     if rank == 0:
         print(json.dumps(res), flush=True)
     if dist is not None:
