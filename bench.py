@@ -260,6 +260,7 @@ def main():
     fq = {"total": fl / max(args.steps, 1) / B} if is2 else flops_per_question(arch, S, n_img)   # Idefics2: GEMM flops as launched
     res = {
         "metric": ("VQA questions/sec (whole node), Idefics2-8B-base 1-shot ICV forward" if is2 else
+                   "VQA questions/sec (whole node), Idefics-9B 32-shot L-ICV training micro-batch" if training else
                    "VQA questions/sec (whole node), Idefics-9B 32-shot ICV forward"),
         "value": qps, "unit": "questions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

@@ -133,6 +133,22 @@ struct AttnBwdP {
     int want_dkv;
 };
 
+__device__ __forceinline__ float dot8(const bf16_t* __restrict__ x, const bf16_t* __restrict__ y, int hd) {
+    float acc = 0.f;
+    for (int d = 0; d < hd; d += 8) {
+        const uint4 xv = *reinterpret_cast<const uint4*>(x + d), yv = *reinterpret_cast<const uint4*>(y + d);
+        const uint32_t xu[4] = {xv.x, xv.y, xv.z, xv.w}, yu[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc += __uint_as_float(xu[e] << 16) * __uint_as_float(yu[e] << 16);
+            acc += __uint_as_float(xu[e] & 0xffff0000u) * __uint_as_float(yu[e] & 0xffff0000u);
+        }
+    }
+    return acc;
+}
+
+// One workgroup per (batch, head); every phase spreads its (row, column) or (row, 8-channel chunk) items over all 256
+// lanes.  Q/K/V/dO stay in global memory (a few KiB per head, L1/L2 resident); P and dS (Sq x Sk fp32 each) live in LDS.
 __global__ __launch_bounds__(256)
 void attn_bwd_small_k(AttnBwdP a) {
     extern __shared__ float bsm[];
@@ -141,78 +157,97 @@ void attn_bwd_small_k(AttnBwdP a) {
     const int head = blockIdx.x % a.nh, b = blockIdx.x / a.nh;
     const int kvh = head / (a.nh / a.nkv);
     const int coff = a.Sk - a.Sq;
-    const bf16_t* qb = a.q + (int64_t)b * a.q_bs + (int64_t)head * a.hd;
-    const bf16_t* kb = a.k + (int64_t)b * a.kv_bs + (int64_t)kvh * a.hd;
-    const bf16_t* vb = a.v + (int64_t)b * a.kv_bs + (int64_t)kvh * a.hd;
-    const bf16_t* dob = a.dout + (int64_t)b * a.Sq * a.nh * a.hd + (int64_t)head * a.hd;
-    for (int i = threadIdx.x; i < a.Sq; i += blockDim.x) {
-        const bf16_t* qi = qb + (int64_t)i * a.q_rs;
-        const bf16_t* doi = dob + (int64_t)i * a.nh * a.hd;
-        const int32_t* imrow = a.mask_mode == 3 ? a.img_mask + ((int64_t)b * a.Sq + i) * a.n_img : nullptr;
-        float mx = -INFINITY;
-        for (int j = 0; j < a.Sk; ++j) {
-            bool ok = true;
-            if (a.mask_mode == 1) ok = (j <= i + coff) && (!a.key_valid || a.key_valid[(int64_t)b * a.Sk + j] != 0);
-            else if (a.mask_mode == 2) ok = !a.key_valid || a.key_valid[(int64_t)b * a.Sk + j] != 0;
-            else if (a.mask_mode == 3) ok = imrow[j / a.img_len] != 0;
-            float s = -INFINITY;
-            if (ok) {
-                const bf16_t* kj = kb + (int64_t)j * a.kv_rs;
-                float acc = 0.f;
-                for (int d = 0; d < a.hd; ++d) acc += bf2f(qi[d]) * bf2f(kj[d]);
-                s = acc * a.scale;
-            }
-            P[i * a.Sk + j] = s;
-            mx = fmaxf(mx, s);
+    const int hd = a.hd, Sq = a.Sq, Sk = a.Sk, tid = threadIdx.x;
+    const bf16_t* qb = a.q + (int64_t)b * a.q_bs + (int64_t)head * hd;
+    const bf16_t* kb = a.k + (int64_t)b * a.kv_bs + (int64_t)kvh * hd;
+    const bf16_t* vb = a.v + (int64_t)b * a.kv_bs + (int64_t)kvh * hd;
+    const int64_t do_rs = (int64_t)a.nh * hd;
+    const bf16_t* dob = a.dout + (int64_t)b * Sq * do_rs + (int64_t)head * hd;
+    // phase 1: masked scores and dP = dO V^T
+    for (int idx = tid; idx < Sq * Sk; idx += 256) {
+        const int i = idx / Sk, j = idx - i * Sk;
+        bool ok = true;
+        if (a.mask_mode == 1) ok = (j <= i + coff) && (!a.key_valid || a.key_valid[(int64_t)b * Sk + j] != 0);
+        else if (a.mask_mode == 2) ok = !a.key_valid || a.key_valid[(int64_t)b * Sk + j] != 0;
+        else if (a.mask_mode == 3) ok = a.img_mask[((int64_t)b * Sq + i) * a.n_img + j / a.img_len] != 0;
+        float s = -INFINITY, dp = 0.f;
+        if (ok) {
+            s = dot8(qb + (int64_t)i * a.q_rs, kb + (int64_t)j * a.kv_rs, hd) * a.scale;
+            dp = dot8(dob + (int64_t)i * do_rs, vb + (int64_t)j * a.kv_rs, hd);
         }
+        P[idx] = s;
+        dS[idx] = dp;
+    }
+    __syncthreads();
+    // phase 2: one wave per query row: softmax (probabilities rounded to bf16 like the forward), D = sum_j p dP, dS
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int i = wave; i < Sq; i += 4) {
+        float mx = -INFINITY;
+        for (int j = lane; j < Sk; j += 64) mx = fmaxf(mx, P[i * Sk + j]);
+        mx = wave_max(mx);
         float sum = 0.f;
-        for (int j = 0; j < a.Sk; ++j) {
-            const float s = P[i * a.Sk + j];
-            const float e = (s == -INFINITY) ? 0.f : __expf(s - mx);
-            P[i * a.Sk + j] = e;
+        for (int j = lane; j < Sk; j += 64) {
+            const float sc = P[i * Sk + j];
+            const float e = (sc == -INFINITY) ? 0.f : __expf(sc - mx);
+            P[i * Sk + j] = e;
             sum += e;
         }
+        sum = wave_sum(sum);
         const float inv = sum > 0.f ? 1.0f / sum : 0.f;
-        float D = 0.f;                           // sum_j p_ij dP_ij
-        for (int j = 0; j < a.Sk; ++j) {
-            const float p = rbf(P[i * a.Sk + j] * inv);           // forward rounds the probabilities to bf16
-            P[i * a.Sk + j] = p;
-            float dp = 0.f;
-            if (p != 0.f) {
-                const bf16_t* vj = vb + (int64_t)j * a.kv_rs;
-                for (int d = 0; d < a.hd; ++d) dp += bf2f(doi[d]) * bf2f(vj[d]);
-            }
-            dS[i * a.Sk + j] = dp;
-            D += p * dp;
+        float D = 0.f;
+        for (int j = lane; j < Sk; j += 64) {
+            const float p = rbf(P[i * Sk + j] * inv);
+            P[i * Sk + j] = p;
+            D += p * dS[i * Sk + j];
         }
-        for (int j = 0; j < a.Sk; ++j) dS[i * a.Sk + j] = P[i * a.Sk + j] * (dS[i * a.Sk + j] - D) * a.scale;
-        // dQ_i = sum_j dS_ij K_j
-        bf16_t* dqi = a.dq + (int64_t)b * a.dq_bs + (int64_t)i * a.dq_rs + (int64_t)head * a.hd;
-        for (int d = 0; d < a.hd; ++d) {
-            float acc = 0.f;
-            for (int j = 0; j < a.Sk; ++j) {
-                const float ds = dS[i * a.Sk + j];
-                if (ds != 0.f) acc += ds * bf2f(kb[(int64_t)j * a.kv_rs + d]);
-            }
-            dqi[d] = f2bf(acc);
+        D = wave_sum(D);
+        for (int j = lane; j < Sk; j += 64) dS[i * Sk + j] = P[i * Sk + j] * (dS[i * Sk + j] - D) * a.scale;
+    }
+    __syncthreads();
+    // phase 3: dQ_i = sum_j dS_ij K_j, 8 channels per item
+    const int nch = hd >> 3;
+    for (int idx = tid; idx < Sq * nch; idx += 256) {
+        const int i = idx / nch, c = (idx - i * nch) * 8;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < Sk; ++j) {
+            const float ds = dS[i * Sk + j];
+            if (ds == 0.f) continue;
+            const uint4 kv = *reinterpret_cast<const uint4*>(kb + (int64_t)j * a.kv_rs + c);
+            const uint32_t ku[4] = {kv.x, kv.y, kv.z, kv.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc[2 * e] += ds * __uint_as_float(ku[e] << 16); acc[2 * e + 1] += ds * __uint_as_float(ku[e] & 0xffff0000u); }
         }
+        uint32_t o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (uint32_t)f2bf(acc[2 * e]) | ((uint32_t)f2bf(acc[2 * e + 1]) << 16);
+        *reinterpret_cast<uint4*>(a.dq + (int64_t)b * a.dq_bs + (int64_t)i * a.dq_rs + (int64_t)head * hd + c) = make_uint4(o[0], o[1], o[2], o[3]);
     }
     if (!a.want_dkv) return;
-    __syncthreads();
-    // dK_j = sum_i dS_ij Q_i ; dV_j = sum_i P_ij dO_i.  GQA: several query heads share a kv head -> the caller passes
-    // n_kv_heads == n_heads layouts only (asserted on the host) so each (b, head) owns its dK/dV slice.
-    for (int j = threadIdx.x; j < a.Sk; j += blockDim.x) {
-        bf16_t* dkj = a.dk + (int64_t)b * a.dkv_bs + (int64_t)j * a.dkv_rs + (int64_t)head * a.hd;
-        bf16_t* dvj = a.dv + (int64_t)b * a.dkv_bs + (int64_t)j * a.dkv_rs + (int64_t)head * a.hd;
-        for (int d = 0; d < a.hd; ++d) {
-            float ak = 0.f, av = 0.f;
-            for (int i = 0; i < a.Sq; ++i) {
-                ak += dS[i * a.Sk + j] * bf2f(qb[(int64_t)i * a.q_rs + d]);
-                av += P[i * a.Sk + j] * bf2f(dob[(int64_t)i * a.nh * a.hd + d]);
+    // phase 4: dK_j = sum_i dS_ij Q_i ; dV_j = sum_i P_ij dO_i  (n_kv_heads == n_heads asserted on the host)
+    for (int idx = tid; idx < Sk * nch; idx += 256) {
+        const int j = idx / nch, c = (idx - j * nch) * 8;
+        float ak[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, av[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < Sq; ++i) {
+            const float ds = dS[i * Sk + j], p = P[i * Sk + j];
+            if (ds == 0.f && p == 0.f) continue;
+            const uint4 qv = *reinterpret_cast<const uint4*>(qb + (int64_t)i * a.q_rs + c);
+            const uint4 gv = *reinterpret_cast<const uint4*>(dob + (int64_t)i * do_rs + c);
+            const uint32_t qu[4] = {qv.x, qv.y, qv.z, qv.w}, gu[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                ak[2 * e] += ds * __uint_as_float(qu[e] << 16); ak[2 * e + 1] += ds * __uint_as_float(qu[e] & 0xffff0000u);
+                av[2 * e] += p * __uint_as_float(gu[e] << 16);  av[2 * e + 1] += p * __uint_as_float(gu[e] & 0xffff0000u);
             }
-            dkj[d] = f2bf(ak);
-            dvj[d] = f2bf(av);
         }
+        uint32_t ok_[4], ov[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            ok_[e] = (uint32_t)f2bf(ak[2 * e]) | ((uint32_t)f2bf(ak[2 * e + 1]) << 16);
+            ov[e] = (uint32_t)f2bf(av[2 * e]) | ((uint32_t)f2bf(av[2 * e + 1]) << 16);
+        }
+        const int64_t off = (int64_t)b * a.dkv_bs + (int64_t)j * a.dkv_rs + (int64_t)head * hd + c;
+        *reinterpret_cast<uint4*>(a.dk + off) = make_uint4(ok_[0], ok_[1], ok_[2], ok_[3]);
+        *reinterpret_cast<uint4*>(a.dv + off) = make_uint4(ov[0], ov[1], ov[2], ov[3]);
     }
 }
 
@@ -310,6 +345,11 @@ extern "C" int licv_attn_bwd_small(const licv_attn_args* x, const void* dout, vo
     LICV_CHECK_ARG(x->Sq > 0 && x->Sk > 0 && x->Sq * x->Sk <= 16384, "attn_bwd_small: Sq*Sk = %lld exceeds the short-sequence limit 16384",
                    (long long)(x->Sq * x->Sk));
     LICV_CHECK_ARG(x->mask_mode >= 0 && x->mask_mode <= 3, "attn_bwd_small: bad mask mode");
+    LICV_CHECK_ARG(x->head_dim % 8 == 0 && x->q_rs % 8 == 0 && x->kv_rs % 8 == 0 && x->q_bs % 8 == 0 && x->kv_bs % 8 == 0 &&
+                   dq_bs % 8 == 0 && dq_rs % 8 == 0 && dkv_bs % 8 == 0 && dkv_rs % 8 == 0,
+                   "attn_bwd_small: head_dim and strides must be multiples of 8 elements");
+    LICV_CHECK_ARG((((uintptr_t)x->q | (uintptr_t)x->k | (uintptr_t)x->v | (uintptr_t)dout | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15) == 0,
+                   "attn_bwd_small: pointers must be 16-byte aligned");
     LICV_CHECK_ARG(x->mask_mode != 3 || (x->img_mask && x->n_img > 0 && x->img_len > 0), "attn_bwd_small: image mask arguments missing");
     const int want = (dk && dv) ? 1 : 0;
     LICV_CHECK_ARG(!want || x->n_heads == x->n_kv_heads, "attn_bwd_small: dK/dV need n_kv_heads == n_heads");

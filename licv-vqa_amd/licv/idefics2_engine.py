@@ -57,6 +57,14 @@ class Idefics2Weights:
         self.patch_b = g(vp + "embeddings.patch_embedding.bias")
         self.pos = g(vp + "embeddings.position_embedding.weight")
         self.vit: List[_SigLayer] = []
+        # MLP width padded to a multiple of 64 (4304 -> 4352) with zero rows / bias / columns: gelu(0) = 0, so the result
+        # is unchanged and fc2's K dimension qualifies for the 256x256 LDS-DMA GEMM (K % 64 == 0)
+        ipad = (a.v_inter + 63) // 64 * 64
+
+        def pad_rows(t):
+            out = torch.zeros((ipad, *t.shape[1:]), dtype=t.dtype, device=t.device)
+            out[: t.shape[0]] = t
+            return out
         for i in range(a.v_layers):
             p = f"{vp}encoder.layers.{i}."
             qkv = ("q_proj", "k_proj", "v_proj")
@@ -64,7 +72,8 @@ class Idefics2Weights:
                                       cat(p + "self_attn.", qkv, "weight"), cat(p + "self_attn.", qkv, "bias"),
                                       g(p + "self_attn.out_proj.weight"), g(p + "self_attn.out_proj.bias"),
                                       g(p + "layer_norm2.weight"), g(p + "layer_norm2.bias"),
-                                      g(p + "mlp.fc1.weight"), g(p + "mlp.fc1.bias"), g(p + "mlp.fc2.weight"), g(p + "mlp.fc2.bias")))
+                                      pad_rows(g(p + "mlp.fc1.weight")), pad_rows(g(p + "mlp.fc1.bias")),
+                                      _pad_cols(g(p + "mlp.fc2.weight"), ipad), g(p + "mlp.fc2.bias")))
         self.post_ln_w, self.post_ln_b = g(vp + "post_layernorm.weight"), g(vp + "post_layernorm.bias")
         cp = "model.connector."
         mp = cp + "modality_projection."

@@ -276,7 +276,7 @@ def synth_idefics2_weights(arch: Idefics2Arch, seed: int = 426, dtype=torch.bflo
 
 def synth_vqa_batch_idefics2(arch: Idefics2Arch, batch: int, seq_len: int, n_images: int, img_h: int, img_w: int, seed: int = 426,
                              min_len: Optional[int] = None, dtype=torch.bfloat16, device="cpu", ragged: bool = True,
-                             drop_last_image_of_row0: bool = False) -> Dict[str, torch.Tensor]:
+                             drop_last_image_of_row0: bool = False, padding_side: str = "right") -> Dict[str, torch.Tensor]:
     """input_ids with ``r_latents`` `<image>` tokens per image (hf:idefics2/processing_idefics2.py:129), right padded;
     pixel_values (B, N, 3, H, W) with per-image valid regions given by pixel_attention_mask (ragged NaViT images:
     the valid height/width are multiples of the patch size); optionally one all-zero padding image."""
@@ -298,6 +298,9 @@ def synth_vqa_batch_idefics2(arch: Idefics2Arch, batch: int, seq_len: int, n_ima
             p += a.r_latents + 2
     att = (torch.arange(seq_len).unsqueeze(0) < lengths.unsqueeze(1)).long()
     ids = torch.where(att.bool(), ids, torch.full_like(ids, a.pad_token_id))
+    if padding_side == "left":
+        idx = (torch.arange(seq_len).unsqueeze(0) - (seq_len - lengths).unsqueeze(1)) % seq_len
+        ids, att = ids.gather(1, idx), att.gather(1, idx)
     pix = torch.randn(batch, n_images, 3, img_h, img_w, generator=g)
     pam = torch.zeros(batch, n_images, img_h, img_w, dtype=torch.bool)
     P = a.v_patch

@@ -1,9 +1,10 @@
 """Oracle (test infrastructure): hooked greedy / beam-search decoding on the CPU restatement.
 
 Search bookkeeping follows transformers 5.15 ``GenerationMixin._sample`` / ``_beam_search``
-(generation/utils.py:3077-3460) driven as ref:inference.py:300-321 does; the model is
-``oracle.idefics_ref.forward`` with its KV cache.  Pinned by tests/golden/g5_generate.npz (ids the reference
-wrapper + HF generate produced in fp32): ``tests/test_oracle_golden.py::test_g5_generate``.
+(generation/utils.py:3077-3460) driven as ref:inference.py:300-321 does.  Models: ``oracle.idefics_ref.forward`` with
+its KV cache (pinned by tests/golden/g5_generate.npz) and ``oracle.idefics2_ref.forward`` re-run over the whole prefix at
+every step with HF's generate-time position ids (generation/utils.py:751-773, :975-985; pinned by
+tests/golden/g8_generate_idefics2.npz).  Both fixtures hold ids the reference wrapper + HF generate produced in fp32.
 """
 from __future__ import annotations
 
@@ -12,33 +13,88 @@ from typing import Optional, Sequence
 import torch
 
 from . import idefics_ref as R
+from . import idefics2_ref as R2
+
+
+class _IdeficsModel:
+    def __init__(self, sd, arch, pixel_values, image_attention_mask, nb, hooks):
+        self.sd, self.arch, self.hooks = sd, arch, hooks
+        self.img = R.image_states_from_pixels(pixel_values, sd, arch).repeat_interleave(nb, 0)
+        self.iam = image_attention_mask.repeat_interleave(nb, 0)
+        self.cache = [None] * arch.num_layers
+
+    def _fwd(self, ids, am, iam):
+        return R.forward(self.sd, self.arch, ids, am, image_attention_mask=iam, image_states=self.img, kv_cache=self.cache,
+                         **self.hooks)[:, -1, :].float()
+
+    def prefill(self, ids, am):
+        return self._fwd(ids, am, self.iam)
+
+    def step(self, new_ids, am):
+        return self._fwd(new_ids, am, self.iam[:, -1:, :])
+
+    def reorder(self, flat):
+        for i in range(len(self.cache)):
+            self.cache[i] = (self.cache[i][0].index_select(0, flat), self.cache[i][1].index_select(0, flat))
+
+
+class _Idefics2Model:
+    """No cache: the whole prefix is re-run each step (tiny test models).  position ids as HF generate builds them:
+    cumsum(attention_mask)-1 with pads at 0 for the prompt, previous+1 for every generated token."""
+
+    def __init__(self, sd, arch, pixel_values, pixel_attention_mask, nb, hooks):
+        self.sd, self.arch, self.hooks, self.nb = sd, arch, hooks, nb
+        self.img = R2.image_features(pixel_values, pixel_attention_mask, sd, arch)          # (n_real*L, H), rows in batch order
+        self.ids = self.pos = None
+
+    def _fwd(self, am):
+        B = self.ids.shape[0] // self.nb
+        per_row = (self.ids[:: self.nb] == self.arch.image_token_id).sum(1)                # image rows per original question
+        chunks = torch.split(self.img, per_row.tolist())
+        img = torch.cat([c for c in chunks for _ in range(self.nb)]) if self.nb > 1 else self.img
+        return R2.forward(self.sd, self.arch, self.ids, am, image_hidden_states=img, position_ids=self.pos, **self.hooks)[:, -1, :].float()
+
+    def prefill(self, ids, am):
+        self.ids = ids
+        self.pos = (am.long().cumsum(-1) - 1).masked_fill(am == 0, 0)
+        return self._fwd(am)
+
+    def step(self, new_ids, am):
+        self.ids = torch.cat([self.ids, new_ids], 1)
+        self.pos = torch.cat([self.pos, self.pos[:, -1:] + 1], 1)
+        return self._fwd(am)
+
+    def reorder(self, flat):
+        self.ids, self.pos = self.ids.index_select(0, flat), self.pos.index_select(0, flat)
 
 
 @torch.no_grad()
 def generate(sd, arch, input_ids, attention_mask, pixel_values, image_attention_mask, icv=None,
-             hook_layers: Optional[Sequence[int]] = None, max_new_tokens=5, num_beams=1, length_penalty=1.0,
-             min_new_tokens=0, early_stopping=False, eos_token_id=None, pad_token_id=None):
+             hook_layers: Optional[Sequence[int]] = None, **kw):
+    hooks = dict(icv=icv, hook_layers=hook_layers) if icv is not None else {}
+    model = _IdeficsModel(sd, arch, pixel_values, image_attention_mask, kw.get("num_beams", 1), hooks)
+    return _decode(model, arch, input_ids, attention_mask, **kw)
+
+
+@torch.no_grad()
+def generate_idefics2(sd, arch, input_ids, attention_mask, pixel_values, pixel_attention_mask, icv=None,
+                      hook_layers: Optional[Sequence[int]] = None, **kw):
+    hooks = dict(icv=icv, hook_layers=hook_layers) if icv is not None else {}
+    model = _Idefics2Model(sd, arch, pixel_values, pixel_attention_mask, kw.get("num_beams", 1), hooks)
+    return _decode(model, arch, input_ids, attention_mask, **kw)
+
+
+def _decode(model, arch, input_ids, attention_mask, max_new_tokens=5, num_beams=1, length_penalty=1.0,
+            min_new_tokens=0, early_stopping=False, eos_token_id=None, pad_token_id=None):
     eos = arch.eos_token_id if eos_token_id is None else eos_token_id
     pad = arch.pad_token_id if pad_token_id is None else pad_token_id
     B, P = input_ids.shape
     nb = num_beams
     max_len = P + max_new_tokens
-    hooks = dict(icv=icv, hook_layers=hook_layers) if icv is not None else {}
-    image_states = R.image_states_from_pixels(pixel_values, sd, arch)
-
     # HF expands every input to B*nb rows before the prefill
-    ids = input_ids.repeat_interleave(nb, 0)
     am = attention_mask.repeat_interleave(nb, 0)
-    iam = image_attention_mask.repeat_interleave(nb, 0)
-    img = image_states.repeat_interleave(nb, 0)
-    cache = [None] * arch.num_layers
-
-    def step(new_ids, am, iam):
-        return R.forward(sd, arch, new_ids, am, image_attention_mask=iam, image_states=img, kv_cache=cache, **hooks)[:, -1, :].float()
-
-    logits = step(ids, am, iam)
+    logits = model.prefill(input_ids.repeat_interleave(nb, 0), am)
     V = logits.shape[-1]
-    last_iam = iam[:, -1:, :]
 
     if nb == 1:
         seq = torch.full((B, max_len), pad, dtype=torch.long)
@@ -55,7 +111,7 @@ def generate(sd, arch, input_ids, attention_mask, pixel_values, image_attention_
             if cur >= max_len or not bool(unfinished.any()):
                 break
             am = torch.cat([am, torch.ones((B, 1), dtype=am.dtype)], 1)
-            logits = step(nxt[:, None], am, last_iam)
+            logits = model.step(nxt[:, None], am)
         return seq[:, :cur]
 
     keep = 2 * nb
@@ -97,8 +153,7 @@ def generate(sd, arch, input_ids, attention_mask, pixel_values, image_attention_
         gen_len = gather(torch.cat([gen_len, torch.full_like(top_ix, cur + 1 - P)], 1), best)
         fin_scores = gather(m_sc, best)
         flat = (beam_src + torch.arange(B)[:, None] * nb).reshape(-1)
-        for i in range(len(cache)):
-            cache[i] = (cache[i][0].index_select(0, flat), cache[i][1].index_select(0, flat))
+        model.reorder(flat)
         cur += 1
         best_run = run_scores[:, :1] / (float(cur - P) ** length_penalty)
         worst = torch.where(is_fin, fin_scores.min(dim=1, keepdim=True)[0], torch.full_like(fin_scores, -1.0e9))
@@ -106,5 +161,5 @@ def generate(sd, arch, input_ids, attention_mask, pixel_values, image_attention_
         if not (bool(improve.any()) and not (bool(is_fin.all()) and early_stopping is True) and not bool(hits.all())):
             break
         am = torch.cat([am, torch.ones((B * nb, 1), dtype=am.dtype)], 1)
-        logits = step(running[:, :, cur - 1].reshape(B * nb, 1), am, last_iam)
+        logits = model.step(running[:, :, cur - 1].reshape(B * nb, 1), am)
     return finished[:, 0, : P + int(gen_len[:, 0].max())]

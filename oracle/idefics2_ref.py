@@ -147,7 +147,7 @@ def image_features(pixel_values, pixel_attention_mask, sd, arch):
 # ----------------------------------------------------------------------------- Mistral text model
 def forward(sd: Dict[str, torch.Tensor], arch, input_ids, attention_mask, pixel_values=None, pixel_attention_mask=None,
             icv: Optional[torch.Tensor] = None, hook_layers: Optional[Sequence[int]] = None, capture: Optional[dict] = None,
-            image_hidden_states: Optional[torch.Tensor] = None):
+            image_hidden_states: Optional[torch.Tensor] = None, position_ids: Optional[torch.Tensor] = None):
     """logits (B, S, V).  icv (1, n_hooked, H) fp32, already alpha-scaled; the hook edits the MLP output of text layer l."""
     tp = "model.text_model."
     B, S = input_ids.shape
@@ -161,9 +161,11 @@ def forward(sd: Dict[str, torch.Tensor], arch, input_ids, attention_mask, pixel_
     nh, nkv, hd = arch.num_heads, arch.num_kv_heads, arch.head_dim
     # rotary from position_ids = arange(S) (hf:mistral/modeling_mistral.py MistralModel.forward), fp32 maths, cast to the model dtype
     inv = 1.0 / (arch.rope_base ** (torch.arange(0, hd, 2, dtype=torch.float) / hd))
-    freqs = torch.outer(torch.arange(S, dtype=torch.float), inv)
+    if position_ids is None:                              # plain forward; generate passes HF's mask-derived ids (B, S)
+        position_ids = torch.arange(S)[None, :]
+    freqs = position_ids[..., None].to(torch.float) * inv
     emb = torch.cat((freqs, freqs), dim=-1)
-    cos, sin = emb.cos()[None, None].to(dtype), emb.sin()[None, None].to(dtype)
+    cos, sin = emb.cos()[:, None].to(dtype), emb.sin()[:, None].to(dtype)
     minv = torch.finfo(dtype).min
     allowed = torch.tril(torch.ones(S, S, dtype=torch.bool))[None, None] & attention_mask.bool()[:, None, None, :]
     causal = torch.where(allowed, torch.zeros((), dtype=dtype), minv)

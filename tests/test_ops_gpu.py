@@ -452,3 +452,49 @@ def test_adamw_matches_oracle():
         p, m, v = torch.cat([pa, pi]), torch.cat([ma, mi]), torch.cat([va, vi])
         ops().adamw_step_(dp, gr.to(DEV), dm, dv, n0, 1e-2, 1e-4, step)
         assert (dp.cpu() - p).abs().max() <= 1e-6
+
+
+@pytest.mark.parametrize("B,nh,Sq,Sk,hd,mode", [(2, 4, 32, 32, 128, 1), (2, 2, 24, 64, 128, 3), (1, 3, 16, 40, 16, 2), (2, 2, 20, 20, 64, 0)])
+def test_attention_bwd_small_matches_closed_form(B, nh, Sq, Sk, hd, mode):
+    """dQ/dK/dV of softmax attention for the student pass (short sequences), against the closed form evaluated in fp64
+    on the same bf16 inputs with the forward's bf16-rounded probabilities.  Bar: 2 bf16 ulp of each tensor's scale."""
+    from licv import ops
+    g = torch.Generator().manual_seed(5)
+    H = nh * hd
+    q = torch.randn(B, Sq, H, generator=g).bfloat16()
+    kv = torch.randn(B, Sk, 2 * H, generator=g).bfloat16()
+    do = torch.randn(B, Sq, H, generator=g).bfloat16()
+    key_valid = torch.ones(B, Sk, dtype=torch.int32)
+    key_valid[0, Sk - 3:] = 0
+    n_img, img_len = 4, Sk // 4
+    img_mask = (torch.rand(B, Sq, n_img, generator=g) > 0.4).int()
+    img_mask[:, :, 0] = 1
+    img_mask[0, 1] = 0                                           # a row that sees no image: zero probabilities, zero grads
+    allowed = torch.ones(B, Sq, Sk, dtype=torch.bool)
+    if mode == 1:
+        allowed = (torch.arange(Sk)[None, :] <= torch.arange(Sq)[:, None] + (Sk - Sq))[None] & key_valid.bool()[:, None, :]
+    elif mode == 2:
+        allowed = key_valid.bool()[:, None, :].expand(B, Sq, Sk)
+    elif mode == 3:
+        allowed = img_mask.bool().repeat_interleave(img_len, dim=-1)[:, :, :Sk]
+    qf, kf, vf, dof = (t.double().view(B, -1, nh, hd).transpose(1, 2) for t in (q, kv[..., :H], kv[..., H:], do))
+    s = (qf @ kf.transpose(-1, -2)) * hd ** -0.5
+    s = s.masked_fill(~allowed[:, None], float("-inf"))
+    p = torch.softmax(s, -1)
+    p = torch.where(allowed[:, None].any(-1, keepdim=True), p, torch.zeros_like(p)).nan_to_num(0.0)
+    p = p.float().bfloat16().double()
+    dp = dof @ vf.transpose(-1, -2)
+    ds = p * (dp - (p * dp).sum(-1, keepdim=True)) * hd ** -0.5
+    ref = [(ds @ kf), (ds.transpose(-1, -2) @ qf), (p.transpose(-1, -2) @ dof)]
+    ref = [t.transpose(1, 2).reshape(B, -1, H) for t in ref]
+    qd, kvd, dod = q.to(DEV), kv.to(DEV), do.to(DEV)
+    dq = torch.zeros_like(qd)
+    dkv = torch.zeros_like(kvd)
+    ops.attention_bwd_small(qd, kvd, kvd.view(-1)[H:], dod, B, Sq, Sk, nh, nh, hd, Sq * H, H, Sk * 2 * H, 2 * H, hd ** -0.5, mode,
+                            dq, Sq * H, H, dk=dkv, dv=dkv.view(-1)[H:], dkv_bs=Sk * 2 * H, dkv_rs=2 * H,
+                            key_valid=key_valid.to(DEV) if mode in (1, 2) else None,
+                            img_mask=img_mask.to(DEV) if mode == 3 else None, img_len=img_len if mode == 3 else 0)
+    got = [dq.cpu().double(), dkv[..., :H].cpu().double(), dkv[..., H:].cpu().double()]
+    for name, g_, r_ in zip(("dQ", "dK", "dV"), got, ref):
+        tol = 2 * 2.0 ** -8 * float(r_.abs().max())
+        assert float((g_ - r_).abs().max()) <= tol, f"{name}: {float((g_ - r_).abs().max()):.3e} > {tol:.3e}"

@@ -13,13 +13,20 @@ def short(name):
 
 def main(d, out, note=""):
     d = Path(d)
-    stats = next(d.rglob("*_kernel_stats.csv"))
-    rows = list(csv.DictReader(open(stats)))
     agg = {}
-    for r in rows:
-        k = short(r["Name"])
-        a = agg.setdefault(k, [0, 0.0, 1e30, 0.0])
-        a[0] += int(r["Calls"]); a[1] += float(r["TotalDurationNs"]); a[2] = min(a[2], float(r["MinNs"])); a[3] = max(a[3], float(r["MaxNs"]))
+    stats = next(d.rglob("*_kernel_stats.csv"), None)
+    if stats is not None:
+        for r in csv.DictReader(open(stats)):
+            k = short(r["Name"])
+            a = agg.setdefault(k, [0, 0.0, 1e30, 0.0])
+            a[0] += int(r["Calls"]); a[1] += float(r["TotalDurationNs"]); a[2] = min(a[2], float(r["MinNs"])); a[3] = max(a[3], float(r["MaxNs"]))
+    else:                                   # rocprofv3's default output: a rocpd SQLite database (view `kernels`)
+        import sqlite3
+        db = sqlite3.connect(str(next(d.rglob("*_results.db"))))
+        for name, n, tot, mn, mx in db.execute("select name, count(*), sum(duration), min(duration), max(duration) from kernels group by name"):
+            k = short(name)
+            a = agg.setdefault(k, [0, 0.0, 1e30, 0.0])
+            a[0] += n; a[1] += tot; a[2] = min(a[2], mn); a[3] = max(a[3], mx)
     tot = sum(a[1] for a in agg.values())
     lines = [f"# rocprofv3 --kernel-trace --stats summary\n", note, "",
              "| kernel | calls | total ms | avg us | min us | max us | % |", "|---|---:|---:|---:|---:|---:|---:|"]
