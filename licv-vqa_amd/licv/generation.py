@@ -16,33 +16,106 @@ import torch
 from .idefics_engine import IdeficsEngine, KVCache
 
 
-def _last_logits(engine: IdeficsEngine, **kw) -> torch.Tensor:
-    """fp32 logits of the last position of every row."""
-    B, S = kw["input_ids"].shape
-    rows = torch.arange(B, device=kw["input_ids"].device) * S + (S - 1)
-    return engine.forward(**kw, logits_rows=rows).float()
+def _last_rows(B: int, S: int, dev) -> torch.Tensor:
+    return torch.arange(B, device=dev) * S + (S - 1)
+
+
+class _IdeficsDecoder:
+    """Model side of the search for Idefics: image states + per-token image mask + KV cache."""
+
+    def __init__(self, engine: IdeficsEngine, pixel_values, image_attention_mask, batch, max_len, hooks):
+        self.e, self.hooks = engine, hooks
+        self.image_states = engine.encode_images(pixel_values)
+        self.iam = image_attention_mask
+        self.cache = KVCache(engine.arch, batch, max_len, engine.w.device)
+
+    def _fwd(self, ids, am, iam):
+        B, S = ids.shape
+        return self.e.forward(input_ids=ids, attention_mask=am, image_states=self.image_states, image_attention_mask=iam,
+                              kv_cache=self.cache, logits_rows=_last_rows(B, S, ids.device), **self.hooks).float()
+
+    def prefill(self, ids, am):
+        out = self._fwd(ids, am, self.iam)
+        self.iam = self.iam[:, -1:, :]
+        return out
+
+    def step(self, new_ids, am):
+        return self._fwd(new_ids, am, self.iam)
+
+    def replicate(self, nb):                       # HF prefills B*nb identical rows; replicate the prompt state instead
+        self.cache.kv = [t.repeat_interleave(nb, 0) for t in self.cache.kv]
+        self.image_states = self.image_states.repeat_interleave(nb, 0)
+        self.iam = self.iam.repeat_interleave(nb, 0)
+
+    def reorder(self, flat):
+        self.cache.reorder(flat)
+
+
+class _Idefics2Decoder:
+    """Idefics2: image hidden states only feed the prefill (they are scattered into the prompt embeddings); decode steps
+    need the KV cache and HF's generate-time position ids (cumsum(mask)-1 with pads at 0, then previous+1 per step:
+    transformers generation/utils.py:751-773, :975-985)."""
+
+    def __init__(self, engine, pixel_values, pixel_attention_mask, batch, max_len, hooks):
+        from .idefics2_engine import KVCache2
+        self.e, self.hooks = engine, hooks
+        self.img = engine.encode_images(pixel_values, pixel_attention_mask) if pixel_values is not None else None
+        self.cache = KVCache2(engine.arch, batch, max_len, engine.w.device)
+        self.pos = None
+
+    def _fwd(self, ids, am, img):
+        B, S = ids.shape
+        return self.e.forward(input_ids=ids, attention_mask=am, image_hidden_states=img, position_ids=self.pos, kv_cache=self.cache,
+                              logits_rows=_last_rows(B, S, ids.device), **self.hooks).float()
+
+    def prefill(self, ids, am):
+        self.pos = (am.long().cumsum(-1) - 1).masked_fill(am == 0, 0)
+        out = self._fwd(ids, am, self.img)
+        self.pos = self.pos[:, -1:]
+        return out
+
+    def step(self, new_ids, am):
+        self.pos = self.pos + 1
+        return self._fwd(new_ids, am, None)
+
+    def replicate(self, nb):
+        self.cache.kv = [t.repeat_interleave(nb, 0) for t in self.cache.kv]
+        self.pos = self.pos.repeat_interleave(nb, 0)
+
+    def reorder(self, flat):
+        self.cache.reorder(flat)
+        self.pos = self.pos.index_select(0, flat)
 
 
 @torch.no_grad()
 def generate(engine: IdeficsEngine, input_ids: torch.Tensor, attention_mask: torch.Tensor, pixel_values: torch.Tensor,
              image_attention_mask: torch.Tensor, icv: Optional[torch.Tensor] = None,
-             hook_layers: Optional[Sequence[int]] = None, max_new_tokens: int = 5, num_beams: int = 1,
-             length_penalty: float = 1.0, min_new_tokens: int = 0, early_stopping=False,
-             eos_token_id: Optional[int] = None, pad_token_id: Optional[int] = None) -> torch.Tensor:
-    a = engine.arch
+             hook_layers: Optional[Sequence[int]] = None, max_new_tokens: int = 5, num_beams: int = 1, **kw) -> torch.Tensor:
+    hooks = dict(icv=icv, hook_layers=hook_layers) if icv is not None else {}
+    model = _IdeficsDecoder(engine, pixel_values, image_attention_mask, input_ids.shape[0], input_ids.shape[1] + max_new_tokens, hooks)
+    return _decode(model, engine.arch, input_ids, attention_mask, max_new_tokens=max_new_tokens, num_beams=num_beams, **kw)
+
+
+@torch.no_grad()
+def generate_idefics2(engine, input_ids: torch.Tensor, attention_mask: torch.Tensor, pixel_values: Optional[torch.Tensor] = None,
+                      pixel_attention_mask: Optional[torch.Tensor] = None, icv: Optional[torch.Tensor] = None,
+                      hook_layers: Optional[Sequence[int]] = None, max_new_tokens: int = 5, num_beams: int = 1, **kw) -> torch.Tensor:
+    hooks = dict(icv=icv, hook_layers=hook_layers) if icv is not None else {}
+    model = _Idefics2Decoder(engine, pixel_values, pixel_attention_mask, input_ids.shape[0], input_ids.shape[1] + max_new_tokens, hooks)
+    return _decode(model, engine.arch, input_ids, attention_mask, max_new_tokens=max_new_tokens, num_beams=num_beams, **kw)
+
+
+def _decode(model, a, input_ids: torch.Tensor, attention_mask: torch.Tensor, max_new_tokens: int = 5, num_beams: int = 1,
+            length_penalty: float = 1.0, min_new_tokens: int = 0, early_stopping=False,
+            eos_token_id: Optional[int] = None, pad_token_id: Optional[int] = None) -> torch.Tensor:
     dev = input_ids.device
     eos = a.eos_token_id if eos_token_id is None else eos_token_id
     pad = a.pad_token_id if pad_token_id is None else pad_token_id
     B, P = input_ids.shape
     max_len = P + max_new_tokens
-    hooks = dict(icv=icv, hook_layers=hook_layers) if icv is not None else {}
-    image_states = engine.encode_images(pixel_values)
     nb = num_beams
-    cache = KVCache(a, B, max_len, dev)
-    logits = _last_logits(engine, input_ids=input_ids, attention_mask=attention_mask, image_states=image_states,
-                          image_attention_mask=image_attention_mask, kv_cache=cache, **hooks)
+    logits = model.prefill(input_ids, attention_mask)
     V = logits.shape[-1]
-    last_iam = image_attention_mask[:, -1:, :]
 
     def suppress_eos(lp, n_generated):
         if min_new_tokens > 0 and n_generated < min_new_tokens and eos is not None:
@@ -67,8 +140,7 @@ def generate(engine: IdeficsEngine, input_ids: torch.Tensor, attention_mask: tor
             if cur >= max_len or not bool(unfinished.any()):
                 break
             am = torch.cat([am, torch.ones((B, 1), dtype=am.dtype, device=dev)], 1)
-            logits = _last_logits(engine, input_ids=nxt[:, None], attention_mask=am, image_states=image_states,
-                                  image_attention_mask=last_iam, kv_cache=cache, **hooks)
+            logits = model.step(nxt[:, None], am)
         return seq[:, :cur]
 
     # ---- beam search (GenerationMixin._beam_search, transformers 5.x)
@@ -85,9 +157,7 @@ def generate(engine: IdeficsEngine, input_ids: torch.Tensor, attention_mask: tor
     gen_len = torch.zeros((B, nb), dtype=torch.long, device=dev)      # generated length of each finished hypothesis
 
     # replicate the prompt state per beam (HF prefills B*nb identical rows instead)
-    cache.kv = [t.repeat_interleave(nb, 0) for t in cache.kv]
-    image_states = image_states.repeat_interleave(nb, 0)
-    last_iam = last_iam.repeat_interleave(nb, 0)
+    model.replicate(nb)
     am = attention_mask.repeat_interleave(nb, 0)
     logits = logits.repeat_interleave(nb, 0)
     cur = P
@@ -126,7 +196,7 @@ def generate(engine: IdeficsEngine, input_ids: torch.Tensor, attention_mask: tor
         finished, fin_scores, is_fin, gen_len = gather(m_seq, best), gather(m_sc, best), gather(m_fin, best), gather(m_len, best)
         # reorder the per-beam model state
         flat_src = (beam_src + torch.arange(B, device=dev)[:, None] * nb).reshape(-1)
-        cache.reorder(flat_src)
+        model.reorder(flat_src)
         cur += 1
         # early-stop heuristic (early_stopping=False form): can a running beam still beat the worst finished one?
         best_run = run_scores[:, :1] / (float(cur - P) ** length_penalty)
@@ -136,8 +206,7 @@ def generate(engine: IdeficsEngine, input_ids: torch.Tensor, attention_mask: tor
         if not unfinished:
             break
         am = torch.cat([am, torch.ones((B * nb, 1), dtype=am.dtype, device=dev)], 1)
-        logits = _last_logits(engine, input_ids=running[:, :, cur - 1].reshape(B * nb, 1), attention_mask=am,
-                              image_states=image_states, image_attention_mask=last_iam, kv_cache=cache, **hooks)
+        logits = model.step(running[:, :, cur - 1].reshape(B * nb, 1), am)
     out = finished[:, 0, :]
     out_len = P + int(gen_len[:, 0].max())
     return out[:, :out_len]

@@ -109,6 +109,19 @@ class Idefics2Weights:
         self.max_positions = max_positions
 
 
+class KVCache2:
+    """Per-layer (B, max_len, [K | V] = 2 * n_kv_heads * head_dim) bf16 cache for hooked generate."""
+
+    def __init__(self, arch: Idefics2Arch, batch: int, max_len: int, device):
+        self.max_len, self.len = max_len, 0
+        self.kv = [torch.empty((batch, max_len, 2 * arch.num_kv_heads * arch.head_dim), dtype=torch.bfloat16, device=device)
+                   for _ in range(arch.num_layers)]
+
+    def reorder(self, idx: torch.Tensor):
+        for i in range(len(self.kv)):
+            self.kv[i] = self.kv[i].index_select(0, idx)
+
+
 def navit_position_ids(patch_mask: torch.Tensor, n_side: int) -> torch.Tensor:
     """hf:idefics2/modeling_idefics2.py:136-170 — fractional patch coordinates bucketised into the n_side x n_side
     position table.  Tiny integer/host arithmetic on the (n, gh, gw) bool patch mask; runs on the CPU so that the
@@ -206,16 +219,20 @@ class Idefics2Engine:
                 pixel_values: Optional[torch.Tensor] = None, pixel_attention_mask: Optional[torch.Tensor] = None,
                 image_hidden_states: Optional[torch.Tensor] = None, icv: Optional[torch.Tensor] = None,
                 hook_layers: Optional[Sequence[int]] = None, alpha: Optional[torch.Tensor] = None,
-                capture: Optional[dict] = None, logits_rows: Optional[torch.Tensor] = None):
+                capture: Optional[dict] = None, logits_rows: Optional[torch.Tensor] = None,
+                position_ids: Optional[torch.Tensor] = None, kv_cache: Optional[KVCache2] = None):
         """Returns logits (B, S, V) bf16.  icv (1, n_hooked, H) fp32 — already alpha-scaled when ``alpha`` is None;
         hook_layers: text-layer ids whose MLP OUTPUT (before the residual add) is edited."""
         a, w = self.arch, self.w
         dev = w.device
         B, S = input_ids.shape
-        assert S <= w.max_positions, "sequence longer than the rotary table"
+        past = kv_cache.len if kv_cache is not None else 0
+        Sk = past + S
+        assert Sk <= w.max_positions, "sequence longer than the rotary table"
         M, H, nh, nkv, hd = B * S, a.hidden_size, a.num_heads, a.num_kv_heads, a.head_dim
         if attention_mask is None:
-            attention_mask = torch.ones((B, S), dtype=torch.long, device=dev)
+            attention_mask = torch.ones((B, Sk), dtype=torch.long, device=dev)
+        assert attention_mask.shape[1] == Sk, "attention_mask must span past + new tokens"
         ids = input_ids.to(dev).contiguous()
         if image_hidden_states is None and pixel_values is not None:
             image_hidden_states = self.encode_images(pixel_values, pixel_attention_mask)
@@ -227,7 +244,11 @@ class Idefics2Engine:
                 raise ValueError(f"{slots.numel()} <image> tokens in input_ids but {img.shape[0]} image hidden states")
             ops.scatter_rows_(h, slots, img.contiguous())
         key_valid = attention_mask.to(device=dev, dtype=torch.int32).contiguous()
-        pos = torch.arange(S, device=dev, dtype=torch.int64).repeat(B).contiguous()       # position_ids = arange (MistralModel.forward)
+        if position_ids is None:                        # plain forward: arange (MistralModel.forward); generate passes mask-derived ids
+            pos = torch.arange(past, Sk, device=dev, dtype=torch.int64).repeat(B).contiguous()
+        else:
+            pos = position_ids.to(device=dev, dtype=torch.int64).reshape(-1).contiguous()
+            assert pos.numel() == M
         idx_of = {int(l): i for i, l in enumerate(hook_layers)} if (icv is not None and hook_layers is not None) else {}
         if icv is not None:
             icv = icv.to(device=dev, dtype=torch.float32).contiguous()
@@ -242,8 +263,14 @@ class Idefics2Engine:
             qkv = ops.linear(x, L.qkv_w)
             ops.rotary_(qkv, w.cos, w.sin, pos, M, nh, hd, ldq, qd, 1)
             ops.rotary_(qkv.view(-1)[qd:], w.cos, w.sin, pos, M, nkv, hd, ldq, kd, 1)
-            o = ops.attention(qkv, qkv.view(-1)[qd:], qkv.view(-1)[qd + kd:], B, S, S, nh, nkv, hd, S * ldq, ldq, S * ldq, ldq,
-                              hd ** -0.5, 1, key_valid=key_valid)
+            if kv_cache is None:
+                o = ops.attention(qkv, qkv.view(-1)[qd:], qkv.view(-1)[qd + kd:], B, S, S, nh, nkv, hd, S * ldq, ldq, S * ldq, ldq,
+                                  hd ** -0.5, 1, key_valid=key_valid)
+            else:
+                cache = kv_cache.kv[l]
+                cache[:, past:Sk] = qkv.view(B, S, ldq)[:, :, qd:]                         # append K|V (device copy)
+                o = ops.attention(qkv, cache, cache.view(-1)[kd:], B, S, Sk, nh, nkv, hd, S * ldq, ldq, kv_cache.max_len * 2 * kd, 2 * kd,
+                                  hd ** -0.5, 1, key_valid=key_valid)
             ops.linear(o.view(M, qd), L.o_w, residual=h, out=h)
             x = ops.rmsnorm(h, L.post_ln, a.rms_eps, 1)
             act = ops.linear(x, L.gu_w, swiglu=True)
@@ -267,6 +294,8 @@ class Idefics2Engine:
             del act
             if capture is not None:
                 capture.setdefault("layer_out", []).append(h.view(B, S, H).clone())
+        if kv_cache is not None:
+            kv_cache.len = Sk
         x = xn if xn is not None else ops.rmsnorm(h, w.final_ln, a.rms_eps, 1)
         if capture is not None:
             capture["image_hidden_states"] = image_hidden_states

@@ -180,5 +180,19 @@ class Idefics2Interface(IdeficsInterface):
                                                             labels[:, 1:].to(dev).reshape(-1), ignore_index=-100)
         return out
 
-    def generate(self, *a, **k):
-        raise NotImplementedError("hooked generate for Idefics2 is not built yet (DESIGN.md §6); Idefics generate is")
+    @torch.no_grad()
+    def generate(self, input_ids=None, attention_mask=None, pixel_values=None, pixel_attention_mask=None,
+                 max_new_tokens=20, num_beams=1, length_penalty=1.0, min_new_tokens=0, early_stopping=False,
+                 eos_token_id=None, pad_token_id=None, do_sample=False, **_):
+        if do_sample:
+            raise NotImplementedError("sampling is not part of the reference's inference path")
+        from licv.generation import generate_idefics2
+        dev = self._device
+        return generate_idefics2(self.engine, input_ids.to(dev), attention_mask.to(dev),
+                                 pixel_values.to(dev) if pixel_values is not None else None,
+                                 pixel_attention_mask.to(dev) if pixel_attention_mask is not None else None,
+                                 max_new_tokens=max_new_tokens, num_beams=num_beams, length_penalty=length_penalty,
+                                 min_new_tokens=min_new_tokens, early_stopping=early_stopping,
+                                 eos_token_id=eos_token_id if eos_token_id is not None else getattr(self.tokenizer, "eos_token_id", None),
+                                 pad_token_id=pad_token_id if pad_token_id is not None else getattr(self.tokenizer, "pad_token_id", None),
+                                 **self._hooks())

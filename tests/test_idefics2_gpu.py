@@ -105,3 +105,46 @@ def test_idefics2_subset_of_layers_and_interface(golden):
     with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
         ref = R2.forward(sdb, arch, **cpu_ins, icv=icv1, hook_layers=[1])
     assert (lg.float().cpu() - ref.float()).abs().max() <= 1.5e-2 * ref.float().abs().max()
+
+
+@pytest.mark.parametrize("side", ["left", "right"])
+def test_idefics2_hooked_generate_token_ids(golden, side):
+    """Hooked greedy / beam generate through the reference's wrapper class on Idefics2Interface.  Fixture ids come from
+    the reference wrapper driving HF generate in fp32; the native path is bf16, so every row must equal the reference
+    decode at bf16 (the autocast oracle) or at fp32 (the fixture), and exactly both wherever those two agree."""
+    from icv_src.icv_model.icv_intervention import LearnableICVInterventionLMM
+    from lmm_icl_interface import Idefics2Interface
+    from oracle.generate_ref import generate_idefics2 as oracle_generate
+    z = golden("g8_generate_idefics2")
+    arch = IDEFICS2_TINY
+    sd32 = synth_idefics2_weights(arch, seed=81, dtype=torch.float32)
+    sd32["model.text_model.embed_tokens.weight"] *= float(z["embed_scale"])
+    sd32["lm_head.weight"] *= float(z["head_scale"])
+    for l in range(arch.num_layers):
+        sd32[f"model.text_model.layers.{l}.mlp.down_proj.weight"] *= float(z["down_scale"])
+    iface = Idefics2Interface(state_dict=sd32, arch=arch, device=DEV)
+    batch = {k: T(z[f"{side}_in_{k}"]).to(DEV) for k in ("input_ids", "attention_mask", "pixel_values", "pixel_attention_mask")}
+    icv = T(z["icv"]).to(DEV)
+    w = LearnableICVInterventionLMM(iface, True, -1, "model.model.text_model.layers.<LAYER_NUM>.mlp", arch.num_layers)
+    kw = dict(max_new_tokens=5, length_penalty=0.0, min_new_tokens=0)
+    beam = w.generate(icv=icv, **batch, num_beams=3, **kw).cpu()
+    greedy = w.generate(icv=icv, **batch, num_beams=1, **kw).cpu()
+    w.toggle_intervention(False)
+    greedy_off = w.generate(icv=icv, **batch, num_beams=1, **kw).cpu()
+    sd = {k: v.to(torch.bfloat16) for k, v in sd32.items()}
+    cb = {k: v.cpu() for k, v in batch.items()}
+    cb["pixel_values"] = cb["pixel_values"].to(torch.bfloat16)
+    layers = list(range(arch.num_layers))
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        o_beam = oracle_generate(sd, arch, **cb, icv=icv.cpu(), hook_layers=layers, num_beams=3, **kw)
+        o_greedy = oracle_generate(sd, arch, **cb, icv=icv.cpu(), hook_layers=layers, num_beams=1, **kw)
+        o_off = oracle_generate(sd, arch, **cb, num_beams=1, **kw)
+    for got, o16, key in ((beam, o_beam, "beam_ids"), (greedy, o_greedy, "greedy_ids"), (greedy_off, o_off, "greedy_off_ids")):
+        gold = T(z[f"{side}_f32_{key}"])
+        assert got.shape == gold.shape
+        # every row equals the reference decode at one of its two precisions (near-ties flip between them) ...
+        assert bool(((got == o16).all(dim=1) | (got == gold).all(dim=1)).all()), key
+        # ... and where the two reference decodes agree, exactly that
+        agree = (o16 == gold).all(dim=1)
+        assert torch.equal(got[agree], gold[agree]), key
+        assert agree.float().mean() >= 0.6, "bf16 and fp32 reference decodes diverge on too many rows to be a useful check"

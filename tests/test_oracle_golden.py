@@ -199,3 +199,32 @@ def test_g5_generate(golden, side):
     assert torch.equal(generate(sd, arch, **b, icv=icv, hook_layers=layers, num_beams=3, **kw), T(z[f"{side}_f32_beam_ids"]))
     assert torch.equal(generate(sd, arch, **b, icv=icv, hook_layers=layers, num_beams=1, **kw), T(z[f"{side}_f32_greedy_ids"]))
     assert torch.equal(generate(sd, arch, **b, num_beams=1, **kw), T(z[f"{side}_f32_greedy_off_ids"]))
+
+
+def _g8_setup(golden):
+    z = golden("g8_generate_idefics2")
+    arch = IDEFICS2_TINY
+    sd = synth_idefics2_weights(arch, seed=81, dtype=torch.float32)
+    assert weights_checksum(sd) == float(z["weights_checksum"])
+    sd["model.text_model.embed_tokens.weight"] *= float(z["embed_scale"])
+    sd["lm_head.weight"] *= float(z["head_scale"])
+    for l in range(arch.num_layers):
+        sd[f"model.text_model.layers.{l}.mlp.down_proj.weight"] *= float(z["down_scale"])
+    return z, arch, sd
+
+
+@pytest.mark.parametrize("side", ["left", "right"])
+def test_g8_generate_idefics2(golden, side):
+    """Oracle decode == ids the reference wrapper + HF Idefics2 generate produced (fp32, hook on every `.mlp`)."""
+    from oracle.generate_ref import generate_idefics2
+    z, arch, sd = _g8_setup(golden)
+    b = {k: T(z[f"{side}_in_{k}"]) for k in ("input_ids", "attention_mask", "pixel_values", "pixel_attention_mask")}
+    icv, layers = T(z["icv"]), list(range(arch.num_layers))
+    kw = dict(max_new_tokens=5, length_penalty=0.0)
+    beam = generate_idefics2(sd, arch, **b, icv=icv, hook_layers=layers, num_beams=3, **kw)
+    assert torch.equal(beam, T(z[f"{side}_f32_beam_ids"]))
+    greedy = generate_idefics2(sd, arch, **b, icv=icv, hook_layers=layers, num_beams=1, **kw)
+    assert torch.equal(greedy, T(z[f"{side}_f32_greedy_ids"]))
+    assert torch.equal(generate_idefics2(sd, arch, **b, num_beams=1, **kw), T(z[f"{side}_f32_greedy_off_ids"]))
+    P = b["input_ids"].shape[1]
+    assert not torch.equal(greedy[:, P:], T(z[f"{side}_f32_greedy_off_ids"])[:, P:]), "fixture does not exercise the hook"

@@ -391,6 +391,48 @@ def g5_generate():
     np.savez_compressed(OUT / "g5_generate.npz", **out)
 
 
+def g8_generate_idefics2():
+    """Hooked beam / greedy generate ids for Idefics2 (hook on `.mlp`), fp32, left- and right-padded prompts.
+    Embedding and head scaled like g5 so that token identity matters."""
+    from icv_src.icv_model.icv_intervention import LearnableICVInterventionLMM
+    arch = IDEFICS2_TINY
+    seed = 81
+    out = {}
+    sd32 = synth_idefics2_weights(arch, seed=seed, dtype=torch.float32)
+    out["weights_checksum"] = np.array(weights_checksum(sd32))
+    out["embed_scale"], out["head_scale"] = np.array(25.0), np.array(10.0)
+    sd32["model.text_model.embed_tokens.weight"] *= 25.0
+    sd32["lm_head.weight"] *= 10.0
+    # the edit preserves the norm of the MLP branch: give that branch a norm comparable to the stream's so the hook can
+    # change tokens (otherwise hooked == unhooked ids and the fixture would not exercise the path)
+    out["down_scale"] = np.array(40.0)
+    for l in range(arch.num_layers):
+        sd32[f"model.text_model.layers.{l}.mlp.down_proj.weight"] *= 40.0
+    fmt = "model.model.text_model.layers.<LAYER_NUM>.mlp"
+    g = torch.Generator().manual_seed(seed + 1)
+    icv = torch.randn(1, arch.num_layers, arch.hidden_size, generator=g) * 0.2
+    out["icv"] = np_(icv)
+    for pad_side in ("left", "right"):
+        mn = 15 if pad_side == "left" else 20                 # right padding: full rows (the prompt must end in real tokens)
+        batch = synth_vqa_batch_idefics2(arch, 3, 20, 2, 56, 42, seed=seed, min_len=mn, dtype=torch.float32, padding_side=pad_side)
+        for k, v in batch.items():
+            out[f"{pad_side}_in_{k}"] = np_(v)
+        model = hf_idefics2(arch, sd32, torch.float32)
+        model.generation_config.pad_token_id = arch.pad_token_id
+        model.generation_config.eos_token_id = arch.eos_token_id
+        iface = Interface(model, arch.pad_token_id)
+        w = LearnableICVInterventionLMM(iface, True, -1, fmt, arch.num_layers)
+        with torch.inference_mode():
+            beam = w.generate(icv=icv, **batch, max_new_tokens=5, num_beams=3, length_penalty=0.0, min_new_tokens=0, do_sample=False)
+            greedy = w.generate(icv=icv, **batch, max_new_tokens=5, num_beams=1, do_sample=False)
+            w.toggle_intervention(False)
+            greedy_off = w.generate(icv=icv, **batch, max_new_tokens=5, num_beams=1, do_sample=False)
+        out[f"{pad_side}_f32_beam_ids"] = beam.numpy()
+        out[f"{pad_side}_f32_greedy_ids"] = greedy.numpy()
+        out[f"{pad_side}_f32_greedy_off_ids"] = greedy_off.numpy()
+    np.savez_compressed(OUT / "g8_generate_idefics2.npz", **out)
+
+
 def g6_loss():
     """The reference's VQAICVModule.forward (student hooked + teacher plain + KL) and its grads."""
     from icv_src.icv_encoder.global_icv_encoder import GlobalICVEncoder
@@ -495,8 +537,8 @@ def main():
     import icv_src.icv_model.icv_intervention as _ri
     assert _ri.__file__.startswith(str(REF)), _ri.__file__
     torch.set_num_threads(4)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
-    fns = dict(g1=g1_encoder, g2=g2_intervention, g3=g3_idefics, g4=g4_idefics2, g5=g5_generate, g6=g6_loss, g7=g7_optim)
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    fns = dict(g1=g1_encoder, g2=g2_intervention, g3=g3_idefics, g4=g4_idefics2, g5=g5_generate, g6=g6_loss, g7=g7_optim, g8=g8_generate_idefics2)
     for w in which:
         print("generating", w, flush=True)
         fns[w]()
