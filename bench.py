@@ -253,7 +253,7 @@ def main():
 
     # roofline of the dominant kernel (the bf16 MFMA GEMM) from the in-run event pairs
     def agg(kind):
-        ev = [(e0.elapsed_time(e1) * 1e-3, w) for k, e0, e1, w in prof if k == kind]
+        ev = [(e0.elapsed_time(e1) * 1e-3, w) for k, e0, e1, w, *_ in prof if k == kind]
         return sum(t for t, _ in ev), sum(w for _, w in ev), len(ev)
     tg, fl, ng = agg("gemm")
     ti, by, ni = agg("inject")

@@ -86,9 +86,9 @@ __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
 }
 
-// Phase B of the staged epilogue (see below): a compact run-time loop over the rows of the LDS image.
+// Phase B, generic form: every epilogue option under run-time flags (used only for combinations without a specialisation).
 template <int TM, int TN, int NWAVES, int EPL>            // EPL: output elements per lane (8 = bf16 out, 4 = fp32 out)
-__device__ __noinline__ void epilogue_rows(const GemmEpi& ep, void* __restrict__ C, int64_t ldc, int M, int N, int m0, int n0,
+__device__ __noinline__ void epilogue_rows_generic(const GemmEpi& ep, void* __restrict__ C, int64_t ldc, int M, int N, int m0, int n0,
                                            int wave, int lane, const char* smem) {
     constexpr int YS = TN * 2 + 16;
     constexpr bool F32 = (EPL == 4);
@@ -191,6 +191,186 @@ __device__ __noinline__ void epilogue_rows(const GemmEpi& ep, void* __restrict__
     }
 }
 
+
+// Phase B of the staged epilogue (see below): compact run-time loops over the rows of the LDS image, one specialisation
+// per epilogue family.  Measured on the all-flags-at-run-time form: 600 basic blocks / 22 KiB of code, 7.6 us per
+// 256 x 256 tile just to copy a finished bf16 image out (13 us with a residual, 19 us with GELU) on an otherwise idle
+// chip — per-element branches on ep.act / ep.swiglu / residual dtype the compiler cannot hoist out of a noinline
+// body.  Each family below is branch-free inside its row loop.
+struct RowMap {                 // lane -> (row group, first output column) for EPL consecutive output columns per lane
+    int lr, lcol, rstep, c, nv;
+};
+template <int TN, int NWAVES, int EPL>
+__device__ __forceinline__ RowMap row_map(int tcols, int oc0, int on, int wave, int lane, int& rb_first) {
+    const int lpr = tcols / EPL, rpi = 64 / lpr;
+    RowMap r;
+    r.lr = lane / lpr; r.lcol = (lane % lpr) * EPL; r.rstep = NWAVES * rpi; r.c = oc0 + r.lcol; r.nv = min(EPL, on - r.c);
+    rb_first = wave * rpi;
+    return r;
+}
+__device__ __forceinline__ void unpack8(const u32x4& v, float (&y)[8]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { y[2 * e] = __uint_as_float(v[e] << 16); y[2 * e + 1] = __uint_as_float(v[e] & 0xffff0000u); }
+}
+__device__ __forceinline__ u32x4 pack8(const float (&y)[8]) {
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (uint32_t)f2bf(y[2 * e]) | ((uint32_t)f2bf(y[2 * e + 1]) << 16);
+    return o;
+}
+__device__ __forceinline__ void store_bf16_row(bf16_t* cp, const float (&y)[8], int nv) {
+    if (nv == 8) *reinterpret_cast<u32x4*>(cp) = pack8(y);
+    else for (int e = 0; e < nv; ++e) cp[e] = f2bf(y[e]);
+}
+
+// no activation / residual / gate, bf16 out: the LDS image already holds the result -> 16-byte copies
+template <int TM, int TN, int NWAVES>
+__device__ __noinline__ void epilogue_rows_plain(void* __restrict__ C, int64_t ldc, int M, int N, int m0, int n0, int wave, int lane,
+                                                 const char* smem) {
+    constexpr int YS = TN * 2 + 16;
+    int rb0;
+    const RowMap r = row_map<TN, NWAVES, 8>(TN, n0, N, wave, lane, rb0);
+    if (r.c >= N) return;
+    for (int rb = rb0; rb < TM; rb += r.rstep) {
+        const int row = rb + r.lr, m = m0 + row;
+        if (m >= M) break;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(smem + row * YS + r.lcol * 2);
+        bf16_t* cp = reinterpret_cast<bf16_t*>(C) + (int64_t)m * ldc + r.c;
+        if (r.nv == 8) *reinterpret_cast<u32x4*>(cp) = v;
+        else for (int e = 0; e < r.nv; ++e) cp[e] = (bf16_t)(e & 1 ? v[e >> 1] >> 16 : v[e >> 1] & 0xffffu);
+    }
+}
+
+// activation only (ACT: 1 erf-GELU, 2 tanh-GELU, 3 ReLU), bf16 out
+template <int TM, int TN, int NWAVES, int ACT>
+__device__ __noinline__ void epilogue_rows_act(void* __restrict__ C, int64_t ldc, int M, int N, int m0, int n0, int wave, int lane,
+                                               const char* smem) {
+    constexpr int YS = TN * 2 + 16;
+    int rb0;
+    const RowMap r = row_map<TN, NWAVES, 8>(TN, n0, N, wave, lane, rb0);
+    if (r.c >= N) return;
+    for (int rb = rb0; rb < TM; rb += r.rstep) {
+        const int row = rb + r.lr, m = m0 + row;
+        if (m >= M) break;
+        float y[8];
+        unpack8(*reinterpret_cast<const u32x4*>(smem + row * YS + r.lcol * 2), y);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] = act_apply(y[e], ACT);
+        store_bf16_row(reinterpret_cast<bf16_t*>(C) + (int64_t)m * ldc + r.c, y, r.nv);
+    }
+}
+
+// SwiGLU pairing of the interleaved gate|up image, bf16 out (N/2 output columns)
+template <int TM, int TN, int NWAVES>
+__device__ __noinline__ void epilogue_rows_swiglu(void* __restrict__ C, int64_t ldc, int M, int N, int m0, int n0, int wave, int lane,
+                                                  const char* smem) {
+    constexpr int YS = TN * 2 + 16;
+    int rb0;
+    const RowMap r = row_map<TN, NWAVES, 8>(TN / 2, n0 >> 1, N >> 1, wave, lane, rb0);
+    if (r.c >= (N >> 1)) return;
+    const int pc = (r.lcol >> 4) * 32 + (r.lcol & 15);    // output cols lcol.. live in packed cols pc.. (gate) and pc+16.. (up)
+    for (int rb = rb0; rb < TM; rb += r.rstep) {
+        const int row = rb + r.lr, m = m0 + row;
+        if (m >= M) break;
+        const char* yrow = smem + row * YS;
+        float g[8], u[8], y[8];
+        unpack8(*reinterpret_cast<const u32x4*>(yrow + pc * 2), g);
+        unpack8(*reinterpret_cast<const u32x4*>(yrow + (pc + 16) * 2), u);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] = rbf(silu_fast(g[e])) * u[e];
+        store_bf16_row(reinterpret_cast<bf16_t*>(C) + (int64_t)m * ldc + r.c, y, r.nv);
+    }
+}
+
+// residual add (same dtype in and out: bf16 stream or fp32 stream), optional row gate and tanh-gate scale.  The residual
+// rows are fetched PF row-groups ahead: nothing else runs on the CU to hide their latency.
+template <int TM, int TN, int NWAVES, bool F32>
+__device__ __noinline__ void epilogue_rows_res(const GemmEpi& ep, void* __restrict__ C, int64_t ldc, int M, int N, int m0, int n0,
+                                               int wave, int lane, const char* smem) {
+    constexpr int YS = TN * 2 + 16;
+    constexpr int EPL = F32 ? 4 : 8, ESZ = F32 ? 4 : 2, PF = 4;
+    int rb0;
+    const RowMap r = row_map<TN, NWAVES, EPL>(TN, n0, N, wave, lane, rb0);
+    if (r.c >= N) return;
+    const bool full = r.nv == EPL;
+    const char* res = reinterpret_cast<const char*>(ep.residual);
+    const float* gate = ep.row_gate;
+    const bool scaled = ep.use_scale != 0;
+    const float scale = ep.scale;
+    for (; rb0 < TM; rb0 += PF * r.rstep) {
+        u32x4 rv[PF];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int m = m0 + rb0 + u * r.rstep + r.lr;
+            rv[u] = u32x4{0u, 0u, 0u, 0u};
+            if (rb0 + u * r.rstep < TM && m < M) {
+                const char* rp = res + ((int64_t)m * ep.ld_res + r.c) * ESZ;
+                if (full) rv[u] = *reinterpret_cast<const u32x4*>(rp);
+                else for (int e = 0; e < r.nv; ++e) {
+                    if (F32) rv[u][e] = reinterpret_cast<const uint32_t*>(rp)[e];
+                    else rv[u][e >> 1] |= (uint32_t)reinterpret_cast<const bf16_t*>(rp)[e] << ((e & 1) * 16);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int row = rb0 + u * r.rstep + r.lr, m = m0 + row;
+            if (rb0 + u * r.rstep >= TM || m >= M) break;
+            float y[EPL];
+            if (F32) {
+                const uint2 v = *reinterpret_cast<const uint2*>(smem + row * YS + r.lcol * 2);
+                y[0] = __uint_as_float(v.x << 16); y[1] = __uint_as_float(v.x & 0xffff0000u);
+                y[2] = __uint_as_float(v.y << 16); y[3] = __uint_as_float(v.y & 0xffff0000u);
+            } else {
+                float t[8];
+                unpack8(*reinterpret_cast<const u32x4*>(smem + row * YS + r.lcol * 2), t);
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) y[e] = t[e];
+            }
+            if (gate && gate[m] == 0.0f) {
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) y[e] = 0.0f;
+            }
+            if (scaled) {
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) y[e] = rbf(scale * y[e]);
+            }
+            if (F32) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = __uint_as_float(rv[u][e]) + y[e];
+                float* cp = reinterpret_cast<float*>(C) + (int64_t)m * ldc + r.c;
+                if (full) *reinterpret_cast<floatx4*>(cp) = floatx4{y[0], y[1], y[2], y[3]};
+                else for (int e = 0; e < r.nv; ++e) cp[e] = y[e];
+            } else {
+                float q[8];
+                unpack8(rv[u], q);
+                float z[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) z[e] = q[e] + y[e < EPL ? e : 0];
+                store_bf16_row(reinterpret_cast<bf16_t*>(C) + (int64_t)m * ldc + r.c, z, r.nv);
+            }
+        }
+    }
+}
+
+template <int TM, int TN, int NWAVES>
+__device__ __forceinline__ void epilogue_rows(const GemmEpi& ep, void* __restrict__ C, int64_t ldc, int M, int N, int m0, int n0,
+                                              int wave, int lane, const char* smem) {
+    const bool bf_out = ep.out_dtype == LICV_BF16;
+    const bool simple = !ep.residual && !ep.row_gate && !ep.use_scale && bf_out;
+    if (simple && ep.swiglu)                 epilogue_rows_swiglu<TM, TN, NWAVES>(C, ldc, M, N, m0, n0, wave, lane, smem);
+    else if (simple && ep.act == 0)          epilogue_rows_plain<TM, TN, NWAVES>(C, ldc, M, N, m0, n0, wave, lane, smem);
+    else if (simple && ep.act == 1)          epilogue_rows_act<TM, TN, NWAVES, 1>(C, ldc, M, N, m0, n0, wave, lane, smem);
+    else if (simple && ep.act == 2)          epilogue_rows_act<TM, TN, NWAVES, 2>(C, ldc, M, N, m0, n0, wave, lane, smem);
+    else if (simple && ep.act == 3)          epilogue_rows_act<TM, TN, NWAVES, 3>(C, ldc, M, N, m0, n0, wave, lane, smem);
+    else if (ep.residual && !ep.swiglu && !ep.act && ep.residual_dtype == LICV_BF16 && bf_out)
+        epilogue_rows_res<TM, TN, NWAVES, false>(ep, C, ldc, M, N, m0, n0, wave, lane, smem);
+    else if (ep.residual && !ep.swiglu && !ep.act && ep.residual_dtype == LICV_F32 && !bf_out)
+        epilogue_rows_res<TM, TN, NWAVES, true>(ep, C, ldc, M, N, m0, n0, wave, lane, smem);
+    else if (bf_out) epilogue_rows_generic<TM, TN, NWAVES, 8>(ep, C, ldc, M, N, m0, n0, wave, lane, smem);
+    else             epilogue_rows_generic<TM, TN, NWAVES, 4>(ep, C, ldc, M, N, m0, n0, wave, lane, smem);
+}
+
 // ------------------------------------------------------------------------------------------------
 // LDS-staged epilogue (all kernels).  Two measured problems of storing straight from the accumulator layout:
 // 32-byte row fragments per store, and — far worse — code size: the element-wise epilogue (erf / tanh / exp
@@ -202,9 +382,18 @@ __device__ __noinline__ void epilogue_rows(const GemmEpi& ep, void* __restrict__
 // SwiGLU pairing / row gate / tanh-gate scale / residual on the bf16 values (exactly where the unfused torch
 // ops would round) and stores bf16 or fp32.
 // ------------------------------------------------------------------------------------------------
+// timing-only instrumentation (scratch/gemm_phases.py): when set, wave 0 of every pingpong workgroup records
+// wall_clock64() at [0] start, [1] stage 0 published, [2] main loop done, [3] output image in LDS, [4] end
+__device__ long long* g_dbg_ts = nullptr;
+extern "C" int licv_gemm_debug_timestamps(void* dev_buffer) {
+    long long* p = (long long*)dev_buffer;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_ts), &p, sizeof(p)) == hipSuccess ? LICV_OK : LICV_E_HIP;
+}
+
 template <int TM, int TN, int NWAVES, int MT, int NT>
 __device__ __forceinline__ void epilogue_staged(floatx4 (&acc)[MT][NT], const GemmEpi& ep, void* __restrict__ C, int64_t ldc,
-                                                int M, int N, int m0, int n0, int wrow0, int wcol0, int wave, int lane, char* smem) {
+                                                int M, int N, int m0, int n0, int wrow0, int wcol0, int wave, int lane, char* smem,
+                                                long long* ts = nullptr) {
     constexpr int YS = TN * 2 + 16;                       // LDS row stride in bytes
     // ---- phase A: registers -> LDS image of y0 = bf16(acc + bias)
     {
@@ -229,9 +418,9 @@ __device__ __forceinline__ void epilogue_staged(floatx4 (&acc)[MT][NT], const Ge
         });
     }
     __syncthreads();
+    if (ts) ts[3] = wall_clock64();
     // ---- phase B: compact loop over rows; lane -> 8 (bf16 out) or 4 (fp32 out) consecutive OUTPUT columns
-    if (ep.out_dtype == LICV_F32) epilogue_rows<TM, TN, NWAVES, 4>(ep, C, ldc, M, N, m0, n0, wave, lane, smem);
-    else                          epilogue_rows<TM, TN, NWAVES, 8>(ep, C, ldc, M, N, m0, n0, wave, lane, smem);
+    epilogue_rows<TM, TN, NWAVES>(ep, C, ldc, M, N, m0, n0, wave, lane, smem);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -428,11 +617,13 @@ void gemm_bf16_ring_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* _
 template <int ABL>     // ABL 1: timing-only build without the epilogue
 __global__ __launch_bounds__(512, 2)
 void gemm_bf16_pingpong_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw,
-                          void* __restrict__ C, int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n, GemmEpi ep) {
+                          void* __restrict__ C, int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n, GemmEpi ep, int stagger_ticks) {
     extern __shared__ __attribute__((aligned(16))) char smem[];     // [5 stages][A 16 KiB | W 16 KiB]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;                         // group = wm: waves 0-3 lead, 4-7 trail
+    long long* ts = (g_dbg_ts && tid == 0) ? g_dbg_ts + (int64_t)blockIdx.x * 8 : nullptr;
+    if (ts) ts[0] = wall_clock64();
     int tm, tn;
     tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn);
     const int m0 = tm * 256, n0 = tn * 256;
@@ -445,16 +636,35 @@ void gemm_bf16_pingpong_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_
         const int chunk = (lane & 3) ^ (((row >> 2) & 1) << 1);
         srcA[i] = A + (int64_t)min(m0 + row, M - 1) * lda + chunk * 8;
         srcW[i] = W + (int64_t)min(n0 + row, N - 1) * ldw + chunk * 8;
+        if (ABL == 2) {       // WRONG RESULTS, timing only: a piece = 8 rows x 128 B instead of 16 rows x 64 B
+            const int r2 = wave * 32 + i * 16 + (lane >> 3), c2 = lane & 7;
+            srcA[i] = A + (int64_t)min(m0 + r2, M - 9) * lda + c2 * 8;
+            srcW[i] = W + (int64_t)min(n0 + r2, N - 9) * ldw + c2 * 8;
+        }
+    }
+    const int ns = K / 32;                                   // >= 4 (host guarantees K >= 128)
+    // First-round start stagger by XCD (blockIdx % 8): every tile of a GEMM takes the same time, so all 256 CUs reach
+    // their epilogue together and its HBM traffic arrives as one burst (measured 3.5-3.9 TB/s for 8-38 us per tile while
+    // the MFMA pipes idle).  Offsetting the XCDs by an eighth of a tile time each spreads the bursts; later workgroups
+    // inherit the offset from the workgroup they replace.
+    if (stagger_ticks > 0 && blockIdx.x < 256) {
+        const long long t_start = wall_clock64(), wait = (long long)(blockIdx.x & 7) * stagger_ticks;
+        while (wall_clock64() - t_start < wait) __builtin_amdgcn_s_sleep(16);
     }
     auto issue = [&](int s) {
         char* sa = smem + (s % RING_STAGES) * RING_STAGE_BYTES + wave * 32 * 64;
         char* sw = sa + 16384;
-        const int64_t koff = (int64_t)s * 32;
+        int64_t koff = (int64_t)s * 32;
+        int64_t koffw = koff;
+        if (ABL == 2) {            // timing-only: whole 128-B lines, each fetched once: odd stages take the other 8 rows
+            koff = (int64_t)(s >> 1) * 64 + (int64_t)(s & 1) * 8 * lda;
+            koffw = (int64_t)(s >> 1) * 64 + (int64_t)(s & 1) * 8 * ldw;
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + koff),
                                              (__attribute__((address_space(3))) void*)(sa + i * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[i] + koff),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[i] + koffw),
                                              (__attribute__((address_space(3))) void*)(sw + i * 1024), 16, 0, 0);
         }
     };
@@ -465,13 +675,13 @@ void gemm_bf16_pingpong_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-    const int ns = K / 32;                                   // >= 4 (host guarantees K >= 128)
     const int fo = ring_off(lane & 15, lane >> 4);
     bf16x8 fa[8], fw[4];
 
     issue(0); issue(1); issue(2); issue(3);
     wait_vmcnt(12);                                          // my pieces of stage 0 have landed
     __builtin_amdgcn_s_barrier();                            // stage 0 published
+    if (ts) ts[1] = wall_clock64();
     if (wm == 1) __builtin_amdgcn_s_barrier();               // trailing group starts half a stage later
 
     for (int s = 0; s < ns; ++s) {
@@ -502,6 +712,7 @@ void gemm_bf16_pingpong_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_
         __builtin_amdgcn_s_barrier();
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();               // leading group: match the barrier count
+    if (ts) ts[2] = wall_clock64();
     if (ABL == 1) {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -509,7 +720,8 @@ void gemm_bf16_pingpong_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_
             for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(acc[i][j]));
         return;
     }
-    epilogue_staged<256, 256, 8, 8, 4>(acc, ep, C, ldc, M, N, m0, n0, wm * 128, wn * 64, wave, lane, smem);
+    epilogue_staged<256, 256, 8, 8, 4>(acc, ep, C, ldc, M, N, m0, n0, wm * 128, wn * 64, wave, lane, smem, ts);
+    if (ts) ts[4] = wall_clock64();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -641,8 +853,7 @@ void gemm_bf16_persist_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t
                     });
                 }
                 __syncthreads();
-                if (ep.out_dtype == LICV_F32) epilogue_rows<64, 256, 8, 4>(ep, C, ldc, M, N, cm0 + 64 * P, cn0, wave, lane, ybase);
-                else                          epilogue_rows<64, 256, 8, 8>(ep, C, ldc, M, N, cm0 + 64 * P, cn0, wave, lane, ybase);
+                epilogue_rows<64, 256, 8>(ep, C, ldc, M, N, cm0 + 64 * P, cn0, wave, lane, ybase);
                 __syncthreads();
             });
         }
@@ -745,7 +956,10 @@ void pack_gate_up_k(const bf16_t* __restrict__ g, const bf16_t* __restrict__ u, 
 }
 
 static int g_stagger = 0;        // per-XCD start stagger of the persistent kernel: measured slower, off
-extern "C" int licv_gemm_stagger(int on) { g_stagger = on; return LICV_OK; }
+// pingpong kernel, per-XCD first-round start stagger in percent of the estimated tile time / 8 (0 = off).
+// (A rotated K traversal per tile was also tried: -3 ... -25 %, lockstep K sweeps are what makes L2 sharing work.)
+static int g_pp_stagger = 0;
+extern "C" int licv_gemm_stagger(int on) { if (on >= 100) g_pp_stagger = on - 100; else g_stagger = on; return LICV_OK; }
 static int g_num_cus = 256;        // persistent grid size (queried once)
 static int g_force_kernel = 0;     // 0 auto, 1 tile128, 2 tile256 (tests / A-B timing)
 extern "C" int licv_gemm_select(int which) { g_force_kernel = which; return LICV_OK; }
@@ -778,6 +992,7 @@ extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
         hipFuncSetAttribute((const void*)gemm_bf16_persist_k, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
         hipFuncSetAttribute((const void*)gemm_bf16_pingpong_k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
         hipFuncSetAttribute((const void*)gemm_bf16_pingpong_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
+        hipFuncSetAttribute((const void*)gemm_bf16_pingpong_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
         hipFuncSetAttribute((const void*)gemm_bf16_ring_k, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
         hipFuncSetAttribute((const void*)gemm_bf16_tile256_k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, T256_LDS);
         hipFuncSetAttribute((const void*)gemm_bf16_tile256_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, T256_LDS);
@@ -790,6 +1005,9 @@ extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
     if (use256) {
         const int tiles_m = (int)((M + 255) / 256), tiles_n = (int)((N + 255) / 256);
         const dim3 grid(tiles_m * tiles_n), block(512);
+        // estimated tile time: K/32 stages x ~0.85 us + ~15 us of fill/epilogue, in 10 ns ticks; an eighth of it per XCD
+        const int pp_ticks = (g_pp_stagger > 0 && tiles_m * tiles_n >= 2 * g_num_cus)
+                                 ? (int)(((K / 32) * 85 + 1500) / 8 * g_pp_stagger / 100) : 0;
 #define LAUNCH256(ABL) gemm_bf16_tile256_k<ABL><<<grid, block, T256_LDS, (hipStream_t)stream>>>( \
             (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep)
         if (g_force_kernel == 3) LAUNCH256(1); else if (g_force_kernel == 4) LAUNCH256(2);
@@ -798,10 +1016,13 @@ extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
                 (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep);
         else if (g_force_kernel == 7 && K >= 128)
             gemm_bf16_pingpong_k<1><<<grid, block, RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>(
-                (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep);
+                (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, pp_ticks);
+        else if (g_force_kernel == 10 && K >= 128)       // timing-only ablation: full-line DMA pieces (wrong results)
+            gemm_bf16_pingpong_k<2><<<grid, block, RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>(
+                (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, pp_ticks);
         else if (g_force_kernel == 6 && K >= 128)
             gemm_bf16_pingpong_k<0><<<grid, block, RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>(
-                (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep);
+                (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, pp_ticks);
         else if (g_force_kernel == 8 && K >= 128)        // measured: no faster than relaunching (kept for A/B)
             gemm_bf16_persist_k<<<dim3(min(tiles_m * tiles_n, g_num_cus)), block, RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>(
                 (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep,
@@ -809,7 +1030,7 @@ extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
                 (tiles_m * tiles_n > g_num_cus && g_stagger) ? (int)((K / 32) * 1300 / 8 / 4096 + 1) : 0);
         else if ((g_force_kernel == 0 || g_force_kernel == 9) && K >= 128)
             gemm_bf16_pingpong_k<0><<<grid, block, RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>(
-                (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep);
+                (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, pp_ticks);
         else LAUNCH256(0);
 #undef LAUNCH256
     } else {

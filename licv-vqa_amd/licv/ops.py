@@ -20,14 +20,14 @@ def set_profiler(store):
     _prof = store
 
 
-def _timed(kind, work, fn):
+def _timed(kind, work, fn, label=None):
     if _prof is None:
         return fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     r = fn()
     e1.record()
-    _prof.append((kind, e0, e1, work))
+    _prof.append((kind, e0, e1, work) if label is None else (kind, e0, e1, work, label))
     return r
 
 
@@ -187,7 +187,7 @@ def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     ep.scale = 0.0 if scale is None else float(scale)
     ep.out_dtype = _dt(out)
     _timed("gemm", 2.0 * M * N * K, lambda: check(_lib.lib().licv_gemm_bf16(
-        _p(a), lda, _p(w), K, _p(out), ldc, M, N, K, C.byref(ep), _stream(a))))
+        _p(a), lda, _p(w), K, _p(out), ldc, M, N, K, C.byref(ep), _stream(a))), label=(M, N, K))
     return out if ret is None else ret
 
 
