@@ -288,7 +288,7 @@ template <int TM, int TN, int NWAVES, bool F32>
 __device__ __noinline__ void epilogue_rows_res(const GemmEpi& ep, void* __restrict__ C, int64_t ldc, int M, int N, int m0, int n0,
                                                int wave, int lane, const char* smem) {
     constexpr int YS = TN * 2 + 16;
-    constexpr int EPL = F32 ? 4 : 8, ESZ = F32 ? 4 : 2, PF = 4;
+    constexpr int EPL = F32 ? 4 : 8, ESZ = F32 ? 4 : 2, PF = F32 ? 8 : 4;
     int rb0;
     const RowMap r = row_map<TN, NWAVES, EPL>(TN, n0, N, wave, lane, rb0);
     if (r.c >= N) return;
@@ -297,25 +297,32 @@ __device__ __noinline__ void epilogue_rows_res(const GemmEpi& ep, void* __restri
     const float* gate = ep.row_gate;
     const bool scaled = ep.use_scale != 0;
     const float scale = ep.scale;
-    for (; rb0 < TM; rb0 += PF * r.rstep) {
-        u32x4 rv[PF];
-#pragma unroll
-        for (int u = 0; u < PF; ++u) {
-            const int m = m0 + rb0 + u * r.rstep + r.lr;
-            rv[u] = u32x4{0u, 0u, 0u, 0u};
-            if (rb0 + u * r.rstep < TM && m < M) {
-                const char* rp = res + ((int64_t)m * ep.ld_res + r.c) * ESZ;
-                if (full) rv[u] = *reinterpret_cast<const u32x4*>(rp);
-                else for (int e = 0; e < r.nv; ++e) {
-                    if (F32) rv[u][e] = reinterpret_cast<const uint32_t*>(rp)[e];
-                    else rv[u][e >> 1] |= (uint32_t)reinterpret_cast<const bf16_t*>(rp)[e] << ((e & 1) * 16);
-                }
+    // rolling prefetch: PF row-groups of residual in flight; slot u is refilled for group g + PF right after group g
+    // has consumed it
+    auto fetch = [&](int rb) -> u32x4 {
+        u32x4 v = u32x4{0u, 0u, 0u, 0u};
+        const int m = m0 + rb + r.lr;
+        if (rb < TM && m < M) {
+            const char* rp = res + ((int64_t)m * ep.ld_res + r.c) * ESZ;
+            if (full) v = *reinterpret_cast<const u32x4*>(rp);
+            else for (int e = 0; e < r.nv; ++e) {
+                if (F32) v[e] = reinterpret_cast<const uint32_t*>(rp)[e];
+                else v[e >> 1] |= (uint32_t)reinterpret_cast<const bf16_t*>(rp)[e] << ((e & 1) * 16);
             }
         }
+        return v;
+    };
+    u32x4 rv[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) rv[u] = fetch(rb0 + u * r.rstep);
+    for (; rb0 < TM; rb0 += PF * r.rstep) {
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
-            const int row = rb0 + u * r.rstep + r.lr, m = m0 + row;
-            if (rb0 + u * r.rstep >= TM || m >= M) break;
+            const int rb = rb0 + u * r.rstep;
+            const int row = rb + r.lr, m = m0 + row;
+            if (rb >= TM || m >= M) break;
+            const u32x4 rcur = rv[u];
+            rv[u] = fetch(rb + PF * r.rstep);
             float y[EPL];
             if (F32) {
                 const uint2 v = *reinterpret_cast<const uint2*>(smem + row * YS + r.lcol * 2);
@@ -337,13 +344,13 @@ __device__ __noinline__ void epilogue_rows_res(const GemmEpi& ep, void* __restri
             }
             if (F32) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) y[e] = __uint_as_float(rv[u][e]) + y[e];
+                for (int e = 0; e < 4; ++e) y[e] = __uint_as_float(rcur[e]) + y[e];
                 float* cp = reinterpret_cast<float*>(C) + (int64_t)m * ldc + r.c;
                 if (full) *reinterpret_cast<floatx4*>(cp) = floatx4{y[0], y[1], y[2], y[3]};
                 else for (int e = 0; e < r.nv; ++e) cp[e] = y[e];
             } else {
                 float q[8];
-                unpack8(rv[u], q);
+                unpack8(rcur, q);
                 float z[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) z[e] = q[e] + y[e < EPL ? e : 0];
@@ -393,7 +400,7 @@ extern "C" int licv_gemm_debug_timestamps(void* dev_buffer) {
 template <int TM, int TN, int NWAVES, int MT, int NT>
 __device__ __forceinline__ void epilogue_staged(floatx4 (&acc)[MT][NT], const GemmEpi& ep, void* __restrict__ C, int64_t ldc,
                                                 int M, int N, int m0, int n0, int wrow0, int wcol0, int wave, int lane, char* smem,
-                                                long long* ts = nullptr) {
+                                                long long* ts = nullptr, const float (*bias_pre)[4] = nullptr) {
     constexpr int YS = TN * 2 + 16;                       // LDS row stride in bytes
     // ---- phase A: registers -> LDS image of y0 = bf16(acc + bias)
     {
@@ -404,7 +411,8 @@ __device__ __forceinline__ void epilogue_staged(floatx4 (&acc)[MT][NT], const Ge
             constexpr int j = decltype(jc)::value;
             const int ncol = n0 + wcol0 + j * 16 + cq;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) bv[j][r] = (ep.bias && ncol + r < N) ? bf2f(ep.bias[ncol + r]) : 0.f;
+            for (int r = 0; r < 4; ++r)
+                bv[j][r] = bias_pre ? bias_pre[j][r] : ((ep.bias && ncol + r < N) ? bf2f(ep.bias[ncol + r]) : 0.f);
         });
         static_for<0, MT>([&](auto ic) {
             constexpr int i = decltype(ic)::value;

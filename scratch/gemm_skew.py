@@ -14,7 +14,7 @@ for (M,N,K,epi) in cases:
         'swiglu':dict(swiglu=True),'none':{}}[epi]
     line=f"{M:6d} {N:6d} {K:6d} {epi:7s}"
     base=None
-    for skew in (0,50,100,150,0):
+    for skew in (0,30,60,100,0):
         lib.licv_gemm_stagger(100+skew)
         for _ in range(2): o=ops.linear(a,w,**kw)
         torch.cuda.synchronize()
