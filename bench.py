@@ -36,12 +36,12 @@ WORKLOADS = {
     # backward + [every 2nd micro-batch] all-reduce + clipped AdamW.  (arch, B, S_teacher, n_img_teacher, min_len)
     "idefics9b_train_bs8": ("idefics-9b", 8, 800, 33, 720),
     "idefics_mid_train_debug": ("idefics-mid", 4, 96, 5, 80),
-    # BASELINE configs[3]: Idefics2-8B-base 1-shot (1 demo + query image per question, 64 <image> tokens each),
-    # COCO-sized 480x640 images (processor keeps them: shortest edge >= 378, longest <= 980), hook on all 32 MLP branches
-    "idefics2_8b_1shot_bs8": ("idefics2-8b", 8, 192, 2, 176),
+    # BASELINE configs[3] = SURVEY.md §8d shape "I2": Idefics2-8B-base 1-shot, B=8, 2 images per question at 378x504
+    # (27x36 = 972 patches), 64 <image> tokens each, S = 2*66 + 40 = 172, hook on all 32 MLP branches
+    "idefics2_8b_1shot_bs8": ("idefics2-8b", 8, 172, 2, 160),
     "idefics2_mid_debug": ("idefics2-mid", 2, 40, 2, 30),
 }
-IDEFICS2_IMAGE = {"idefics2-8b": (480, 640), "idefics2-mid": (84, 70)}
+IDEFICS2_IMAGE = {"idefics2-8b": (378, 504), "idefics2-mid": (84, 70)}
 
 
 def _host_cores() -> int:
@@ -121,16 +121,17 @@ def cpu_baseline_idefics2(arch, S, n_img, hw):
                 best = min(best, time.perf_counter() - t0)
         tm[tag] = best
 
+    # per-layer costs from 4-layer differences (a single layer is a few tens of ms here: below the run-to-run noise)
     run(arch.with_(v_layers=1, r_depth=1, num_layers=1), "1v+1p+1t")
-    run(arch.with_(v_layers=2, r_depth=1, num_layers=1), "2v+1p+1t")
-    run(arch.with_(v_layers=1, r_depth=2, num_layers=1), "1v+2p+1t")
-    run(arch.with_(v_layers=1, r_depth=1, num_layers=2), "1v+1p+2t")
+    run(arch.with_(v_layers=5, r_depth=1, num_layers=1), "5v+1p+1t")
+    run(arch.with_(v_layers=1, r_depth=3, num_layers=1), "1v+3p+1t")
+    run(arch.with_(v_layers=1, r_depth=1, num_layers=5), "1v+1p+5t")
     base = tm["1v+1p+1t"]
-    dv, dp, dt_ = (max(tm[k] - base, 0.0) for k in ("2v+1p+1t", "1v+2p+1t", "1v+1p+2t"))
+    dv, dp, dt_ = max(tm["5v+1p+1t"] - base, 0.0) / 4, max(tm["1v+3p+1t"] - base, 0.0) / 2, max(tm["1v+1p+5t"] - base, 0.0) / 4
     full = base + dv * (arch.v_layers - 1) + dp * (arch.r_depth - 1) + dt_ * (arch.num_layers - 1)
     return {"value": 1.0 / full, "unit": "questions/s", "cores": cores, "kind": "port",
-            "sample": (f"1 question (S={S}, {n_img} images {hw[0]}x{hw[1]}) through the CPU oracle (bf16 autocast) truncated to 1-2 layers "
-                       f"of each kind: " + ", ".join(f"{k} {v:.2f}s" for k, v in tm.items())
+            "sample": (f"1 question (S={S}, {n_img} images {hw[0]}x{hw[1]}) through the CPU oracle (bf16 autocast) truncated to 1-5 layers "
+                       f"of each kind (min of 3 runs each): " + ", ".join(f"{k} {v:.2f}s" for k, v in tm.items())
                        + f"; per-layer differences scaled to {arch.v_layers} SigLIP / {arch.r_depth} perceiver / {arch.num_layers} text layers "
                        f"= {full:.1f} s/question")}
 

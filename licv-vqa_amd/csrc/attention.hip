@@ -128,7 +128,7 @@ __device__ __forceinline__ void attn_tile_n(int nst, const char* kt, const char*
 }
 
 template <int DPK, int DPV, int QT, int NW>   // NW waves per workgroup, QT 16-query sub-tiles per wave: QT*NW*16 queries
-__global__ __launch_bounds__(NW * 64, (NW == 8 ? 2 : 2))
+__global__ __launch_bounds__(NW * 64, (DPK == 128 ? 3 : 2))      // 3 waves per SIMD (<= 168 VGPRs) measured 7-10 % faster at head_dim 128; 4 spills
 void attn_fwd_k(AttnP a) {
     constexpr int NTHR = NW * 64;
     constexpr int SLAB = NW * 16;               // queries per slab (one sub-tile of every wave)
@@ -467,7 +467,9 @@ extern "C" int licv_attn_fwd(const licv_attn_args* x, void* stream) {
     p.scale = x->scale; p.mask_mode = x->mask_mode; p.key_valid = x->key_valid;
     p.img_mask = x->img_mask; p.n_img = (int)x->n_img; p.img_len = (int)x->img_len;
     const int hd0 = (int)x->head_dim;
-    if (x->mask_mode == 0 && !g_attn_force_tiled && hd0 > 32 && hd0 <= 96 && x->Sk >= 128 && x->Sq >= 64) {
+    // (Sq >= 128: with fewer than 8 sub-tiles of 16 queries some of the 8 waves idle — the perceiver's 64 latents run
+    //  1.4x faster on the tiled kernel)
+    if (x->mask_mode == 0 && !g_attn_force_tiled && hd0 > 32 && hd0 <= 96 && x->Sk >= 128 && x->Sq >= 128) {
         // resident-K/V variant: needs skp * (KSTR + VSTR) bytes of LDS
         const int skp = (int)((x->Sk + 15) / 16 * 16) + 16;       // the transposing V read touches one 16-row group past the last real one
         const int dpk = hd0 <= 64 ? 64 : 96, dpv = hd0 <= 64 ? 64 : (hd0 <= 80 ? 80 : 96);
@@ -488,10 +490,14 @@ extern "C" int licv_attn_fwd(const licv_attn_args* x, void* stream) {
             return LICV_OK;
         }
     }
-    // 64 queries per 4-wave workgroup.  (The kernel also instantiates as QT slabs x NW waves per workgroup so a
-    // K/V tile is fetched once for up to QT*NW*16 queries; measured SLOWER here — 745 vs 590 us on the ViT shape —
-    // because this kernel is bound by softmax VALU + LDS, not by K/V loads, and fewer, fatter workgroups overlap
-    // MFMA and VALU phases less.)
+    // 64 queries per 4-wave workgroup.  Measured and dropped (this kernel is bound by each wave's dependency chain
+    // QK -> max -> exp2 -> PV and lives on waves in flight, not on loads or the LDS port):
+    //  (i)   several 64-query slabs per workgroup sharing each fetched K/V tile: 745 vs 590 us on the ViT shape;
+    //  (ii)  two 16-query sub-tiles per wave sharing every K / V^T fragment read (half the LDS bytes per flop):
+    //        1.4-3x slower (240+ VGPRs, spills, half the waves in flight);
+    //  (iii) issuing S^T(t+1) before softmax(t) with double-buffered tiles: 1.3-1.4x slower (184 VGPRs -> 2 waves per
+    //        SIMD instead of 3, twice the LDS);
+    //  (iv)  v_permlane16/32_swap instead of ds_bpermute for the 4-lane reductions: neutral.
     const int hd = p.hd;
     const int64_t qtiles = (x->Sq + ATT_QB - 1) / ATT_QB;
     const int64_t nblk = x->B * x->n_heads * qtiles;
