@@ -257,6 +257,13 @@ def main():
         ev = [(e0.elapsed_time(e1) * 1e-3, w) for k, e0, e1, w, *_ in prof if k == kind]
         return sum(t for t, _ in ev), sum(w for _, w in ev), len(ev)
     tg, fl, ng = agg("gemm")
+    # algorithmic bytes of the GEMM launches (operands once + output once; bf16 operands, output/residual in their dtype is
+    # not known here -> bf16 output assumed, a lower bound) and the PMC-measured L2<->fabric traffic of the same launches
+    gemm_alg = sum(2.0 * (m * k + n * k + m * n) for rec in prof if rec[0] == "gemm" and len(rec) > 4 for (m, n, k) in [rec[4]])
+    pmc = None
+    pmc_file = ROOT / "profiles" / "r01_pmc_headline_gemm.json"
+    if args.workload == "idefics9b_32shot_bs8" and not args.no_hooks and pmc_file.exists():
+        pmc = json.loads(pmc_file.read_text())
     ti, by, ni = agg("inject")
     fq = {"total": fl / max(args.steps, 1) / B} if is2 else flops_per_question(arch, S, n_img)   # Idefics2: GEMM flops as launched
     res = {
@@ -271,7 +278,12 @@ def main():
                    **({"train": "teacher fwd + student fwd/bwd + KL; accumulate 2; 1 all-reduce of 131 105 fp32 + AdamW per optimiser step"} if training else {})},
         "roofline": {"bound": "mfma", "kernel": "gemm_bf16_pingpong_k (256x256 LDS-DMA ring; small shapes: gemm_bf16_tile128_k)", "achieved": fl / tg / 1e12 if tg else None,
                      "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": (fl / tg / 1e12) / PEAK_BF16_TFLOPS if tg else None,
-                     "traffic": None, "launches_per_step": ng // max(args.steps, 1),
+                     "traffic": pmc["traffic_bytes_per_launch"] / 1e9 if pmc else None, "traffic_unit": "GB per launch (average over the step's GEMM launches)",
+                     "traffic_source": ("profiles/r01_pmc_headline_gemm.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command; "
+                                        "FETCH_SIZE x2 (gfx950), counts Infinity-Cache hits as well as HBM") if pmc else None,
+                     "algorithmic_GB_per_launch": gemm_alg / ng / 1e9 if ng else None,
+                     "achieved_GBps_algorithmic": gemm_alg / tg / 1e9 if tg else None,
+                     "launches_per_step": ng // max(args.steps, 1),
                      "avg_launch_us": 1e6 * tg / ng if ng else None, "gemm_share_of_step": tg / elapsed if elapsed else None},
         "whole_path": {"tflop_per_question": fq["total"] / 1e12, "achieved_tflops_per_gpu": fq["total"] * B * args.steps / elapsed / 1e12,
                        "frac_of_mfma_peak": fq["total"] * B * args.steps / elapsed / 1e12 / PEAK_BF16_TFLOPS},

@@ -68,11 +68,10 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {       // bytes with
 
 // XCD-aware tile id: blocks b and b+8 share an XCD; give each XCD a contiguous run of tiles, and order tiles
 // in groups of GROUP tile-rows (M fastest inside a group) so a run is a compact 2-D patch of the tile grid.
-__device__ __forceinline__ void tile_coords(int bid, int tiles_m, int tiles_n, int& tm, int& tn) {
+__device__ __forceinline__ void tile_coords(int bid, int tiles_m, int tiles_n, int& tm, int& tn, int GROUP = 8) {
     const int nwg = tiles_m * tiles_n;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    const int GROUP = 8;
     const int per_group = GROUP * tiles_n;
     const int first_m = (bid / per_group) * GROUP;
     const int gsize = min(tiles_m - first_m, GROUP);
@@ -625,7 +624,7 @@ void gemm_bf16_ring_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* _
 template <int ABL>     // ABL 1: timing-only build without the epilogue
 __global__ __launch_bounds__(512, 2)
 void gemm_bf16_pingpong_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw,
-                          void* __restrict__ C, int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n, GemmEpi ep, int stagger_ticks) {
+                          void* __restrict__ C, int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n, GemmEpi ep, int stagger_ticks, int group) {
     extern __shared__ __attribute__((aligned(16))) char smem[];     // [5 stages][A 16 KiB | W 16 KiB]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -633,7 +632,7 @@ void gemm_bf16_pingpong_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_
     long long* ts = (g_dbg_ts && tid == 0) ? g_dbg_ts + (int64_t)blockIdx.x * 8 : nullptr;
     if (ts) ts[0] = wall_clock64();
     int tm, tn;
-    tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn);
+    tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn, group);
     const int m0 = tm * 256, n0 = tn * 256;
 
     const bf16_t* srcA[2];
@@ -967,7 +966,11 @@ static int g_stagger = 0;        // per-XCD start stagger of the persistent kern
 // pingpong kernel, per-XCD first-round start stagger in percent of the estimated tile time / 8 (0 = off).
 // (A rotated K traversal per tile was also tried: -3 ... -25 %, lockstep K sweeps are what makes L2 sharing work.)
 static int g_pp_stagger = 0;
-extern "C" int licv_gemm_stagger(int on) { if (on >= 100) g_pp_stagger = on - 100; else g_stagger = on; return LICV_OK; }
+static int g_pp_group = 0;      // experiment knob: tile-rows per XCD patch group (0 = heuristic)
+extern "C" int licv_gemm_stagger(int on) {
+    if (on >= 200) g_pp_group = on - 200; else if (on >= 100) g_pp_stagger = on - 100; else g_stagger = on;
+    return LICV_OK;
+}
 static int g_num_cus = 256;        // persistent grid size (queried once)
 static int g_force_kernel = 0;     // 0 auto, 1 tile128, 2 tile256 (tests / A-B timing)
 extern "C" int licv_gemm_select(int which) { g_force_kernel = which; return LICV_OK; }
@@ -1014,6 +1017,7 @@ extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
         const int tiles_m = (int)((M + 255) / 256), tiles_n = (int)((N + 255) / 256);
         const dim3 grid(tiles_m * tiles_n), block(512);
         // estimated tile time: K/32 stages x ~0.85 us + ~15 us of fill/epilogue, in 10 ns ticks; an eighth of it per XCD
+        const int pp_group = g_pp_group > 0 ? g_pp_group : 8;
         const int pp_ticks = (g_pp_stagger > 0 && tiles_m * tiles_n >= 2 * g_num_cus)
                                  ? (int)(((K / 32) * 85 + 1500) / 8 * g_pp_stagger / 100) : 0;
 #define LAUNCH256(ABL) gemm_bf16_tile256_k<ABL><<<grid, block, T256_LDS, (hipStream_t)stream>>>( \
@@ -1024,13 +1028,13 @@ extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
                 (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep);
         else if (g_force_kernel == 7 && K >= 128)
             gemm_bf16_pingpong_k<1><<<grid, block, RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>(
-                (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, pp_ticks);
+                (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, pp_ticks, pp_group);
         else if (g_force_kernel == 10 && K >= 128)       // timing-only ablation: full-line DMA pieces (wrong results)
             gemm_bf16_pingpong_k<2><<<grid, block, RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>(
-                (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, pp_ticks);
+                (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, pp_ticks, pp_group);
         else if (g_force_kernel == 6 && K >= 128)
             gemm_bf16_pingpong_k<0><<<grid, block, RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>(
-                (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, pp_ticks);
+                (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, pp_ticks, pp_group);
         else if (g_force_kernel == 8 && K >= 128)        // measured: no faster than relaunching (kept for A/B)
             gemm_bf16_persist_k<<<dim3(min(tiles_m * tiles_n, g_num_cus)), block, RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>(
                 (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep,
@@ -1038,7 +1042,7 @@ extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
                 (tiles_m * tiles_n > g_num_cus && g_stagger) ? (int)((K / 32) * 1300 / 8 / 4096 + 1) : 0);
         else if ((g_force_kernel == 0 || g_force_kernel == 9) && K >= 128)
             gemm_bf16_pingpong_k<0><<<grid, block, RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>(
-                (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, pp_ticks);
+                (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, pp_ticks, pp_group);
         else LAUNCH256(0);
 #undef LAUNCH256
     } else {
