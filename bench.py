@@ -171,6 +171,8 @@ def main():
     ap.add_argument("--workload", default="idefics9b_32shot_bs8", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hooks", action="store_true", help="teacher shape: same forward with the intervention off")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; default).  'gloo' only to rehearse the multi-rank code path "
+                    "on a box with fewer GPUs than ranks (ranks then share devices: timings are meaningless)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -178,12 +180,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     assert torch.cuda.is_available(), "bench.py needs a GPU: the L-ICV hot path has no CPU fallback"
+    if args.dist_backend != "nccl":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend)
 
     from licv import ops
     from licv.config import idefics_arch
