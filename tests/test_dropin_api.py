@@ -76,3 +76,61 @@ def test_checkpoint_dict_layout_round_trip(tmp_path):
     args = dict(back["lmm_args"])
     w = LearnableICVInterventionLMM(torch.nn.Identity(), True, args["intervention_layer"], args["layer_format"], args["total_layers"])
     assert w.intervention_layer_names == [f"model.model.layers.{i}" for i in range(3)]
+
+
+def test_collator_contract_masks_select_the_same_answer_tokens():
+    """ref:icv_src/icv_datamodule.py:73-130 contract with a whitespace tokenizer: student and teacher masks built from
+    query_x_length / in_context_length (ref:icv_src/icv_module.py:136-148) pick the same answer tokens (+EOS) in both rows."""
+    import types
+    import torch
+    from icv_src.icv_datamodule import VQAICVDataModule, collator_data
+
+    PAD, BOS, EOS = 0, 1, 2
+    vocab = {}
+
+    class Proc:
+        input_ids_field = "input_ids"
+        tokenizer = types.SimpleNamespace(pad_token_id=PAD, bos_token_id=BOS, eos_token_id=EOS, padding_side="left")
+
+        def prepare_input(self, batch_prompts, padding=True, truncation=None, add_eos_token=False, return_tensors="pt", **kw):
+            rows = []
+            for prompt in batch_prompts:                      # prompt = list of items; strings are text, anything else an image
+                ids = [BOS]
+                for item in prompt:
+                    if isinstance(item, str):
+                        ids += [vocab.setdefault(w, 10 + len(vocab)) for w in item.split()]
+                    else:
+                        ids += [5, 6, 5]                      # <fake><image><fake>
+                if add_eos_token:
+                    ids.append(EOS)
+                rows.append(ids)
+            n = max(map(len, rows))
+            ids = torch.tensor([r + [PAD] * (n - len(r)) for r in rows])
+            return {"input_ids": ids, "attention_mask": (ids != PAD).long()}
+
+    img = object()
+    samples = [
+        dict(ice_prompt=[img, "Question: what colour ? Short answer: red", img, "Question: how many ? Short answer: two"],
+             query_prompt=[img, "Question: what animal is this ? Short answer: a small dog"],
+             query_x=[img, "Question: what animal is this ? Short answer:"]),
+        dict(ice_prompt=[img, "Question: is it day ? Short answer: yes"],
+             query_prompt=[img, "Question: where ? Short answer: beach"],
+             query_x=[img, "Question: where ? Short answer:"]),
+    ]
+    proc = Proc()
+    dm = VQAICVDataModule(types.SimpleNamespace(bs=2, num_workers=0), None, proc)
+    assert proc.tokenizer.padding_side == "right"
+    out = dm.collator_data(samples)
+    assert set(out) == {"query_inputs", "inputs", "in_context_length", "query_x_length"}
+    assert torch.equal(out["in_context_length"], collator_data(samples, proc)["in_context_length"])
+    stu, tea = out["query_inputs"]["input_ids"], out["inputs"]["input_ids"]
+
+    def mask(ids, length):
+        steps = torch.arange(ids.shape[1]).unsqueeze(0).expand(ids.shape[0], -1)
+        return (steps >= length.unsqueeze(1)) & (ids != PAD)
+
+    ms, mt = mask(stu, out["query_x_length"]), mask(tea, out["in_context_length"])
+    assert torch.equal(ms.sum(1), mt.sum(1)) and int(ms.sum()) > 0
+    for b in range(2):
+        assert torch.equal(stu[b][ms[b]], tea[b][mt[b]])            # the answer tokens and the EOS, identical in both rows
+    assert stu[0][ms[0]].tolist()[-1] == EOS and len(stu[0][ms[0]]) == 4   # "a small dog" + EOS
