@@ -105,7 +105,8 @@ class ICVTrainer:
         scale = min(1.0, self.clip / (norm + 1e-6)) if self.clip else 1.0
         lam = m.lr_lambda(self.opt_step, self.spec["warm_steps"], self.spec["total_steps"])
         self.opt_step += 1
-        n0 = self.n_alpha if enc.alpha.requires_grad else 0
+        # the module's parameters are the source of truth (a checkpoint may have been loaded after this trainer was built)
+        self.flat_p.copy_(torch.cat([enc.alpha.detach().reshape(-1), enc.icv.detach().reshape(-1)]))
         lr_alpha = self.spec["alpha_lr"] * lam if enc.alpha.requires_grad else 0.0
         ops.adamw_step_(self.flat_p, g, self.flat_m, self.flat_v, self.n_alpha, lr_alpha, self.spec["icv_lr"] * lam, self.opt_step,
                         weight_decay=self.spec["weight_decay"] , grad_scale=scale)

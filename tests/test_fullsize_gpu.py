@@ -1,0 +1,158 @@
+"""Idefics-9B at BASELINE.json's full headline size (B=8 questions, S=800, 33 images each, hooks on all 32 layers):
+no oracle finishes at this size in seconds, so parity is carried by size-independent properties of the path.
+
+  P1  the hook preserves every token's L2 norm at every hooked layer (ref:icv_src/icv_model/icv_intervention.py:75-79) and
+      promotes the stream to fp32 from the first hooked layer on;
+  P2  a question's logits do not depend on its batch neighbours: row b of the batch of 8 == the same row run alone, bit for bit
+      (same kernels, same per-element summation order);
+  P3  two runs of the same batch are bit-identical (no atomics, no run-to-run scheduling dependence);
+  P4  the fused hook+RMSNorm kernel == hook kernel followed by the RMSNorm kernel, bit for bit, at full width;
+  P5  alpha folded into the kernel == alpha pre-multiplied on the host (ref:icv_src/icv_module.py:89-92) within 2 bf16 ulp of
+      the logit scale, identical argmax on >= 99.9 % of the positions;
+  P6  hooks off leaves the stream bf16 and the logits differ from the hooked ones (the hook is live).
+"""
+import pytest
+import torch
+
+from licv.config import IDEFICS_9B
+from licv.synthetic import synth_icv, synth_idefics_weights, synth_vqa_batch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def full():
+    from licv.idefics_engine import IdeficsEngine, IdeficsWeights
+    arch = IDEFICS_9B
+    sd = synth_idefics_weights(arch, seed=426, dtype=torch.bfloat16, device=DEV)
+    w = IdeficsWeights(sd, arch, DEV)
+    del sd
+    torch.cuda.empty_cache()
+    batch = synth_vqa_batch(arch, 8, 800, 33, seed=426, min_len=720, dtype=torch.bfloat16, device=DEV)
+    icv, alpha = synth_icv(arch.num_layers, arch.hidden_size, seed=426, alpha=0.1, device=DEV)
+    return arch, IdeficsEngine(w, fuse_hook_norm=True), IdeficsEngine(w, fuse_hook_norm=False), batch, icv, alpha
+
+
+def test_fullsize_hook_properties(full):
+    arch, eng, eng_unfused, batch, icv, alpha = full
+    layers = list(range(arch.num_layers))
+    img = eng.encode_images(batch["pixel_values"])
+    ins = dict(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], image_states=img,
+               image_attention_mask=batch["image_attention_mask"])
+    scaled = alpha.unsqueeze(-1) * icv
+
+    cap = {}
+    lg = eng.forward(**ins, icv=scaled, hook_layers=layers, capture=cap).clone()
+    valid = batch["attention_mask"].bool()
+    # P1
+    for l in (0, 1, 15, 31):
+        a, b = cap["raw"][l].float().norm(dim=-1), cap["edited"][l].float().norm(dim=-1)
+        assert cap["edited"][l].dtype == torch.float32
+        assert bool(((a - b).abs() <= 4e-3 * a)[valid].all()), f"layer {l}: token norm not preserved"
+        assert (cap["edited"][l].float() - cap["raw"][l].float()).abs().max() > 0
+    assert cap["raw"][0].dtype == torch.bfloat16 and cap["raw"][1].dtype == torch.float32
+    del cap
+    # P3
+    lg2 = eng.forward(**ins, icv=scaled, hook_layers=layers)
+    assert torch.equal(lg, lg2)
+    # P4
+    lg3 = eng_unfused.forward(**ins, icv=scaled, hook_layers=layers)
+    assert torch.equal(lg, lg3)
+    # P5
+    lg4 = eng.forward(**ins, icv=icv, alpha=alpha, hook_layers=layers)
+    scale = float(lg.float().abs().max())
+    assert float((lg4.float() - lg.float()).abs().max()) <= 2 * 2.0 ** -8 * scale
+    same = (lg4.float().argmax(-1) == lg.float().argmax(-1))[valid].float().mean()
+    assert float(same) >= 0.999
+    # P6
+    cap = {}
+    off = eng.forward(**ins, capture=cap)
+    assert cap["edited"][-1].dtype == torch.bfloat16
+    assert float((off.float() - lg.float()).abs().max()) > 1e-2 * scale
+    del cap
+    # P2: rows 0 and 5 alone (their own images, masks and lengths)
+    for b in (0, 5):
+        one = {k: v[b:b + 1].contiguous() for k, v in batch.items()}
+        alone = eng.forward(**one, icv=scaled, hook_layers=layers)
+        assert torch.equal(alone[0], lg[b]), f"row {b} depends on its batch neighbours"
+
+
+def test_fullsize_idefics2_properties():
+    """Idefics2-8B at SURVEY shape I2 (B=8, 2 images 378x504 per question, S=172, hooks on all 32 MLP branches): P2-P5."""
+    from licv.config import IDEFICS2_8B
+    from licv.idefics2_engine import Idefics2Engine, Idefics2Weights
+    from licv.synthetic import synth_idefics2_weights, synth_vqa_batch_idefics2
+    arch = IDEFICS2_8B
+    sd = synth_idefics2_weights(arch, seed=426, dtype=torch.bfloat16, device=DEV)
+    w = Idefics2Weights(sd, arch, DEV)
+    del sd
+    torch.cuda.empty_cache()
+    eng, eng_unfused = Idefics2Engine(w, True), Idefics2Engine(w, False)
+    batch = synth_vqa_batch_idefics2(arch, 8, 172, 2, 378, 504, seed=426, min_len=160, dtype=torch.bfloat16, device=DEV, ragged=True)
+    icv, alpha = synth_icv(arch.num_layers, arch.hidden_size, seed=426, alpha=0.1, device=DEV)
+    layers = list(range(arch.num_layers))
+    scaled = alpha.unsqueeze(-1) * icv
+    cap = {}
+    lg = eng.forward(**batch, icv=scaled, hook_layers=layers, capture=cap).clone()
+    assert all(t.dtype == torch.float32 for t in cap["layer_out"]) and cap["mlp_raw"][0].dtype == torch.bfloat16
+    del cap
+    assert torch.equal(lg, eng.forward(**batch, icv=scaled, hook_layers=layers))                      # P3
+    assert torch.equal(lg, eng_unfused.forward(**batch, icv=scaled, hook_layers=layers))              # P4
+    lg4 = eng.forward(**batch, icv=icv, alpha=alpha, hook_layers=layers)                              # P5
+    scale = float(lg.float().abs().max())
+    assert float((lg4.float() - lg.float()).abs().max()) <= 2 * 2.0 ** -8 * scale
+    off = eng.forward(**batch)
+    assert float((off.float() - lg.float()).abs().max()) > 1e-3 * scale                              # P6
+    for b in (0, 3):                                                                                  # P2
+        one = {k: v[b:b + 1].contiguous() for k, v in batch.items()}
+        alone = eng.forward(**one, icv=scaled, hook_layers=layers)
+        assert torch.equal(alone[0], lg[b]), f"row {b} depends on its batch neighbours"
+
+
+def test_fullsize_training_micro_batch_properties(full):
+    """BASELINE configs[2] shape on one GPU: teacher 32-shot + student query-only + KL + explicit backward at 9B.
+    T1 gradients are finite, non-zero and bit-reproducible; T2 KL(p, p) = 0 over the full vocabulary;
+    T3 one clipped AdamW step moves every parameter by at most its lr (Adam's per-element bound)."""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+    import bench
+    arch = full[0]
+    sd = synth_idefics_weights(arch, seed=426, dtype=torch.bfloat16, device=DEV)
+    trainer, targs = bench.build_trainer(arch, sd, torch.device(DEV), 8, 800, 33, 720, 0)
+    del sd
+    torch.cuda.empty_cache()
+    m = trainer.m
+    with torch.no_grad():
+        m.icv_encoder.alpha.fill_(-2.0)                 # sigmoid(-2) = 0.12: a live, non-saturated hook
+    g1 = trainer.loss_and_backward(*targs)
+    grad_icv, grad_alpha = m.icv_encoder.icv.grad.clone(), m.icv_encoder.alpha.grad.clone()
+    assert torch.isfinite(grad_icv).all() and torch.isfinite(grad_alpha).all() and grad_icv.abs().max() > 0
+    m.icv_encoder.icv.grad = None; m.icv_encoder.alpha.grad = None
+    g2 = trainer.loss_and_backward(*targs)
+    assert torch.equal(m.icv_encoder.icv.grad, grad_icv) and torch.equal(m.icv_encoder.alpha.grad, grad_alpha)   # T1
+    assert float(g1) == float(g2) and float(g1) > 0
+    # T2: the KL of a distribution with itself is 0 at the full 32 002-wide vocabulary, and the batch KL is non-negative
+    from licv import ops
+    stu, tea, ql, cl = targs
+    with torch.no_grad():
+        rows = m.get_mask(tea, cl).reshape(-1).nonzero().squeeze(1)
+        lt = trainer.m.interface.engine.forward(**tea, logits_rows=rows)
+        idx = torch.arange(rows.numel(), device=DEV)
+        lt2 = lt if lt.stride(1) == 1 else lt.contiguous()
+        self_kl = ops.kl_rows(lt2, lt2, idx, idx, lt.shape[1], 1.0, 1e-6)
+    assert float(self_kl.abs().max()) <= 1e-6
+    # T3: clipped AdamW steps move no parameter by more than its lr (Adam's per-element bound); the very first step of the
+    # cosine warm-up has lr 0 (ref:icv_src/icv_module.py:189-209 -> get_cosine_schedule_with_warmup), the second does move
+    for step in range(2):
+        if step:
+            trainer.loss_and_backward(*targs)
+        icv0, alpha0 = m.icv_encoder.icv.detach().clone(), m.icv_encoder.alpha.detach().clone()
+        log = trainer.optimizer_step()
+        lam, spec = log["lr_scale"], trainer.spec
+        d_icv = float((m.icv_encoder.icv.detach() - icv0).abs().max())
+        d_alpha = float((m.icv_encoder.alpha.detach() - alpha0).abs().max())
+        assert d_icv <= spec["icv_lr"] * lam * 1.01 + 1e-12 and d_alpha <= spec["alpha_lr"] * lam * 1.05 + 1e-12
+        assert (lam == 0.0 and d_icv == 0.0) if step == 0 else (lam > 0.0 and d_icv > 0.0 and d_alpha > 0.0)
+        assert log["grad_norm"] > 0 and log["kl_loss"] == log["loss"]
