@@ -228,3 +228,45 @@ def test_g8_generate_idefics2(golden, side):
     assert torch.equal(generate_idefics2(sd, arch, **b, num_beams=1, **kw), T(z[f"{side}_f32_greedy_off_ids"]))
     P = b["input_ids"].shape[1]
     assert not torch.equal(greedy[:, P:], T(z[f"{side}_f32_greedy_off_ids"])[:, P:]), "fixture does not exercise the hook"
+
+
+def _g9_setup(golden, dt):
+    z = golden("g9_loss_idefics2")
+    arch = IDEFICS2_TINY
+    sd32 = synth_idefics2_weights(arch, seed=91, dtype=torch.float32)
+    assert weights_checksum(sd32) == float(z["weights_checksum"])
+    sd = {k: v.to(dt) for k, v in sd32.items()}
+
+    def b(n):
+        return dict(input_ids=T(z[f"{n}_input_ids"]), attention_mask=T(z[f"{n}_attention_mask"]),
+                    pixel_values=T(z[f"{n}_pixel_values"]).to(dt), pixel_attention_mask=T(z[f"{n}_pixel_attention_mask"]))
+    return z, arch, sd, b("stu"), b("tea")
+
+
+@pytest.mark.parametrize("dn,dt", [("f32", torch.float32), ("bf16", torch.bfloat16)])
+@pytest.mark.parametrize("temp", [1.0, 2.0])
+def test_g9_idefics2_kl_loss_and_grads(golden, dn, dt, temp):
+    """Training objective on Idefics2 (hook on every `.mlp`): KL and d/d icv, d/d alpha against the reference's
+    VQAICVModule.forward + autograd through HF (bf16 = autocast regime)."""
+    import contextlib
+    z, arch, sd, stu, tea = _g9_setup(golden, dt)
+    icv = T(z["enc_icv"]).clone().requires_grad_(True)
+    alpha = T(z["enc_alpha_param"]).clone().requires_grad_(True)
+    layers = list(range(arch.num_layers))
+    sm, tm = T(z["stu_mask"]), T(z["tea_mask"])
+    assert torch.equal(O.get_mask(stu["input_ids"], T(z["query_x_length"]), arch.pad_token_id), sm)
+    assert torch.equal(O.get_mask(tea["input_ids"], T(z["in_context_length"]), arch.pad_token_id), tm)
+    ctx = torch.autocast("cpu", dtype=torch.bfloat16) if dn == "bf16" else contextlib.nullcontext()
+    with ctx:
+        icv_eff = O.scale_icv(O.encoder_alpha(alpha, True), icv)
+        s_logits = R2.forward(sd, arch, **stu, icv=icv_eff, hook_layers=layers)
+        with torch.no_grad():
+            t_logits = R2.forward(sd, arch, **tea)
+        kl = O.kl_divergence(s_logits[sm].view(-1, s_logits.shape[-1]), t_logits[tm].view(-1, t_logits.shape[-1]), temp)
+    kl.backward()
+    key = f"{dn}_T{int(temp)}"
+    tol = 1e-6 if dn == "f32" else 0.0
+    assert abs(float(kl) - float(z[f"{key}_kl"])) <= tol
+    gtol = 1e-7 if dn == "f32" else 0.0
+    assert (icv.grad - T(z[f"{key}_grad_icv"])).abs().max() <= gtol
+    assert (alpha.grad - T(z[f"{key}_grad_alpha"])).abs().max() <= gtol

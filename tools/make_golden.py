@@ -504,6 +504,65 @@ def g6_loss():
     np.savez_compressed(OUT / "g6_loss.npz", **out)
 
 
+def g9_loss_idefics2():
+    """g6 for Idefics2: the reference's VQAICVModule.forward (student hooked on every `.mlp` + teacher plain + KL) and the
+    grads of icv / alpha through HF Idefics2; bf16 under autocast (the regime the reference uses for this model)."""
+    from icv_src.icv_encoder.global_icv_encoder import GlobalICVEncoder
+    from icv_src.icv_model.icv_intervention import LearnableICVInterventionLMM
+    methods = _reference_module_methods()
+    arch = IDEFICS2_TINY
+    seed = 91
+    sd32 = synth_idefics2_weights(arch, seed=seed, dtype=torch.float32)
+    out = {"weights_checksum": np.array(weights_checksum(sd32))}
+    B, ans = 2, 3
+    tea = synth_vqa_batch_idefics2(arch, B, 36, 3, 56, 42, seed=seed, min_len=32, dtype=torch.float32)
+    stu = synth_vqa_batch_idefics2(arch, B, 18, 1, 56, 42, seed=seed + 1, min_len=15, dtype=torch.float32)
+    tl, sl = tea["attention_mask"].sum(1), stu["attention_mask"].sum(1)
+    for b in range(B):
+        stu["input_ids"][b, sl[b] - ans: sl[b]] = tea["input_ids"][b, tl[b] - ans: tl[b]]
+    in_context_length, query_x_length = tl - ans, sl - ans
+    for name, d in (("tea", tea), ("stu", stu)):
+        for k, v in d.items():
+            out[f"{name}_{k}"] = np_(v)
+    out["in_context_length"], out["query_x_length"] = in_context_length.numpy(), query_x_length.numpy()
+
+    class Mod(torch.nn.Module):
+        pass
+    for k, f in methods.items():
+        setattr(Mod, k, f)
+    fmt = "model.model.text_model.layers.<LAYER_NUM>.mlp"
+    for dt_name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+        for T in (1.0, 2.0):
+            model = hf_idefics2(arch, sd32, dt)
+            iface = Interface(model, arch.pad_token_id)
+            iface.requires_grad_(False)
+            mod = Mod()
+            mod.interface = iface
+            mod.module_cfg = types.SimpleNamespace(hard_loss_weight=0.0, only_hard_loss=False, kl_eps=1e-6)
+            mod.icv_model = LearnableICVInterventionLMM(iface, True, -1, fmt, arch.num_layers)
+            torch.manual_seed(seed)
+            mod.icv_encoder = GlobalICVEncoder(arch.hidden_size, arch.num_layers, alpha_init_value=0.3, use_sigmoid=True)
+            with torch.no_grad():
+                mod.icv_encoder.icv.mul_(5.0)
+            mod.temperature = torch.nn.Parameter(torch.tensor(T), requires_grad=False)
+            q = {k: (v.to(dt) if v.is_floating_point() else v.clone()) for k, v in stu.items()}
+            t = {k: (v.to(dt) if v.is_floating_point() else v.clone()) for k, v in tea.items()}
+            ctx = torch.autocast("cpu", dtype=torch.bfloat16) if dt == torch.bfloat16 else contextlib.nullcontext()
+            with ctx:
+                loss_dict, enc_out = mod(q, t, query_x_length, in_context_length)
+            loss_dict["loss"].backward()
+            key = f"{dt_name}_T{int(T)}"
+            out[f"{key}_kl"] = np_(loss_dict["kl_loss"])
+            out[f"{key}_grad_icv"] = np_(mod.icv_encoder.icv.grad)
+            out[f"{key}_grad_alpha"] = np_(mod.icv_encoder.alpha.grad)
+            if key == "f32_T1":
+                out["enc_icv"] = np_(mod.icv_encoder.icv)
+                out["enc_alpha_param"] = np_(mod.icv_encoder.alpha)
+                out["stu_mask"] = mod.get_mask(q, query_x_length).numpy()
+                out["tea_mask"] = mod.get_mask(t, in_context_length).numpy()
+    np.savez_compressed(OUT / "g9_loss_idefics2.npz", **out)
+
+
 def g7_optim():
     """torch.optim.AdamW with the reference's two param groups + transformers cosine warm-up
     (ref:icv_src/icv_module.py:171-209; icv_module.yaml: alpha_lr 1e-2, icv_lr 1e-4, wd 1e-3, warm 0.1)."""
@@ -537,8 +596,8 @@ def main():
     import icv_src.icv_model.icv_intervention as _ri
     assert _ri.__file__.startswith(str(REF)), _ri.__file__
     torch.set_num_threads(4)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
-    fns = dict(g1=g1_encoder, g2=g2_intervention, g3=g3_idefics, g4=g4_idefics2, g5=g5_generate, g6=g6_loss, g7=g7_optim, g8=g8_generate_idefics2)
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
+    fns = dict(g1=g1_encoder, g2=g2_intervention, g3=g3_idefics, g4=g4_idefics2, g5=g5_generate, g6=g6_loss, g7=g7_optim, g8=g8_generate_idefics2, g9=g9_loss_idefics2)
     for w in which:
         print("generating", w, flush=True)
         fns[w]()
