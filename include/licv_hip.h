@@ -168,9 +168,13 @@ int licv_swiglu_bwd(const void* gu_bf16, const void* dact_bf16, void* dgu_bf16, 
 /* grad entering a residual branch: out = bf16(bf16(dh)*scale), rows with row_gate == 0 zeroed (row_gate may be NULL) */
 int licv_branch_grad(const float* dh, void* out_bf16, int64_t rows, int64_t dim, float scale, int use_scale,
                      const float* row_gate, void* stream);
-/* attention backward for short sequences (Sq*Sk <= 16384), same argument struct as the forward; dk/dv may be NULL */
+/* attention backward for short sequences (Sq*Sk <= 16384), same argument struct as the forward; dk/dv may be NULL;
+ * dK/dV are written per QUERY head (n_heads*head_dim columns): with GQA reduce them with licv_head_group_sum */
 int licv_attn_bwd_small(const licv_attn_args* a, const void* dout_bf16, void* dq_bf16, int64_t dq_bs, int64_t dq_rs,
                         void* dk_bf16, void* dv_bf16, int64_t dkv_bs, int64_t dkv_rs, void* stream);
+/* backward of repeat_kv (GQA): out[r, g*hd + d] = sum over the `rep` query heads of group g of src[r, (g*rep+j)*hd + d] */
+int licv_head_group_sum(const void* src_bf16, void* out_bf16, int64_t rows, int64_t n_groups, int64_t rep, int64_t head_dim,
+                        int64_t ld_src, int64_t ld_out, void* stream);
 /* d loss / d student logits for the masked-KL rows: (n_rows, ld_grad >= vocab) bf16, scaled by upstream * T^2 / n_rows */
 int licv_kl_rows_bwd(const void* stu_logits, const void* tea_logits, int dtype, const int64_t* stu_rows, const int64_t* tea_rows,
                      int64_t n_rows, int64_t vocab, int64_t ld_stu, int64_t ld_tea, float temperature, float eps, float upstream,

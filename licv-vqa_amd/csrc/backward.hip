@@ -223,7 +223,7 @@ void attn_bwd_small_k(AttnBwdP a) {
         *reinterpret_cast<uint4*>(a.dq + (int64_t)b * a.dq_bs + (int64_t)i * a.dq_rs + (int64_t)head * hd + c) = make_uint4(o[0], o[1], o[2], o[3]);
     }
     if (!a.want_dkv) return;
-    // phase 4: dK_j = sum_i dS_ij Q_i ; dV_j = sum_i P_ij dO_i  (n_kv_heads == n_heads asserted on the host)
+    // phase 4: dK_j = sum_i dS_ij Q_i ; dV_j = sum_i P_ij dO_i  (written per QUERY head; GQA groups are reduced by head_group_sum_k)
     for (int idx = tid; idx < Sk * nch; idx += 256) {
         const int j = idx / nch, c = (idx - j * nch) * 8;
         float ak[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, av[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -352,7 +352,8 @@ extern "C" int licv_attn_bwd_small(const licv_attn_args* x, const void* dout, vo
                    "attn_bwd_small: pointers must be 16-byte aligned");
     LICV_CHECK_ARG(x->mask_mode != 3 || (x->img_mask && x->n_img > 0 && x->img_len > 0), "attn_bwd_small: image mask arguments missing");
     const int want = (dk && dv) ? 1 : 0;
-    LICV_CHECK_ARG(!want || x->n_heads == x->n_kv_heads, "attn_bwd_small: dK/dV need n_kv_heads == n_heads");
+    // dK / dV are written PER QUERY HEAD (n_heads x head_dim columns); with GQA the caller reduces each group of
+    // n_heads / n_kv_heads query heads with licv_head_group_sum (the backward of repeat_kv)
     AttnBwdP p;
     p.q = (const bf16_t*)x->q; p.q_bs = x->q_bs; p.q_rs = x->q_rs;
     p.k = (const bf16_t*)x->k; p.v = (const bf16_t*)x->v; p.kv_bs = x->kv_bs; p.kv_rs = x->kv_rs;
@@ -365,6 +366,35 @@ extern "C" int licv_attn_bwd_small(const licv_attn_args* x, const void* dout, vo
     static bool attr = false;
     if (!attr) { hipFuncSetAttribute((const void*)attn_bwd_small_k, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); attr = true; }
     attn_bwd_small_k<<<(unsigned)(x->B * x->n_heads), 256, lds, (hipStream_t)stream>>>(p);
+    LICV_LAUNCH_CHECK();
+    return LICV_OK;
+}
+
+// out[r, g*hd + d] = bf16( sum_{j < rep} src[r, (g*rep + j)*hd + d] )   (backward of repeat_kv, hf:mistral/modeling_mistral.py)
+__global__ __launch_bounds__(256)
+void head_group_sum_k(const bf16_t* __restrict__ src, bf16_t* __restrict__ out, int64_t rows, int n_groups, int rep, int hd,
+                      int64_t ld_src, int64_t ld_out) {
+    const int64_t total = rows * n_groups * hd;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i % hd);
+        const int g = (int)((i / hd) % n_groups);
+        const int64_t r = i / ((int64_t)hd * n_groups);
+        float acc = 0.f;
+        for (int j = 0; j < rep; ++j) acc += bf2f(src[r * ld_src + (int64_t)(g * rep + j) * hd + d]);
+        out[r * ld_out + (int64_t)g * hd + d] = f2bf(acc);
+    }
+}
+
+extern "C" int licv_head_group_sum(const void* src, void* out, int64_t rows, int64_t n_groups, int64_t rep, int64_t head_dim,
+                                   int64_t ld_src, int64_t ld_out, void* stream) {
+    LICV_CHECK_ARG(src && out, "head_group_sum: null pointer");
+    LICV_CHECK_ARG(n_groups > 0 && rep > 0 && head_dim > 0 && ld_src >= n_groups * rep * head_dim && ld_out >= n_groups * head_dim,
+                   "head_group_sum: bad shape");
+    const int64_t total = rows * n_groups * head_dim;
+    if (total <= 0) return LICV_OK;
+    int64_t b = (total + 255) / 256; b = b > 8192 ? 8192 : b;
+    head_group_sum_k<<<(unsigned)b, 256, 0, (hipStream_t)stream>>>((const bf16_t*)src, (bf16_t*)out, rows, (int)n_groups, (int)rep,
+                                                                  (int)head_dim, ld_src, ld_out);
     LICV_LAUNCH_CHECK();
     return LICV_OK;
 }

@@ -339,6 +339,12 @@ def attention_bwd_small(q, k, v, dout, B, Sq, Sk, n_heads, n_kv_heads, head_dim,
     return dq
 
 
+def head_group_sum(src: torch.Tensor, out: torch.Tensor, rows: int, n_groups: int, rep: int, head_dim: int, ld_src: int, ld_out: int):
+    """Backward of repeat_kv: sums each group of `rep` query heads (bf16 in, fp32 accumulate, bf16 out)."""
+    check(_lib.lib().licv_head_group_sum(_p(src), _p(out), rows, n_groups, rep, head_dim, ld_src, ld_out, _stream(src)))
+    return out
+
+
 def kl_rows_bwd(stu, tea, stu_rows, tea_rows, vocab, temperature, eps, upstream=1.0) -> torch.Tensor:
     """Returns (n_rows, vocab_padded_to_8) bf16 with zero pad columns (so it can feed the head's dgrad GEMM directly)."""
     n = stu_rows.numel()

@@ -193,3 +193,126 @@ class StudentPass:
                 d_x = ops.linear(dq, TX["q_T"])
                 ops.rmsnorm_bwd(x["h_in"], X.in_ln, d_x, dh, a.rms_eps, accumulate=True)
         return grad_v
+
+
+# ====================================================================================================== Idefics2
+class TrainWeights2:
+    """Transposed / unfused copies of the Mistral stack's weights for the backward (Idefics2)."""
+
+    def __init__(self, w, sd: Dict[str, torch.Tensor]):
+        dev = w.device
+        g = lambda k: sd[k].detach().to(device=dev, dtype=torch.bfloat16).contiguous()
+        self.text = []
+        for i, L in enumerate(w.text):
+            p = f"model.text_model.layers.{i}."
+            gu = torch.cat([g(p + "mlp.gate_proj.weight"), g(p + "mlp.up_proj.weight")]).contiguous()      # (2I, H) gate | up
+            self.text.append(dict(gu=gu, gu_T=_t(gu), down_T=_t(L.down_w), o_T=_t(L.o_w), qkv_T=_t(L.qkv_w)))
+        V = w.lm_head.shape[0]
+        head_T = torch.zeros((w.lm_head.shape[1], (V + 7) // 8 * 8), dtype=torch.bfloat16, device=dev)
+        head_T[:, :V] = w.lm_head.t()
+        self.head_T = head_T
+        self.neg_sin = (-w.sin.float()).to(torch.bfloat16).contiguous()
+
+
+class StudentPass2:
+    """Idefics2 student pass with gradient: hook on every text layer's MLP BRANCH (ref:config/lmm/idefics2-8B-base.yaml:8).
+    Per hooked layer  h_out = h_mid + edit(m):  the stream gradient passes through unchanged and the hook's backward kernel
+    turns it into d m (-> MLP backward) and d (alpha*icv)."""
+
+    def __init__(self, engine, tw: TrainWeights2):
+        self.e, self.tw = engine, tw
+
+    def forward(self, input_ids, attention_mask, pixel_values, pixel_attention_mask, icv: torch.Tensor,
+                hook_layers: Sequence[int], alpha: Optional[torch.Tensor], logits_rows: torch.Tensor):
+        e, a, w, tw = self.e, self.e.arch, self.e.w, self.tw
+        dev = w.device
+        B, S = input_ids.shape
+        M, H, nh, nkv, hd = B * S, a.hidden_size, a.num_heads, a.num_kv_heads, a.head_dim
+        qd, kd = nh * hd, nkv * hd
+        ldq = qd + 2 * kd
+        ids = input_ids.to(dev).contiguous()
+        with torch.no_grad():
+            img = e.encode_images(pixel_values, pixel_attention_mask) if pixel_values is not None else None
+        h = ops.embed_gather(ids, w.embed, None, w.embed.shape[0]).view(M, H)
+        if img is not None:
+            slots = (ids.view(-1) == a.image_token_id).nonzero().view(-1).contiguous()
+            ops.scatter_rows_(h, slots, img.reshape(-1, H).contiguous())
+        key_valid = attention_mask.to(device=dev, dtype=torch.int32).contiguous()
+        pos = torch.arange(S, device=dev, dtype=torch.int64).repeat(B).contiguous()
+        idx_of = {int(l): i for i, l in enumerate(hook_layers)}
+        icv = icv.detach().to(device=dev, dtype=torch.float32).contiguous()
+        alpha = alpha.detach().to(device=dev, dtype=torch.float32).contiguous() if alpha is not None else None
+        st = dict(B=B, S=S, key_valid=key_valid, pos=pos, icv=icv, alpha=alpha, idx_of=idx_of, layers=[], logits_rows=logits_rows)
+        for l, L in enumerate(w.text):
+            T = tw.text[l]
+            rec = {"h_in": h}
+            xn = ops.rmsnorm(h, L.in_ln, a.rms_eps, 1)
+            qkv = ops.linear(xn, L.qkv_w)
+            ops.rotary_(qkv, w.cos, w.sin, pos, M, nh, hd, ldq, qd, 1)
+            ops.rotary_(qkv.view(-1)[qd:], w.cos, w.sin, pos, M, nkv, hd, ldq, kd, 1)
+            rec["qkv"] = qkv
+            o = ops.attention(qkv, qkv.view(-1)[qd:], qkv.view(-1)[qd + kd:], B, S, S, nh, nkv, hd, S * ldq, ldq, S * ldq, ldq,
+                              hd ** -0.5, 1, key_valid=key_valid)
+            h = ops.linear(o.view(M, qd), L.o_w, residual=h)
+            rec["h_mid"] = h
+            xn = ops.rmsnorm(h, L.post_ln, a.rms_eps, 1)
+            gu = ops.linear(xn, T["gu"])
+            rec["gu"] = gu
+            act = ops.swiglu(gu)
+            if l in idx_of:
+                i = idx_of[l]
+                m = ops.linear(act, L.down_w)
+                rec["m"] = m
+                al = alpha[0, i:i + 1] if alpha is not None else None
+                h = ops.inject_renorm_add(m, icv[0, i], h, alpha=al)
+            else:
+                h = ops.linear(act, L.down_w, residual=h)
+            st["layers"].append(rec)
+        st["h_final"] = h
+        xf = ops.rmsnorm(h, w.final_ln, a.rms_eps, 1)
+        logits = ops.linear(xf.index_select(0, logits_rows), w.lm_head)
+        return logits, st
+
+    def backward(self, st: dict, dlogits_rows: torch.Tensor) -> torch.Tensor:
+        e, a, w, tw = self.e, self.e.arch, self.e.w, self.tw
+        B, S = st["B"], st["S"]
+        M, H, nh, nkv, hd = B * S, a.hidden_size, a.num_heads, a.num_kv_heads, a.head_dim
+        qd, kd, rep = nh * hd, nkv * hd, nh // nkv
+        ldq = qd + 2 * kd
+        dev = w.device
+        grad_v = torch.zeros((1, len(st["idx_of"]), H), dtype=torch.float32, device=dev)
+        assert dlogits_rows.shape[1] == tw.head_T.shape[1] and dlogits_rows.is_contiguous(), "pass the padded grad from ops.kl_rows_bwd"
+        d_xf = torch.zeros((M, H), dtype=torch.bfloat16, device=dev)
+        d_xf.index_copy_(0, st["logits_rows"], ops.linear(dlogits_rows, tw.head_T))
+        dh = torch.empty((M, H), dtype=torch.float32, device=dev)
+        ops.rmsnorm_bwd(st["h_final"], w.final_ln, d_xf, dh, a.rms_eps, accumulate=False)
+        for l in reversed(range(a.num_layers)):
+            rec, L, T = st["layers"][l], w.text[l], tw.text[l]
+            # MLP branch: hooked -> through the edit's backward, else straight
+            if l in st["idx_of"]:
+                i = st["idx_of"][l]
+                al = st["alpha"][0, i:i + 1] if st["alpha"] is not None else None
+                d_m, gv = ops.inject_renorm_bwd(rec["m"], st["icv"][0, i], al, dh)
+                grad_v[0, i] = gv
+                d_out = ops.branch_grad(d_m)
+            else:
+                d_out = ops.branch_grad(dh)
+            d_act = ops.linear(d_out, T["down_T"])
+            d_gu = ops.swiglu_bwd(rec["gu"], d_act)
+            d_x = ops.linear(d_gu, T["gu_T"])
+            ops.rmsnorm_bwd(rec["h_mid"], L.post_ln, d_x, dh, a.rms_eps, accumulate=True)
+            # attention branch (GQA): dK / dV per query head, then the group sum = backward of repeat_kv
+            d_attn = ops.linear(ops.branch_grad(dh), T["o_T"])
+            qkv = rec["qkv"]
+            dqkv = torch.empty_like(qkv)
+            dkv_heads = torch.empty((M, 2 * qd), dtype=torch.bfloat16, device=dev)          # [dK per q head | dV per q head]
+            ops.attention_bwd_small(qkv, qkv.view(-1)[qd:], qkv.view(-1)[qd + kd:], d_attn, B, S, S, nh, nkv, hd, S * ldq, ldq,
+                                    S * ldq, ldq, hd ** -0.5, 1, dqkv, S * ldq, ldq, dk=dkv_heads, dv=dkv_heads.view(-1)[qd:],
+                                    dkv_bs=S * 2 * qd, dkv_rs=2 * qd, key_valid=st["key_valid"])
+            ops.head_group_sum(dkv_heads, dqkv.view(-1)[qd:], M, nkv, rep, hd, 2 * qd, ldq)
+            ops.head_group_sum(dkv_heads.view(-1)[qd:], dqkv.view(-1)[qd + kd:], M, nkv, rep, hd, 2 * qd, ldq)
+            ops.rotary_(dqkv, w.cos, tw.neg_sin, st["pos"], M, nh, hd, ldq, qd, 1)           # inverse rotation of dQ and dK
+            ops.rotary_(dqkv.view(-1)[qd:], w.cos, tw.neg_sin, st["pos"], M, nkv, hd, ldq, kd, 1)
+            d_x = ops.linear(dqkv, T["qkv_T"])
+            ops.rmsnorm_bwd(rec["h_in"], L.in_ln, d_x, dh, a.rms_eps, accumulate=True)
+        return grad_v

@@ -14,7 +14,7 @@ from typing import Dict, Optional
 import torch
 
 from . import ops
-from .train_engine import StudentPass, TrainWeights
+from .train_engine import StudentPass, StudentPass2, TrainWeights, TrainWeights2
 
 
 def shard_indices(n: int, rank: int, world: int, drop_last: bool = True):
@@ -41,7 +41,10 @@ class ICVTrainer:
         if module.module_cfg.hard_loss_weight:
             raise NotImplementedError("the native backward covers the KL objective (hard_loss_weight = 0, the reference default)")
         eng = module.interface.engine
-        self.student = StudentPass(eng, TrainWeights(eng.w, state_dict))
+        if type(eng).__name__ == "Idefics2Engine":
+            self.student = StudentPass2(eng, TrainWeights2(eng.w, state_dict))
+        else:
+            self.student = StudentPass(eng, TrainWeights(eng.w, state_dict))
         self.accum, self.clip, self.group = accumulate_grad_batches, grad_clip, group
         spec = module.optimizer_spec(total_steps)
         self.spec = spec
@@ -77,9 +80,8 @@ class ICVTrainer:
         assert s_rows.numel() == t_rows.numel(), "student and teacher must mask the same number of answer tokens"
         enc_out = m.icv_encoder()
         with torch.no_grad():
-            tea = eng.forward(t["input_ids"], t["attention_mask"], t["pixel_values"], t["image_attention_mask"], logits_rows=t_rows)
-        stu, st = self.student.forward(q["input_ids"], q["attention_mask"], q["pixel_values"], q["image_attention_mask"],
-                                       icv=enc_out.in_context_vector, hook_layers=self.layers, alpha=enc_out.alpha,
+            tea = eng.forward(**t, logits_rows=t_rows)          # Idefics: image_attention_mask; Idefics2: pixel_attention_mask
+        stu, st = self.student.forward(**q, icv=enc_out.in_context_vector, hook_layers=self.layers, alpha=enc_out.alpha,
                                        logits_rows=s_rows)
         V = eng.w.lm_head.shape[0]
         idx = torch.arange(s_rows.numel(), device=dev)

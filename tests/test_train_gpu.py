@@ -89,3 +89,45 @@ def test_trainer_step_applies_clipped_adamw_like_the_oracle(golden):
     moved = (p2 - p1)[n_a:]
     nz = g[n_a:].abs() > 1e-9
     assert (torch.sign(moved[nz]) == -torch.sign(g[n_a:][nz])).float().mean() > 0.99
+
+
+@pytest.mark.parametrize("temp", [1.0, 2.0])
+def test_idefics2_native_backward_matches_reference_autograd(golden, temp):
+    """Idefics2 (hook on every `.mlp` branch, GQA attention backward): native grads vs the reference's VQAICVModule.forward +
+    autograd through HF Idefics2 (fixture g9; bf16 = autocast).  Same bar as the Idefics test above."""
+    from icv_src.icv_module import VQAICVModule
+    from licv.config import IDEFICS2_TINY
+    from licv.synthetic import synth_idefics2_weights
+    from licv.trainer import ICVTrainer
+    from lmm_icl_interface import Idefics2Interface
+    z = golden("g9_loss_idefics2")
+    arch = IDEFICS2_TINY
+    sd = synth_idefics2_weights(arch, seed=91, dtype=torch.float32)
+    iface = Idefics2Interface(state_dict=sd, arch=arch, device=DEV)
+    mod_cfg = dict(hard_loss_weight=0.0, only_hard_loss=False, kl_eps=1e-6, init_temperature=temp, learnable_t=False,
+                   decay_ratio=-1, decay_per_step=-1, min_tmeprature=1.0, alpha_lr=1e-2, icv_lr=1e-4, weight_decay=1e-3,
+                   warm_steps=0.1, icv_encoder=dict(use_sigmoid=True, alpha_learnable=True, alpha_init_value=0.3))
+    lmm_cfg = dict(intervention_layer=-1, layer_format="model.model.text_model.layers.<LAYER_NUM>.mlp", total_layers=arch.num_layers,
+                   hidden_size=arch.hidden_size)
+    mod = VQAICVModule(iface, mod_cfg, lmm_cfg).to(DEV)
+    with torch.no_grad():
+        mod.icv_encoder.icv.copy_(T(z["enc_icv"]))
+        mod.icv_encoder.alpha.copy_(T(z["enc_alpha_param"]))
+    tr = ICVTrainer(mod, sd, total_steps=20, accumulate_grad_batches=1, grad_clip=1.0)
+    b = lambda p: {k: T(z[f"{p}{k}"]) for k in ("input_ids", "attention_mask", "pixel_values", "pixel_attention_mask")}
+    kl = tr.loss_and_backward(b("stu_"), b("tea_"), T(z["query_x_length"]), T(z["in_context_length"]))
+    key = f"T{int(temp)}"
+    kl16, kl32 = float(z[f"bf16_{key}_kl"]), float(z[f"f32_{key}_kl"])
+    assert abs(float(kl) - kl32) <= 1.5 * abs(kl16 - kl32) + 0.05 * kl32
+    for name, got in (("grad_icv", mod.icv_encoder.icv.grad), ("grad_alpha", mod.icv_encoder.alpha.grad)):
+        g32, g16 = T(z[f"f32_{key}_{name}"]), T(z[f"bf16_{key}_{name}"])
+        spread = (g16 - g32).abs().max()
+        err = (got.cpu() - g32).abs().max()
+        scale = g32.abs().max()
+        assert err <= 1.5 * spread + 0.02 * scale, f"{name}: err {err:.3e} spread {spread:.3e} scale {scale:.3e}"
+        cos = torch.nn.functional.cosine_similarity(got.cpu().reshape(1, -1), g32.reshape(1, -1)).item()
+        assert cos > 0.99, f"{name}: cosine {cos}"
+    # the module's own forward (reference call shape) gives the same KL as the trainer's path
+    loss_dict, _ = mod({k: v.to(DEV) for k, v in b("stu_").items()}, {k: v.to(DEV) for k, v in b("tea_").items()},
+                       T(z["query_x_length"]).to(DEV), T(z["in_context_length"]).to(DEV))
+    assert abs(float(loss_dict["kl_loss"]) - float(kl)) <= 2e-2 * abs(float(kl)) + 1e-5
