@@ -40,6 +40,11 @@ WORKLOADS = {
     # (27x36 = 972 patches), 64 <image> tokens each, S = 2*66 + 40 = 172, hook on all 32 MLP branches
     "idefics2_8b_1shot_bs8": ("idefics2-8b", 8, 172, 2, 160),
     "idefics2_mid_debug": ("idefics2-mid", 2, 40, 2, 30),
+    # BASELINE configs[4] shape (SURVEY "I2-32") in bf16: 33 images per question, S ~ 33*66 + 700; the fp8-weight GEMM it names is not built
+    "idefics2_8b_32shot_bs8": ("idefics2-8b", 8, 2900, 33, 2800),
+    # Idefics2 L-ICV training micro-batch: teacher 32-shot (no grad) + student query-only (grad) + KL + backward
+    "idefics2_8b_train_bs8": ("idefics2-8b", 8, 2900, 33, 2800),
+    "idefics2_mid_train_debug": ("idefics2-mid", 2, 60, 3, 50),
 }
 IDEFICS2_IMAGE = {"idefics2-8b": (378, 504), "idefics2-mid": (84, 70)}
 
@@ -136,25 +141,31 @@ def cpu_baseline_idefics2(arch, S, n_img, hw):
                        f"= {full:.1f} s/question")}
 
 
-def build_trainer(arch, sd, dev, B, S, n_img, min_len, rank):
+def build_trainer(arch, sd, dev, B, S, n_img, min_len, rank, hw=None):
     """VQAICVModule + ICVTrainer on synthetic teacher/student batches obeying the collator contract (same answer span
     at the tail of both rows, ref:icv_src/icv_datamodule.py:73-130)."""
     from icv_src.icv_module import VQAICVModule
-    from licv.synthetic import synth_vqa_batch
+    from licv.synthetic import synth_vqa_batch, synth_vqa_batch_idefics2
     from licv.trainer import ICVTrainer
-    from lmm_icl_interface import IdeficsInterface
-    iface = IdeficsInterface(state_dict=sd, arch=arch, device=dev)
+    from lmm_icl_interface import Idefics2Interface, IdeficsInterface
+    is2 = hw is not None
+    iface = (Idefics2Interface if is2 else IdeficsInterface)(state_dict=sd, arch=arch, device=dev)
     mod_cfg = dict(hard_loss_weight=0.0, only_hard_loss=False, kl_eps=1e-6, init_temperature=1.0, learnable_t=False, decay_ratio=-1,
                    decay_per_step=-1, min_tmeprature=1.0, alpha_lr=1e-2, icv_lr=1e-4, weight_decay=1e-3, warm_steps=0.1,
                    icv_encoder=dict(use_sigmoid=True, alpha_learnable=True, alpha_init_value=0.0))
-    lmm_cfg = dict(intervention_layer=-1, layer_format="model.model.layers.<LAYER_NUM>", total_layers=arch.num_layers,
-                   hidden_size=arch.hidden_size)
+    lmm_cfg = dict(intervention_layer=-1, total_layers=arch.num_layers, hidden_size=arch.hidden_size,
+                   layer_format="model.model.text_model.layers.<LAYER_NUM>.mlp" if is2 else "model.model.layers.<LAYER_NUM>")
     torch.manual_seed(426)
     mod = VQAICVModule(iface, mod_cfg, lmm_cfg).to(dev)
     ans = 4                                                           # answer span = last 4 real tokens (SURVEY §8d "TR")
-    Sq = 32 if S >= 256 else 16
-    tea = synth_vqa_batch(arch, B, S, n_img, seed=426 + rank, min_len=min_len, dtype=torch.bfloat16)
-    stu = synth_vqa_batch(arch, B, Sq, 1, seed=1426 + rank, min_len=Sq - 8, dtype=torch.bfloat16)
+    if is2:
+        Sq = arch.r_latents + 2 + (40 if S >= 256 else 10)              # one image (64 <image> tokens + 2) + the question
+        tea = synth_vqa_batch_idefics2(arch, B, S, n_img, hw[0], hw[1], seed=426 + rank, min_len=min_len, dtype=torch.bfloat16, ragged=False)
+        stu = synth_vqa_batch_idefics2(arch, B, Sq, 1, hw[0], hw[1], seed=1426 + rank, min_len=Sq - 8, dtype=torch.bfloat16, ragged=False)
+    else:
+        Sq = 32 if S >= 256 else 16
+        tea = synth_vqa_batch(arch, B, S, n_img, seed=426 + rank, min_len=min_len, dtype=torch.bfloat16)
+        stu = synth_vqa_batch(arch, B, Sq, 1, seed=1426 + rank, min_len=Sq - 8, dtype=torch.bfloat16)
     tl, sl = tea["attention_mask"].sum(1), stu["attention_mask"].sum(1)
     for b in range(B):
         stu["input_ids"][b, sl[b] - ans: sl[b]] = tea["input_ids"][b, tl[b] - ans: tl[b]]
@@ -207,14 +218,13 @@ def main():
         from licv.idefics2_engine import Idefics2Engine, Idefics2Weights
         from licv.synthetic import synth_idefics2_weights, synth_vqa_batch_idefics2
         sd = synth_idefics2_weights(arch, seed=426, dtype=torch.bfloat16, device=dev)
-        eng = Idefics2Engine(Idefics2Weights(sd, arch, dev))
     else:
         sd = synth_idefics_weights(arch, seed=426, dtype=torch.bfloat16, device=dev)       # full replica per GPU
-    if is2:
-        pass
-    elif training:
-        trainer, train_args = build_trainer(arch, sd, dev, B, S, n_img, min_len, rank)
+    if training:
+        trainer, train_args = build_trainer(arch, sd, dev, B, S, n_img, min_len, rank, hw=IDEFICS2_IMAGE[preset] if is2 else None)
         eng = trainer.m.interface.engine
+    elif is2:
+        eng = Idefics2Engine(Idefics2Weights(sd, arch, dev))
     else:
         eng = IdeficsEngine(IdeficsWeights(sd, arch, dev))
     del sd
@@ -274,7 +284,8 @@ def main():
     ti, by, ni = agg("inject")
     fq = {"total": fl / max(args.steps, 1) / B} if is2 else flops_per_question(arch, S, n_img)   # Idefics2: GEMM flops as launched
     res = {
-        "metric": ("VQA questions/sec (whole node), Idefics2-8B-base 1-shot ICV forward" if is2 else
+        "metric": (f"VQA questions/sec (whole node), Idefics2-8B-base {'32' if n_img > 2 else '1'}-shot L-ICV training micro-batch" if is2 and training else
+                   f"VQA questions/sec (whole node), Idefics2-8B-base {'32' if n_img > 2 else '1'}-shot ICV forward" if is2 else
                    "VQA questions/sec (whole node), Idefics-9B 32-shot L-ICV training micro-batch" if training else
                    "VQA questions/sec (whole node), Idefics-9B 32-shot ICV forward"),
         "value": qps, "unit": "questions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
