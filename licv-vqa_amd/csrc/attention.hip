@@ -127,8 +127,10 @@ __device__ __forceinline__ void attn_tile_n(int nst, const char* kt, const char*
     else               attn_tile<DPK, DPV, 1>(kt, vt, qf, oacc, m_run, l_run, sc, g, ql, need_mask, allowed);
 }
 
-template <int DPK, int DPV, int QT, int NW>   // NW waves per workgroup, QT 16-query sub-tiles per wave: QT*NW*16 queries
-__global__ __launch_bounds__(NW * 64, (DPK == 128 ? 3 : 2))      // 3 waves per SIMD (<= 168 VGPRs) measured 7-10 % faster at head_dim 128; 4 spills
+// MODE = mask mode as a compile-time constant: the image-mask bookkeeping (run-time divisions, per-image bit sets) and the
+// causal bounds otherwise sit in every instantiation's tile loop (1600 scalar instructions, SGPR spills to VGPR lanes).
+template <int DPK, int DPV, int QT, int NW, int MODE>   // NW waves per workgroup, QT 16-query sub-tiles per wave: QT*NW*16 queries
+__global__ __launch_bounds__(NW * 64, 2)      // 2 waves per SIMD guaranteed (3 at head_dim 128 spills once MODE is a constant: 183 -> 251 us)
 void attn_fwd_k(AttnP a) {
     constexpr int NTHR = NW * 64;
     constexpr int SLAB = NW * 16;               // queries per slab (one sub-tile of every wave)
@@ -171,12 +173,12 @@ void attn_fwd_k(AttnP a) {
     }
 
     int kend = a.Sk;
-    if (a.mask_mode == 1) kend = min(a.Sk, min(q0 + QBLK, a.Sq) + coff);   // keys beyond the last query's diagonal
+    if (MODE == 1) kend = min(a.Sk, min(q0 + QBLK, a.Sq) + coff);   // keys beyond the last query's diagonal
     const int ntiles = (kend + ATT_KB - 1) / ATT_KB;
 
     // image-mask mode with whole tiles inside one image: a tile is visited only if some query of this
     // workgroup attends that image (a token attends ONE image of ~33: >95 % of the key tiles drop out)
-    const bool img_uniform = (a.mask_mode == 3) && (a.img_len % ATT_KB == 0);
+    const bool img_uniform = (MODE == 3) && (a.img_len % ATT_KB == 0);
     const bool img_skip = img_uniform && a.n_img <= 64;
     unsigned long long used = ~0ull;
     if (img_skip) {
@@ -226,7 +228,7 @@ void attn_fwd_k(AttnP a) {
         if (tid < ATT_KB) {
             const int key = key0 + tid;
             int ok = key < a.Sk;
-            if (ok && a.key_valid && (a.mask_mode == 1 || a.mask_mode == 2)) ok = a.key_valid[(int64_t)b * a.Sk + key] != 0;
+            if (ok && a.key_valid && (MODE == 1 || MODE == 2)) ok = a.key_valid[(int64_t)b * a.Sk + key] != 0;
             rvalid = ok;
         }
     };
@@ -272,13 +274,13 @@ void attn_fwd_k(AttnP a) {
         for (int qs = 0; qs < QT; ++qs) {
             const int qw0 = q0 + qs * SLAB + wave * 16;          // first query of this wave's sub-tile (wave-uniform)
             if (qw0 >= a.Sq) continue;                              // sub-tile past the last query: only helps loading
-            if (a.mask_mode == 1 && key0 > qw0 + 15 + coff) continue;   // tile entirely in this sub-tile's future
+            if (MODE == 1 && key0 > qw0 + 15 + coff) continue;   // tile entirely in this sub-tile's future
             const int qrow = qw0 + ql;
             const bool qok = qrow < a.Sq;
-            const int32_t* imrow = (a.mask_mode == 3 && qok) ? a.img_mask + ((int64_t)b * a.Sq + qrow) * a.n_img : nullptr;
+            const int32_t* imrow = (MODE == 3 && qok) ? a.img_mask + ((int64_t)b * a.Sq + qrow) * a.n_img : nullptr;
             bool need_mask = (key0 + ATT_KB > a.Sk) || (qw0 + 16 > a.Sq) || !tile_all_valid;
-            if (a.mask_mode == 1) need_mask = need_mask || (key0 + ATT_KB - 1 > qw0 + coff);
-            if (a.mask_mode == 3) need_mask = true;
+            if (MODE == 1) need_mask = need_mask || (key0 + ATT_KB - 1 > qw0 + coff);
+            if (MODE == 3) need_mask = true;
             const int img_ok_tile = (img_uniform && imrow) ? (imrow[key0 / a.img_len] != 0) : 0;
             int4 kvalid[4] = {int4{1, 1, 1, 1}, int4{1, 1, 1, 1}, int4{1, 1, 1, 1}, int4{1, 1, 1, 1}};
             if (need_mask) {
@@ -290,8 +292,8 @@ void attn_fwd_k(AttnP a) {
                 const int key = key0 + kl;
                 const int kv = r == 0 ? kvalid[st].x : (r == 1 ? kvalid[st].y : (r == 2 ? kvalid[st].z : kvalid[st].w));
                 bool ok = qok && kv != 0;
-                if (a.mask_mode == 1) ok = ok && (key <= qrow + coff);
-                if (a.mask_mode == 3) {
+                if (MODE == 1) ok = ok && (key <= qrow + coff);
+                if (MODE == 3) {
                     if (img_uniform) ok = ok && img_ok_tile;
                     else ok = ok && imrow && (imrow[key / a.img_len] != 0);
                 }
@@ -490,7 +492,9 @@ extern "C" int licv_attn_fwd(const licv_attn_args* x, void* stream) {
             return LICV_OK;
         }
     }
-    // 64 queries per 4-wave workgroup.  Measured and dropped (this kernel is bound by each wave's dependency chain
+    // 64 queries per 4-wave workgroup; the mask mode is a template constant (with it at run time the tile loop carried the
+    // image-mask bookkeeping of mode 3 in every instantiation: 3700 lines of ISA, 1600 scalar instructions, SGPR spills;
+    // as a constant the mode-0 loop is 350 lines: SigLIP 288 -> 217 us).  Measured and dropped (this kernel is bound by each wave's dependency chain
     // QK -> max -> exp2 -> PV and lives on waves in flight, not on loads or the LDS port):
     //  (i)   several 64-query slabs per workgroup sharing each fetched K/V tile: 745 vs 590 us on the ViT shape;
     //  (ii)  two 16-query sub-tiles per wave sharing every K / V^T fragment read (half the LDS bytes per flop):
@@ -504,7 +508,11 @@ extern "C" int licv_attn_fwd(const licv_attn_args* x, void* stream) {
     LICV_CHECK_ARG(nblk < (1ll << 31), "attn_fwd: grid too large");
     const dim3 grid((unsigned)nblk), block(256);
     hipStream_t st = (hipStream_t)stream;
-#define ATT_LAUNCH(DK, DV) attn_fwd_k<DK, DV, 1, 4><<<grid, block, 0, st>>>(p)
+#define ATT_LAUNCH(DK, DV) do { switch (p.mask_mode) { \
+        case 0:  attn_fwd_k<DK, DV, 1, 4, 0><<<grid, block, 0, st>>>(p); break; \
+        case 1:  attn_fwd_k<DK, DV, 1, 4, 1><<<grid, block, 0, st>>>(p); break; \
+        case 2:  attn_fwd_k<DK, DV, 1, 4, 2><<<grid, block, 0, st>>>(p); break; \
+        default: attn_fwd_k<DK, DV, 1, 4, 3><<<grid, block, 0, st>>>(p); break; } } while (0)
     if (hd <= 16)        ATT_LAUNCH(32, 16);
     else if (hd <= 32)   ATT_LAUNCH(32, 32);
     else if (hd <= 64)   ATT_LAUNCH(64, 64);

@@ -29,10 +29,10 @@ def run(name,B,Sq,Sk,nh,nkv,hd,mode,flags_list=(0,2,1,3)):
         line+=f" | f{f}: {t*1e6:7.1f} us {fl/t/1e12:6.1f} TF d={d:.0e}"
     print(line,flush=True)
     lib.licv_attn_select(0)
-run("vit",264,257,257,16,16,80,0,(0,1,0x31,0x41))
-run("lm",8,800,800,32,32,128,1,(0,0x30,0x40))
-run("siglip",16,972,972,16,16,72,0,(0,0x30,0x40))
-run("siglip-m",16,972,972,16,16,72,2,(0,0x30,0x40))
-run("perceiver",264,64,321,16,16,96,0,(0,1,0x31,0x41))
-run("xattn",8,800,33*64,32,32,128,3,(0,0x30,0x40))
-run("mistral",8,172,172,32,8,128,1,(0,0x30,0x40))
+run("vit",264,257,257,16,16,80,0,(0,1))
+run("lm",8,800,800,32,32,128,1,(0,))
+run("siglip",16,972,972,16,16,72,0,(0,))
+run("siglip-m",16,972,972,16,16,72,2,(0,))
+run("perceiver",264,64,321,16,16,96,0,(0,1))
+run("xattn",8,800,33*64,32,32,128,3,(0,))
+run("mistral",8,172,172,32,8,128,1,(0,))
