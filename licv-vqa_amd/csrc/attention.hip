@@ -398,32 +398,38 @@ void attn_resident_k(AttnP a, int skp, int n_items) {
     const int nxt = item + gridDim.x;
     if (nxt < n_items) fetch(nxt);
 
+    // Q fragments of a unit are fetched one unit ahead (their global-load latency otherwise sits at the head of every unit)
+    auto load_q = [&](int qsub, bf16x8 (&qf)[DPK / 32]) {
+        const int qrow = qsub * 16 + ql;
+        const bf16_t* qp = a.q + (int64_t)b * a.q_bs + (int64_t)qrow * a.q_rs + (int64_t)head * a.hd;
+#pragma unroll
+        for (int ks = 0; ks < DPK / 32; ++ks) {
+            const int d = ks * 32 + g * 8;
+            u32x4 r = u32x4{0u, 0u, 0u, 0u};
+            if (qsub < nq && qrow < a.Sq && d < a.hd) r = *reinterpret_cast<const u32x4*>(qp + d);
+            qf[ks] = *reinterpret_cast<bf16x8*>(&r);
+        }
+    };
+    bf16x8 qf[DPK / 32], qf_next[DPK / 32];
+    load_q(wave, qf_next);
+    const int nfull = a.Sk / ATT_KB;                         // tiles with 64 real keys: no mask, 4 live sub-tiles
     for (int qsub = wave; qsub < nq; qsub += 8) {
         const int qrow = qsub * 16 + ql;
         const bool qok = qrow < a.Sq;
-        bf16x8 qf[DPK / 32];
-        {
-            const bf16_t* qp = a.q + (int64_t)b * a.q_bs + (int64_t)qrow * a.q_rs + (int64_t)head * a.hd;
 #pragma unroll
-            for (int ks = 0; ks < DPK / 32; ++ks) {
-                const int d = ks * 32 + g * 8;
-                u32x4 r = u32x4{0u, 0u, 0u, 0u};
-                if (qok && d < a.hd) r = *reinterpret_cast<const u32x4*>(qp + d);
-                qf[ks] = *reinterpret_cast<bf16x8*>(&r);
-            }
-        }
+        for (int ks = 0; ks < DPK / 32; ++ks) qf[ks] = qf_next[ks];
+        load_q(qsub + 8, qf_next);
         floatx4 oacc[DPV / 16];
 #pragma unroll
         for (int i = 0; i < DPV / 16; ++i) oacc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
         float m_run = -INFINITY, l_run = 0.f;
-        for (int t = 0; t < ntiles; ++t) {
-            const int key0 = t * ATT_KB;
-            const int nst = min(4, (a.Sk - key0 + 15) >> 4);
-            const char* kt = sK + key0 * KSTR;
-            const char* vt = sV + key0 * VSTR;
-            const bool need_mask = key0 + ATT_KB > a.Sk;     // ragged last tile: keys past Sk never contribute
+        auto never = [](int, int) -> bool { return true; };
+        for (int t = 0; t < nfull; ++t)
+            attn_tile<DPK, DPV, 4>(sK + t * ATT_KB * KSTR, sV + t * ATT_KB * VSTR, qf, oacc, m_run, l_run, sc, g, ql, false, never);
+        if (nfull < ntiles) {                               // ragged last tile: keys past Sk never contribute
+            const int key0 = nfull * ATT_KB;
             auto allowed = [&](int st, int r) -> bool { return key0 + st * 16 + g * 4 + r < a.Sk; };
-            attn_tile_n<DPK, DPV>(nst, kt, vt, qf, oacc, m_run, l_run, sc, g, ql, need_mask, allowed);
+            attn_tile_n<DPK, DPV>(min(4, (a.Sk - key0 + 15) >> 4), sK + key0 * KSTR, sV + key0 * VSTR, qf, oacc, m_run, l_run, sc, g, ql, true, allowed);
         }
         l_run += __shfl_xor(l_run, 16, 64);
         l_run += __shfl_xor(l_run, 32, 64);
