@@ -110,6 +110,11 @@ int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void*
 int licv_gemm_select(int which);
 /* A/B switch for the persistent kernel's per-XCD start stagger (default on). */
 int licv_gemm_stagger(int on);
+/* A/B timing knobs of the default kernel (0: per-XCD start stagger in percent, 1: tile-rows per XCD patch); off by default */
+int licv_gemm_experiment(int knob, int value);
+/* timing instrumentation: when non-NULL, wave 0 of every workgroup of the default kernel stores 5 wall_clock64() stamps
+ * (start, pipeline filled, main loop done, output image in LDS, end) at dev_buffer[8 * blockIdx.x ...] (int64) */
+int licv_gemm_debug_timestamps(void* dev_buffer);
 /* (2I x K) gate/up weights -> the 16-row interleaved layout the swiglu epilogue expects. */
 int licv_pack_gate_up(const void* gate_bf16, const void* up_bf16, void* packed_bf16,
                       int64_t inter, int64_t K, void* stream);

@@ -967,8 +967,13 @@ static int g_stagger = 0;        // per-XCD start stagger of the persistent kern
 // (A rotated K traversal per tile was also tried: -3 ... -25 %, lockstep K sweeps are what makes L2 sharing work.)
 static int g_pp_stagger = 0;
 static int g_pp_group = 0;      // experiment knob: tile-rows per XCD patch group (0 = heuristic)
-extern "C" int licv_gemm_stagger(int on) {
-    if (on >= 200) g_pp_group = on - 200; else if (on >= 100) g_pp_stagger = on - 100; else g_stagger = on;
+extern "C" int licv_gemm_stagger(int on) { g_stagger = on; return LICV_OK; }
+// A/B timing knobs of the default (ping-pong) kernel, all measured neutral-to-negative and off by default:
+//   knob 0: per-XCD first-round start stagger, percent of an eighth of the estimated tile time (0 = off)
+//   knob 1: tile-rows per XCD patch group (0 = the default 8)
+extern "C" int licv_gemm_experiment(int knob, int value) {
+    if (knob == 0) g_pp_stagger = value; else if (knob == 1) g_pp_group = value;
+    else return licv_set_error(LICV_E_BADARG, "gemm_experiment: unknown knob %d", knob);
     return LICV_OK;
 }
 static int g_num_cus = 256;        // persistent grid size (queried once)

@@ -72,6 +72,8 @@ def lib() -> C.CDLL:
             "licv_pack_gate_up": [P, P, P, I64, I64, P],
             "licv_gemm_select": [I],
             "licv_gemm_stagger": [I],
+            "licv_gemm_experiment": [I, I],
+            "licv_gemm_debug_timestamps": [P],
             "licv_attn_select": [I],
             "licv_attn_fwd": [C.POINTER(AttnArgs), P],
             "licv_embed_gather": [P, P, P, P, I64, I64, I64, I64, P],

@@ -3,7 +3,6 @@ import sys, ctypes, torch
 sys.path.insert(0,'licv-vqa_amd'); sys.path.insert(0,'.')
 from licv import ops, _lib
 lib=_lib.lib()
-lib.licv_gemm_debug_timestamps.argtypes=[ctypes.c_void_p]; lib.licv_gemm_debug_timestamps.restype=ctypes.c_int
 cases=[(67848,5120,1280,'gelu'),(67848,1280,5120,'res16'),(67848,3840,1280,'bias'),(67848,1280,1280,'res16'),
        (6400,22016,4096,'swiglu'),(6400,4096,11008,'res32'),(6400,12288,4096,'none'),(6400,4096,4096,'res32')]
 if len(sys.argv)>1: cases=[tuple(int(x) if x.isdigit() else x for x in a.split(',')) for a in sys.argv[1:]]

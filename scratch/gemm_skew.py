@@ -14,8 +14,8 @@ for (M,N,K,epi) in cases:
         'swiglu':dict(swiglu=True),'none':{}}[epi]
     line=f"{M:6d} {N:6d} {K:6d} {epi:7s}"
     base=None
-    for skew in (108,104,102,116,132,108):
-        lib.licv_gemm_stagger(100+skew)  # 200+group
+    for skew in (8,4,2,16,32,8):
+        lib.licv_gemm_experiment(1, skew)   # knob 1 = patch group height (knob 0 = start stagger %)
         for _ in range(2): o=ops.linear(a,w,**kw)
         torch.cuda.synchronize()
         e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True)
@@ -28,4 +28,4 @@ for (M,N,K,epi) in cases:
         err=float((o.float()-base).abs().max()/base.abs().max())
         line+=f" | skew{skew}: {2*M*N*K/t/1e12:7.1f} TF ({t*1e6:7.1f} us, d={err:.1e})"
     print(line, flush=True)
-lib.licv_gemm_stagger(200)
+lib.licv_gemm_experiment(1, 0)
