@@ -122,3 +122,23 @@ def test_padding_rows_do_not_leak_into_real_rows():
     l2 = eng.forward(**{**b, "input_ids": ids2})
     keep = b["attention_mask"].bool()
     assert torch.equal(l1[keep], l2[keep])
+
+
+def test_idefics_single_row_single_image_and_blind_rows(golden):
+    """Edge cases against the CPU oracle: batch of one; a row whose tokens see no image at all (cross-attention gate 0 on
+    every token: hf:idefics/modeling_idefics.py:1040-1048); hooks on one layer only."""
+    arch = IDEFICS_TINY
+    eng, sd32 = _engine(arch, 5)
+    sdb = {k: v.to(torch.bfloat16) for k, v in sd32.items()}
+    for B in (1, 2):
+        batch = synth_vqa_batch(arch, B, 12, 1, seed=9 + B, min_len=9, dtype=torch.float32)
+        batch["image_attention_mask"][-1] = 0                        # last row: blind to every image
+        icv = torch.randn(1, 1, arch.hidden_size, generator=torch.Generator().manual_seed(3)) * 0.05
+        got = eng.forward(**{k: v.to(DEV) for k, v in batch.items()}, icv=icv.to(DEV), hook_layers=[2])
+        kw = dict(batch)
+        kw["pixel_values"] = batch["pixel_values"].to(torch.bfloat16)
+        with torch.no_grad():
+            ref = R.forward(sdb, arch, **kw, icv=icv, hook_layers=[2]).float()
+        valid = batch["attention_mask"].bool()
+        err = (got.float().cpu() - ref)[valid].abs().max()
+        assert err <= 1.5e-2 * ref.abs().max(), f"B={B}: {float(err):.3e}"

@@ -148,3 +148,27 @@ def test_idefics2_hooked_generate_token_ids(golden, side):
         agree = (o16 == gold).all(dim=1)
         assert torch.equal(got[agree], gold[agree]), key
         assert agree.float().mean() >= 0.6, "bf16 and fp32 reference decodes diverge on too many rows to be a useful check"
+
+
+def test_idefics2_text_only_and_single_token(golden):
+    """Edge cases: no images at all (pixel_values=None), a batch of one, and a one-token sequence — against the CPU oracle."""
+    import oracle.idefics2_ref as R2
+    arch = IDEFICS2_TINY
+    eng, sd32 = _engine(arch, 7)
+    sdb = {k: v.to(torch.bfloat16) for k, v in sd32.items()}
+    g = torch.Generator().manual_seed(11)
+    icv = torch.randn(1, arch.num_layers, arch.hidden_size, generator=g) * 0.05
+    layers = list(range(arch.num_layers))
+    for B, S in ((1, 1), (1, 9), (3, 17)):
+        ids = torch.randint(3, arch.image_token_id - 1, (B, S), generator=g)
+        am = torch.ones(B, S, dtype=torch.long)
+        if S > 4:
+            am[-1, S - 3:] = 0
+            ids[-1, S - 3:] = arch.pad_token_id
+        got = eng.forward(ids.to(DEV), am.to(DEV), icv=icv.to(DEV), hook_layers=layers)
+        with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+            ref = R2.forward(sdb, arch, ids, am, icv=icv, hook_layers=layers).float()
+        assert got.shape == ref.shape
+        valid = am.bool()
+        err = (got.float().cpu() - ref)[valid].abs().max()
+        assert err <= 1.5e-2 * ref.abs().max(), f"B={B} S={S}: {float(err):.3e}"
