@@ -42,6 +42,8 @@ WORKLOADS = {
     "idefics2_mid_debug": ("idefics2-mid", 2, 40, 2, 30),
     # BASELINE configs[4] shape (SURVEY "I2-32") in bf16: 33 images per question, S ~ 33*66 + 700; the fp8-weight GEMM it names is not built
     "idefics2_8b_32shot_bs8": ("idefics2-8b", 8, 2900, 33, 2800),
+    # the same with the text stack's GEMMs on e4m3 operands (W8A8, per-channel / per-row scales, fp32 accumulate)
+    "idefics2_8b_32shot_fp8_bs8": ("idefics2-8b", 8, 2900, 33, 2800),
     # Idefics2 L-ICV training micro-batch: teacher 32-shot (no grad) + student query-only (grad) + KL + backward
     "idefics2_8b_train_bs8": ("idefics2-8b", 8, 2900, 33, 2800),
     "idefics2_mid_train_debug": ("idefics2-mid", 2, 60, 3, 50),
@@ -224,7 +226,7 @@ def main():
         trainer, train_args = build_trainer(arch, sd, dev, B, S, n_img, min_len, rank, hw=IDEFICS2_IMAGE[preset] if is2 else None)
         eng = trainer.m.interface.engine
     elif is2:
-        eng = Idefics2Engine(Idefics2Weights(sd, arch, dev))
+        eng = Idefics2Engine(Idefics2Weights(sd, arch, dev, fp8_text="fp8" in args.workload))
     else:
         eng = IdeficsEngine(IdeficsWeights(sd, arch, dev))
     del sd
@@ -290,7 +292,7 @@ def main():
                    "VQA questions/sec (whole node), Idefics-9B 32-shot ICV forward"),
         "value": qps, "unit": "questions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16", "data": f"synthetic (random-init {preset} weights, seeded image+text batches)",
+        "dtype": "fp8 e4m3 text-stack GEMM operands (fp32 accumulate), bf16 elsewhere" if "fp8" in args.workload else "bf16", "data": f"synthetic (random-init {preset} weights, seeded image+text batches)",
         "config": {"workload": args.workload, "arch": preset, "questions_per_gpu": B, "seq_len": S, "images_per_question": n_img,
                    "hooked_layers": 0 if args.no_hooks else arch.num_layers, "parallelism": f"dp{world}",
                    **({"train": "teacher fwd + student fwd/bwd + KL; accumulate 2; 1 all-reduce of 131 105 fp32 + AdamW per optimiser step"} if training else {})},

@@ -104,6 +104,16 @@ typedef struct {
 
 int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
                    int64_t M, int64_t N, int64_t K, const licv_gemm_epilogue* ep, void* stream);
+/* ---- fp8 path (BASELINE configs[4]: "fp8 weights on CDNA4 MFMA"; no reference counterpart — parity bar in DESIGN.md) ----
+ * q[r,k] = e4m3(x[r,k] / scale[r]), scale[r] = amax(x[r,:]) / 448 (OCP e4m3fn, round to nearest even).  Weights are quantised
+ * once with the same kernel (rows = output channels); activations per call. */
+int licv_quantize_rows_fp8(const void* x, int x_dtype, void* q_fp8, float* scale, int64_t rows, int64_t dim,
+                           int64_t ld_x, int64_t ld_q, void* stream);
+/* C = epilogue( (Aq . Wq^T) * a_scale[m] * w_scale[n] ), fp32 accumulate on v_mfma_f32_16x16x32_fp8_fp8; same epilogue
+ * struct as licv_gemm_bf16.  Aq (M, K) and Wq (N, K) e4m3 bytes, K >= 256, K % 64 == 0, leading dims in bytes. */
+int licv_gemm_fp8(const void* Aq, int64_t lda, const float* a_scale, const void* Wq, int64_t ldw, const float* w_scale,
+                  void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, const licv_gemm_epilogue* e, void* stream);
+
 /* Kernel selection override for tests and A/B timing: 0 = automatic (256x256 LDS-DMA kernel when M >= 512,
  * N >= 256 and K % 64 == 0; else the general 128x128 kernel), 1 = always the 128x128 kernel, 2 = the 256x256
  * kernel whenever K % 64 == 0.  Process-wide. */

@@ -35,6 +35,8 @@ struct GemmEpi {
     int use_scale;
     float scale;
     int out_dtype;
+    const float* a_scale;       // fp8 GEMM only: per-row scale of the quantised activations ...
+    const float* w_scale;       // ... and per-output-channel scale of the quantised weights (NULL for bf16 operands)
 };
 
 // Activations evaluated on bf16-rounded inputs and rounded to bf16 again by the caller, so ~1e-6 relative
@@ -396,7 +398,7 @@ extern "C" int licv_gemm_debug_timestamps(void* dev_buffer) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_ts), &p, sizeof(p)) == hipSuccess ? LICV_OK : LICV_E_HIP;
 }
 
-template <int TM, int TN, int NWAVES, int MT, int NT>
+template <int TM, int TN, int NWAVES, int MT, int NT, bool SCALED = false>
 __device__ __forceinline__ void epilogue_staged(floatx4 (&acc)[MT][NT], const GemmEpi& ep, void* __restrict__ C, int64_t ldc,
                                                 int M, int N, int m0, int n0, int wrow0, int wcol0, int wave, int lane, char* smem,
                                                 long long* ts = nullptr, const float (*bias_pre)[4] = nullptr) {
@@ -413,13 +415,28 @@ __device__ __forceinline__ void epilogue_staged(floatx4 (&acc)[MT][NT], const Ge
             for (int r = 0; r < 4; ++r)
                 bv[j][r] = bias_pre ? bias_pre[j][r] : ((ep.bias && ncol + r < N) ? bf2f(ep.bias[ncol + r]) : 0.f);
         });
+        float cs[NT][4];
+        if (SCALED) {
+            static_for<0, NT>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                const int ncol = n0 + wcol0 + j * 16 + cq;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cs[j][r] = ncol + r < N ? ep.w_scale[ncol + r] : 0.f;
+            });
+        }
         static_for<0, MT>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
+            const float rs = SCALED ? ep.a_scale[min(m0 + rl + i * 16, M - 1)] : 1.0f;
             static_for<0, NT>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
                 uint2 u;
-                u.x = (uint32_t)f2bf(acc[i][j][0] + bv[j][0]) | ((uint32_t)f2bf(acc[i][j][1] + bv[j][1]) << 16);
-                u.y = (uint32_t)f2bf(acc[i][j][2] + bv[j][2]) | ((uint32_t)f2bf(acc[i][j][3] + bv[j][3]) << 16);
+                if (SCALED) {       // fp8 operands: C = (Aq . Wq^T) * a_scale[m] * w_scale[n]
+                    u.x = (uint32_t)f2bf(acc[i][j][0] * rs * cs[j][0] + bv[j][0]) | ((uint32_t)f2bf(acc[i][j][1] * rs * cs[j][1] + bv[j][1]) << 16);
+                    u.y = (uint32_t)f2bf(acc[i][j][2] * rs * cs[j][2] + bv[j][2]) | ((uint32_t)f2bf(acc[i][j][3] * rs * cs[j][3] + bv[j][3]) << 16);
+                } else {
+                    u.x = (uint32_t)f2bf(acc[i][j][0] + bv[j][0]) | ((uint32_t)f2bf(acc[i][j][1] + bv[j][1]) << 16);
+                    u.y = (uint32_t)f2bf(acc[i][j][2] + bv[j][2]) | ((uint32_t)f2bf(acc[i][j][3] + bv[j][3]) << 16);
+                }
                 *reinterpret_cast<uint2*>(smem + (rl + i * 16) * YS + (wcol0 + j * 16 + cq) * 2) = u;
             });
         });
@@ -643,11 +660,6 @@ void gemm_bf16_pingpong_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_
         const int chunk = (lane & 3) ^ (((row >> 2) & 1) << 1);
         srcA[i] = A + (int64_t)min(m0 + row, M - 1) * lda + chunk * 8;
         srcW[i] = W + (int64_t)min(n0 + row, N - 1) * ldw + chunk * 8;
-        if (ABL == 2) {       // WRONG RESULTS, timing only: a piece = 8 rows x 128 B instead of 16 rows x 64 B
-            const int r2 = wave * 32 + i * 16 + (lane >> 3), c2 = lane & 7;
-            srcA[i] = A + (int64_t)min(m0 + r2, M - 9) * lda + c2 * 8;
-            srcW[i] = W + (int64_t)min(n0 + r2, N - 9) * ldw + c2 * 8;
-        }
     }
     const int ns = K / 32;                                   // >= 4 (host guarantees K >= 128)
     // First-round start stagger by XCD (blockIdx % 8): every tile of a GEMM takes the same time, so all 256 CUs reach
@@ -661,12 +673,8 @@ void gemm_bf16_pingpong_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_
     auto issue = [&](int s) {
         char* sa = smem + (s % RING_STAGES) * RING_STAGE_BYTES + wave * 32 * 64;
         char* sw = sa + 16384;
-        int64_t koff = (int64_t)s * 32;
-        int64_t koffw = koff;
-        if (ABL == 2) {            // timing-only: whole 128-B lines, each fetched once: odd stages take the other 8 rows
-            koff = (int64_t)(s >> 1) * 64 + (int64_t)(s & 1) * 8 * lda;
-            koffw = (int64_t)(s >> 1) * 64 + (int64_t)(s & 1) * 8 * ldw;
-        }
+        if (ABL == 2) return;                                    // timing-only ablation: no operand stream at all
+        const int64_t koff = (int64_t)s * 32, koffw = koff;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + koff),
@@ -696,10 +704,12 @@ void gemm_bf16_pingpong_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_
         {
             const char* sa = smem + (s % RING_STAGES) * RING_STAGE_BYTES + (wm * 128) * 64 + fo;
             const char* sw = smem + (s % RING_STAGES) * RING_STAGE_BYTES + 16384 + (wn * 64) * 64 + fo;
+            if (ABL != 3 || s == 0) {                            // ABL 3 (timing only): fragments read once, never again
 #pragma unroll
-            for (int j = 0; j < 4; ++j) fw[j] = *reinterpret_cast<const bf16x8*>(sw + j * 16 * 64);
+                for (int j = 0; j < 4; ++j) fw[j] = *reinterpret_cast<const bf16x8*>(sw + j * 16 * 64);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 64);
+                for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 64);
+            }
             if (s + 4 < ns) issue(s + 4);
             wait_vmcnt(4 * max(0, min(3, ns - 2 - s)));      // retire my pieces of stage s+1; later stages stay in flight
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -709,11 +719,18 @@ void gemm_bf16_pingpong_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_
         // ---- COMPUTE phase (partner loads)
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
+        if (ABL != 4) {                                          // ABL 4 (timing only): no MFMAs
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+            for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("" :: "v"(fa[i]));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(fw[j]));
+        }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -729,6 +746,90 @@ void gemm_bf16_pingpong_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_
     }
     epilogue_staged<256, 256, 8, 8, 4>(acc, ep, C, ldc, M, N, m0, n0, wm * 128, wn * 64, wave, lane, smem, ts);
     if (ts) ts[4] = wall_clock64();
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp8 (OCP e4m3) operands: the SAME kernel in bytes — a ring stage is still 64 B per operand row (= 64 fp8 K-elements
+// instead of 32 bf16), the DMA, swizzle and fragment reads are byte-identical; each 16-byte fragment feeds two
+// v_mfma_f32_16x16x32_fp8_fp8 (its low and high 8 bytes: A and W use the same byte -> k assignment, and a dot product
+// does not care in which order k is visited).  The operand stream, which bounds the bf16 kernel, halves per K; the fp8
+// MFMA runs at the bf16 rate per K, so a stage (K = 64) is MFMA-bound at ~0.43 us per 32 K.  Per-row activation scales
+// and per-output-channel weight scales are applied to the fp32 accumulators in phase A of the epilogue.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2)
+void gemm_fp8_pingpong_k(const char* __restrict__ A, int64_t lda, const char* __restrict__ W, int64_t ldw,
+                         void* __restrict__ C, int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n, GemmEpi ep) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // [5 stages][A 16 KiB | W 16 KiB]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    int tm, tn;
+    tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * 256, n0 = tn * 256;
+    const char* srcA[2];
+    const char* srcW[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = wave * 32 + i * 16 + (lane >> 2);
+        const int chunk = (lane & 3) ^ (((row >> 2) & 1) << 1);
+        srcA[i] = A + (int64_t)min(m0 + row, M - 1) * lda + chunk * 16;
+        srcW[i] = W + (int64_t)min(n0 + row, N - 1) * ldw + chunk * 16;
+    }
+    const int ns = K / 64;                                   // >= 4 (host guarantees K >= 256)
+    auto issue = [&](int s) {
+        char* sa = smem + (s % RING_STAGES) * RING_STAGE_BYTES + wave * 32 * 64;
+        char* sw = sa + 16384;
+        const int64_t koff = (int64_t)s * 64;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + koff),
+                                             (__attribute__((address_space(3))) void*)(sa + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[i] + koff),
+                                             (__attribute__((address_space(3))) void*)(sw + i * 1024), 16, 0, 0);
+        }
+    };
+    floatx4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    const int fo = ring_off(lane & 15, lane >> 4);
+    typedef __attribute__((ext_vector_type(2))) long long2_t;
+    long2_t fa[8], fw[4];
+
+    issue(0); issue(1); issue(2); issue(3);
+    wait_vmcnt(12);
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();
+    for (int s = 0; s < ns; ++s) {
+        {
+            const char* sa = smem + (s % RING_STAGES) * RING_STAGE_BYTES + (wm * 128) * 64 + fo;
+            const char* sw = smem + (s % RING_STAGES) * RING_STAGE_BYTES + 16384 + (wn * 64) * 64 + fo;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fw[j] = *reinterpret_cast<const long2_t*>(sw + j * 16 * 64);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const long2_t*>(sa + i * 16 * 64);
+            if (s + 4 < ns) issue(s + 4);
+            wait_vmcnt(4 * max(0, min(3, ns - 2 - s)));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(fw[j][0], fa[i][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(fw[j][1], fa[i][1], acc[i][j], 0, 0, 0);
+            }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();
+    epilogue_staged<256, 256, 8, 8, 4, true>(acc, ep, C, ldc, M, N, m0, n0, wm * 128, wn * 64, wave, lane, smem);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -999,6 +1100,7 @@ extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
     ep.bias = (const bf16_t*)e->bias_bf16; ep.row_gate = e->row_gate; ep.residual = e->residual;
     ep.residual_dtype = e->residual_dtype; ep.ld_res = e->ld_res; ep.act = e->act; ep.swiglu = e->swiglu;
     ep.use_scale = e->use_scale; ep.scale = e->scale; ep.out_dtype = e->out_dtype;
+    ep.a_scale = nullptr; ep.w_scale = nullptr;
     static bool attr_set = false;
     if (!attr_set) {
         int dev = 0, cus = 0;
@@ -1009,6 +1111,8 @@ extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
         hipFuncSetAttribute((const void*)gemm_bf16_pingpong_k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
         hipFuncSetAttribute((const void*)gemm_bf16_pingpong_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
         hipFuncSetAttribute((const void*)gemm_bf16_pingpong_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
+        hipFuncSetAttribute((const void*)gemm_bf16_pingpong_k<3>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
+        hipFuncSetAttribute((const void*)gemm_bf16_pingpong_k<4>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
         hipFuncSetAttribute((const void*)gemm_bf16_ring_k, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
         hipFuncSetAttribute((const void*)gemm_bf16_tile256_k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, T256_LDS);
         hipFuncSetAttribute((const void*)gemm_bf16_tile256_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, T256_LDS);
@@ -1034,9 +1138,12 @@ extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
         else if (g_force_kernel == 7 && K >= 128)
             gemm_bf16_pingpong_k<1><<<grid, block, RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>(
                 (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, pp_ticks, pp_group);
-        else if (g_force_kernel == 10 && K >= 128)       // timing-only ablation: full-line DMA pieces (wrong results)
-            gemm_bf16_pingpong_k<2><<<grid, block, RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>(
-                (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, pp_ticks, pp_group);
+        else if (g_force_kernel >= 10 && g_force_kernel <= 12 && K >= 128) {      // timing-only ablations of the main loop (wrong results)
+#define PP_ABL(X) gemm_bf16_pingpong_k<X><<<grid, block, RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>( \
+                (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, pp_ticks, pp_group)
+            if (g_force_kernel == 10) PP_ABL(2); else if (g_force_kernel == 11) PP_ABL(3); else PP_ABL(4);
+#undef PP_ABL
+        }
         else if (g_force_kernel == 6 && K >= 128)
             gemm_bf16_pingpong_k<0><<<grid, block, RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>(
                 (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, pp_ticks, pp_group);
@@ -1055,6 +1162,32 @@ extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
         gemm_bf16_tile128_k<<<dim3(tiles_m * tiles_n), dim3(256), 65536, (hipStream_t)stream>>>(
             (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep);
     }
+    LICV_LAUNCH_CHECK();
+    return LICV_OK;
+}
+
+extern "C" int licv_gemm_fp8(const void* Aq, int64_t lda, const float* a_scale, const void* Wq, int64_t ldw, const float* w_scale,
+                             void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, const licv_gemm_epilogue* e, void* stream) {
+    LICV_CHECK_ARG(Aq && Wq && a_scale && w_scale && C && e, "gemm_fp8: null pointer");
+    LICV_CHECK_ARG(M > 0 && N > 0 && K >= 256 && K % 64 == 0, "gemm_fp8: needs K >= 256 and K %% 64 == 0 (M=%lld N=%lld K=%lld)", (long long)M, (long long)N, (long long)K);
+    LICV_CHECK_ARG(lda >= K && ldw >= K && lda % 16 == 0 && ldw % 16 == 0, "gemm_fp8: leading dims (bytes) must be >= K and multiples of 16");
+    LICV_CHECK_ARG(ldc % 4 == 0, "gemm_fp8: ldc (%lld) must be a multiple of 4", (long long)ldc);
+    LICV_CHECK_ARG(((uintptr_t)Aq & 15) == 0 && ((uintptr_t)Wq & 15) == 0 && ((uintptr_t)C & 15) == 0, "gemm_fp8: pointers must be 16-byte aligned");
+    LICV_CHECK_ARG(e->out_dtype == LICV_BF16 || e->out_dtype == LICV_F32, "gemm_fp8: bad out dtype");
+    LICV_CHECK_ARG(e->act >= 0 && e->act <= 3, "gemm_fp8: bad activation %d", e->act);
+    LICV_CHECK_ARG(!e->swiglu || (N % 32 == 0 && !e->bias_bf16 && !e->act), "gemm_fp8: swiglu needs N %% 32 == 0, no bias/act");
+    LICV_CHECK_ARG(!e->residual || (e->ld_res % 4 == 0 && ((uintptr_t)e->residual & 15) == 0), "gemm_fp8: residual misaligned");
+    LICV_CHECK_ARG(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), "gemm_fp8: dimension too large");
+    GemmEpi ep;
+    ep.bias = (const bf16_t*)e->bias_bf16; ep.row_gate = e->row_gate; ep.residual = e->residual;
+    ep.residual_dtype = e->residual_dtype; ep.ld_res = e->ld_res; ep.act = e->act; ep.swiglu = e->swiglu;
+    ep.use_scale = e->use_scale; ep.scale = e->scale; ep.out_dtype = e->out_dtype;
+    ep.a_scale = a_scale; ep.w_scale = w_scale;
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute((const void*)gemm_fp8_pingpong_k, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES); attr = true; }
+    const int tiles_m = (int)((M + 255) / 256), tiles_n = (int)((N + 255) / 256);
+    gemm_fp8_pingpong_k<<<dim3(tiles_m * tiles_n), dim3(512), RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>(
+        (const char*)Aq, lda, (const char*)Wq, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep);
     LICV_LAUNCH_CHECK();
     return LICV_OK;
 }

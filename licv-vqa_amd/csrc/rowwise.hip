@@ -358,6 +358,33 @@ void headnorm_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, cons
     store8_bf16(out + ro * ld_out + ri * dim + sub * 8, y);
 }
 
+// Dynamic per-row quantisation to OCP fp8 e4m3 for the fp8 GEMM (BASELINE configs[4]): scale[r] = amax(x[r, :]) / 448,
+// q[r, k] = e4m3(x[r, k] / scale[r]) (round to nearest even; |x / scale| <= 448 by construction, so nothing saturates).
+// The same kernel quantises weights offline (rows = output channels).  One wave per row, the row held in registers.
+template <int DT>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK)
+void quantize_rows_fp8_k(const void* __restrict__ x, uint8_t* __restrict__ q, float* __restrict__ scale, int64_t rows, int dim,
+                         int64_t ld_x, int64_t ld_q) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float amax = 0.f;
+    for (int i = lane * 4; i < dim; i += 256) {
+        const floatx4 v = RowIO<DT>::load4(x, row * ld_x + i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fabsf(v[j]));
+    }
+    amax = wave_max(amax);
+    const float sc = fmaxf(amax, 1e-12f) / 448.0f;
+    if (lane == 0) scale[row] = sc;
+    for (int i = lane * 4; i < dim; i += 256) {                 // second sweep: the row (<= 64 KB) is still in L2
+        const floatx4 v = RowIO<DT>::load4(x, row * ld_x + i);
+        int w = __builtin_amdgcn_cvt_pk_fp8_f32(v[0] / sc, v[1] / sc, 0, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(v[2] / sc, v[3] / sc, w, true);
+        *reinterpret_cast<int*>(q + row * ld_q + i) = w;
+    }
+}
+
 // ViT embeddings + pre-LN: hf:idefics/vision.py:152-166 then :369
 template <int NCH>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK)
@@ -621,6 +648,21 @@ extern "C" int licv_rmsnorm_fwd(const void* x, int x_dtype, const void* w, void*
 #define LAUNCH_RMS(DTV) rmsnorm_fwd_k<DTV, N><<<grid, block, 0, st>>>(x, (const bf16_t*)w, (bf16_t*)out, rows, (int)dim, inner, ld_x, ld_out, eps, flavour)
     if (x_dtype == LICV_F32) { DISPATCH_NCH(nch, LAUNCH_RMS(LICV_F32)); } else { DISPATCH_NCH(nch, LAUNCH_RMS(LICV_BF16)); }
 #undef LAUNCH_RMS
+    LICV_LAUNCH_CHECK();
+    return LICV_OK;
+}
+
+extern "C" int licv_quantize_rows_fp8(const void* x, int x_dtype, void* q_fp8, float* scale, int64_t rows, int64_t dim,
+                                      int64_t ld_x, int64_t ld_q, void* stream) {
+    LICV_CHECK_ARG(x && q_fp8 && scale, "quantize_rows_fp8: null pointer");
+    LICV_CHECK_ARG(dim > 0 && dim % 4 == 0 && ld_x % 4 == 0 && ld_q % 4 == 0 && ld_x >= dim && ld_q >= dim,
+                   "quantize_rows_fp8: dim and leading dims must be multiples of 4 (dim %lld)", (long long)dim);
+    LICV_CHECK_ARG(x_dtype == LICV_BF16 || x_dtype == LICV_F32, "quantize_rows_fp8: bad dtype %d", x_dtype);
+    if (rows <= 0) return LICV_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(row_blocks(rows)), block(64 * WAVES_PER_BLOCK);
+    if (x_dtype == LICV_F32) quantize_rows_fp8_k<LICV_F32><<<grid, block, 0, st>>>(x, (uint8_t*)q_fp8, scale, rows, (int)dim, ld_x, ld_q);
+    else                     quantize_rows_fp8_k<LICV_BF16><<<grid, block, 0, st>>>(x, (uint8_t*)q_fp8, scale, rows, (int)dim, ld_x, ld_q);
     LICV_LAUNCH_CHECK();
     return LICV_OK;
 }

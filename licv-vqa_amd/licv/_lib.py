@@ -70,6 +70,8 @@ def lib() -> C.CDLL:
             "licv_rotary_fwd": [P, P, P, P, I64, I64, I64, I64, I64, I, I64, P],
             "licv_gemm_bf16": [P, I64, P, I64, P, I64, I64, I64, I64, C.POINTER(GemmEpilogue), P],
             "licv_pack_gate_up": [P, P, P, I64, I64, P],
+            "licv_quantize_rows_fp8": [P, I, P, P, I64, I64, I64, I64, P],
+            "licv_gemm_fp8": [P, I64, P, P, I64, P, P, I64, I64, I64, I64, P, P],
             "licv_gemm_select": [I],
             "licv_gemm_stagger": [I],
             "licv_gemm_experiment": [I, I],

@@ -41,14 +41,18 @@ class _PercLayer:
 class _TextLayer:
     in_ln: torch.Tensor; qkv_w: torch.Tensor; o_w: torch.Tensor; post_ln: torch.Tensor
     gu_w: torch.Tensor; down_w: torch.Tensor
+    q8: Optional[dict] = None           # fp8 copies {name: (e4m3 bytes (N, K), per-output-channel scale (N,))} when fp8_text
 
 
 class Idefics2Weights:
     """Engine-layout weights from an HF-named ``Idefics2ForConditionalGeneration`` state dict (bf16)."""
 
-    def __init__(self, sd: Dict[str, torch.Tensor], arch: Idefics2Arch, device="cuda", max_positions: int = 4096):
+    def __init__(self, sd: Dict[str, torch.Tensor], arch: Idefics2Arch, device="cuda", max_positions: int = 4096,
+                 fp8_text: bool = False):
+        """fp8_text (BASELINE configs[4], "fp8 weights"): the text stack's projection weights are ALSO stored as OCP e4m3 with one
+        scale per output channel; GEMMs with >= 512 rows then quantise their input per row and run on the fp8 MFMA."""
         a, dev = arch, torch.device(device)
-        self.arch, self.device = arch, dev
+        self.arch, self.device, self.fp8_text = arch, dev, fp8_text
         g = lambda k: _bf(sd[k], dev)
         cat = lambda p, names, suf: torch.cat([g(p + f"{n}.{suf}") for n in names]).contiguous()
         vp = "model.vision_model."
@@ -99,6 +103,10 @@ class Idefics2Weights:
                                         g(p + "self_attn.o_proj.weight"), g(p + "post_attention_layernorm.weight"),
                                         ops.pack_gate_up(g(p + "mlp.gate_proj.weight"), g(p + "mlp.up_proj.weight")),
                                         g(p + "mlp.down_proj.weight")))
+        if fp8_text:
+            ok = lambda w_: w_.shape[1] >= 256 and w_.shape[1] % 64 == 0
+            for L in self.text:
+                L.q8 = {n: ops.quantize_fp8(getattr(L, n)) for n in ("qkv_w", "o_w", "gu_w", "down_w") if ok(getattr(L, n))}
         self.final_ln = g(tp + "norm.weight")
         self.lm_head = g("lm_head.weight")
         # rotary tables: fp32 inv_freq and angles, cast to the model dtype (hf:mistral/modeling_mistral.py MistralRotaryEmbedding)
@@ -215,6 +223,15 @@ class Idefics2Engine:
         return ops.rmsnorm(lat, w.perc_ln, a.rms_eps, 1)
 
     # ----------------------------------------------------------------------------------- text side
+    @staticmethod
+    def _tlin(x: torch.Tensor, L: _TextLayer, name: str, **kw) -> torch.Tensor:
+        """A text-stack projection: fp8 operands when the layer carries fp8 weights and the GEMM is large, else bf16."""
+        if L.q8 is not None and name in L.q8 and x.shape[0] >= 512:
+            xq, xs = ops.quantize_fp8(x)
+            wq, ws = L.q8[name]
+            return ops.linear_fp8(xq, xs, wq, ws, **kw)
+        return ops.linear(x, getattr(L, name), **kw)
+
     def forward(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
                 pixel_values: Optional[torch.Tensor] = None, pixel_attention_mask: Optional[torch.Tensor] = None,
                 image_hidden_states: Optional[torch.Tensor] = None, icv: Optional[torch.Tensor] = None,
@@ -260,7 +277,7 @@ class Idefics2Engine:
         for l, L in enumerate(w.text):
             x = xn if xn is not None else ops.rmsnorm(h, L.in_ln, a.rms_eps, 1)
             xn = None
-            qkv = ops.linear(x, L.qkv_w)
+            qkv = self._tlin(x, L, "qkv_w")
             ops.rotary_(qkv, w.cos, w.sin, pos, M, nh, hd, ldq, qd, 1)
             ops.rotary_(qkv.view(-1)[qd:], w.cos, w.sin, pos, M, nkv, hd, ldq, kd, 1)
             if kv_cache is None:
@@ -271,13 +288,13 @@ class Idefics2Engine:
                 cache[:, past:Sk] = qkv.view(B, S, ldq)[:, :, qd:]                         # append K|V (device copy)
                 o = ops.attention(qkv, cache, cache.view(-1)[kd:], B, S, Sk, nh, nkv, hd, S * ldq, ldq, kv_cache.max_len * 2 * kd, 2 * kd,
                                   hd ** -0.5, 1, key_valid=key_valid)
-            ops.linear(o.view(M, qd), L.o_w, residual=h, out=h)
+            self._tlin(o.view(M, qd), L, "o_w", residual=h, out=h)
             x = ops.rmsnorm(h, L.post_ln, a.rms_eps, 1)
-            act = ops.linear(x, L.gu_w, swiglu=True)
+            act = self._tlin(x, L, "gu_w", swiglu=True)
             del qkv, o, x
             if l in idx_of:
                 i = idx_of[l]
-                m = ops.linear(act, L.down_w)                                              # raw MLP branch (bf16)
+                m = self._tlin(act, L, "down_w")                                           # raw MLP branch (bf16)
                 if capture is not None:
                     capture.setdefault("mlp_raw", []).append(m.view(B, S, H).clone())
                 al = alpha[0, i:i + 1] if alpha is not None else None
@@ -290,7 +307,7 @@ class Idefics2Engine:
             else:
                 if capture is not None:
                     capture.setdefault("mlp_raw", []).append(ops.linear(act, L.down_w).view(B, S, H).clone())
-                ops.linear(act, L.down_w, residual=h, out=h)
+                self._tlin(act, L, "down_w", residual=h, out=h)
             del act
             if capture is not None:
                 capture.setdefault("layer_out", []).append(h.view(B, S, H).clone())

@@ -191,6 +191,49 @@ def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     return out if ret is None else ret
 
 
+def quantize_fp8(x: torch.Tensor):
+    """Per-row dynamic quantisation to OCP e4m3: returns (q uint8 (rows, K), scale fp32 (rows,))."""
+    assert x.dim() == 2 and x.stride(1) == 1
+    rows, K = x.shape
+    q = torch.empty((rows, K), dtype=torch.uint8, device=x.device)
+    sc = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    check(_lib.lib().licv_quantize_rows_fp8(_p(x), _dt(x), _p(q), _p(sc), rows, K, x.stride(0), K, _stream(x)))
+    return q, sc
+
+
+def linear_fp8(aq: torch.Tensor, a_scale: torch.Tensor, wq: torch.Tensor, w_scale: torch.Tensor, bias: Optional[torch.Tensor] = None,
+               act=None, swiglu: bool = False, row_gate: Optional[torch.Tensor] = None, scale: Optional[float] = None,
+               residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None):
+    """out = epilogue((aq @ wq.T) * a_scale[:, None] * w_scale[None, :]) on the fp8 MFMA; aq (M, K), wq (N, K) uint8 e4m3."""
+    assert aq.dtype == torch.uint8 and wq.dtype == torch.uint8 and aq.is_contiguous() and wq.is_contiguous()
+    M, K = aq.shape
+    N = wq.shape[0]
+    n_out = N // 2 if swiglu else N
+    if out_dtype is None:
+        out_dtype = residual.dtype if residual is not None else torch.bfloat16
+    ret = None
+    if out is None:
+        ldc = (n_out + 7) // 8 * 8
+        out = torch.empty((M, ldc), dtype=out_dtype, device=aq.device)
+        ret = out if ldc == n_out else out[:, :n_out]
+    else:
+        ldc = out.stride(0)
+    ep = GemmEpilogue()
+    ep.bias_bf16 = bias.data_ptr() if bias is not None else None
+    ep.row_gate = row_gate.data_ptr() if row_gate is not None else None
+    ep.residual = residual.data_ptr() if residual is not None else None
+    ep.residual_dtype = _dt(residual) if residual is not None else 0
+    ep.ld_res = residual.stride(0) if residual is not None else n_out
+    ep.act = ACT[act]
+    ep.swiglu = 1 if swiglu else 0
+    ep.use_scale = 0 if scale is None else 1
+    ep.scale = 0.0 if scale is None else float(scale)
+    ep.out_dtype = _dt(out)
+    _timed("gemm", 2.0 * M * N * K, lambda: check(_lib.lib().licv_gemm_fp8(
+        _p(aq), K, _p(a_scale), _p(wq), K, _p(w_scale), _p(out), ldc, M, N, K, C.byref(ep), _stream(aq))), label=(M, N, K))
+    return out if ret is None else ret
+
+
 def pack_gate_up(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
     _bf16c(gate, "gate"); _bf16c(up, "up")
     inter, K = gate.shape

@@ -1,0 +1,70 @@
+"""fp8 path (BASELINE configs[4], "fp8 weights on CDNA4 MFMA").  The reference has no fp8 mode, so parity is defined in two layers:
+  kernel level (exact):  the quantiser reproduces torch's e4m3fn cast byte for byte; the fp8 GEMM equals the fp64 product of
+                         the DEQUANTISED operands within one bf16 rounding of the output (the only freedom is the order of
+                         the fp32 accumulation);
+  model level (derived): see tests/test_idefics2_gpu.py::test_idefics2_fp8_* — deviation from the bf16 engine.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+F8 = torch.float8_e4m3fn
+
+
+def _ref_quant(x):
+    sc = x.float().abs().amax(1).clamp_min(1e-12) / 448.0
+    q = (x.float() / sc[:, None]).to(F8)
+    return q.view(torch.uint8), sc
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("rows,K", [(5, 64), (300, 1152), (129, 4096), (7, 14336)])
+def test_quantize_rows_matches_torch_cast(dt, rows, K):
+    from licv import ops
+    g = torch.Generator().manual_seed(rows + K)
+    x = (torch.randn(rows, K, generator=g) * torch.rand(rows, 1, generator=g) * 5).to(dt)
+    x[0, :] = 0                                                   # an all-zero row: scale floor, zeros out
+    x[1, 3] = 1000.0                                              # an outlier sets the row scale
+    q, sc = ops.quantize_fp8(x.to(DEV))
+    rq, rsc = _ref_quant(x)
+    assert torch.equal(sc.cpu(), rsc)
+    assert torch.equal(q.cpu(), rq)
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(512, 256, 256, "none"), (1000, 3000, 1152, "bias_gelu"), (700, 512, 4096, "res16"),
+                                       (640, 1024, 1024, "swiglu"), (513, 260, 2048, "res32"), (300, 100, 512, "none")])
+def test_gemm_fp8_matches_dequantised_product(M, N, K, epi):
+    from licv import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    a = (torch.randn(M, K, generator=g)).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16)
+    aq, asc = ops.quantize_fp8(a.to(DEV))
+    wq, wsc = ops.quantize_fp8(w.to(DEV))
+    ad = aq.cpu().view(F8).double() * asc.cpu().double()[:, None]
+    wd = wq.cpu().view(F8).double() * wsc.cpu().double()[:, None]
+    y = ad @ wd.T
+    kw = {}
+    if epi == "bias_gelu":
+        bias = (torch.randn(N, generator=g) * 0.1).to(torch.bfloat16)
+        y = torch.nn.functional.gelu((y + bias.double()).float().bfloat16().double())
+        kw = dict(bias=bias.to(DEV), act="gelu")
+    elif epi == "swiglu":
+        kw = dict(swiglu=True)
+    elif epi in ("res16", "res32"):
+        rdt = torch.bfloat16 if epi == "res16" else torch.float32
+        res = torch.randn(M, N, generator=g).to(rdt)
+        y = y.float().bfloat16().double() + res.double()
+        kw = dict(residual=res.to(DEV))
+    if epi == "swiglu":
+        wq2 = ops.pack_gate_up(w[: N // 2].to(DEV).contiguous(), w[N // 2:].to(DEV).contiguous())       # interleave, then quantise rows
+        wq, wsc = ops.quantize_fp8(wq2)
+        wd = wq.cpu().view(F8).double() * wsc.cpu().double()[:, None]
+        yy = (ad @ wd.T).float().bfloat16().double()
+        gate = torch.cat([yy[:, b:b + 16] for b in range(0, N, 32)], 1)
+        up = torch.cat([yy[:, b + 16:b + 32] for b in range(0, N, 32)], 1)
+        y = torch.nn.functional.silu(gate).float().bfloat16().double() * up
+    out = ops.linear_fp8(aq, asc, wq, wsc, **kw).float().cpu().double()
+    assert out.shape == y.shape
+    tol = 2.0 ** -7 * y.abs().max()                               # one bf16 ulp at the output scale (+ fp32 accumulation order)
+    assert (out - y).abs().max() <= tol, f"{float((out - y).abs().max()):.3e} > {float(tol):.3e}"
