@@ -1126,7 +1126,9 @@ extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
         const int tiles_m = (int)((M + 255) / 256), tiles_n = (int)((N + 255) / 256);
         const dim3 grid(tiles_m * tiles_n), block(512);
         // estimated tile time: K/32 stages x ~0.85 us + ~15 us of fill/epilogue, in 10 ns ticks; an eighth of it per XCD
-        const int pp_group = g_pp_group > 0 ? g_pp_group : 8;
+        // tile-rows per XCD patch: 8 (a 32-CU XCD then works on an 8 x 4 patch); with <= 6 tile-columns an 8-row group is 40-48
+        // tiles and the patch straddles two groups -> 2-row groups keep it compact (measured +6 % at N = 1280, K = 5120)
+        const int pp_group = g_pp_group > 0 ? g_pp_group : (tiles_n <= 6 ? 2 : 8);
         const int pp_ticks = (g_pp_stagger > 0 && tiles_m * tiles_n >= 2 * g_num_cus)
                                  ? (int)(((K / 32) * 85 + 1500) / 8 * g_pp_stagger / 100) : 0;
 #define LAUNCH256(ABL) gemm_bf16_tile256_k<ABL><<<grid, block, T256_LDS, (hipStream_t)stream>>>( \
