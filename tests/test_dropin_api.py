@@ -134,3 +134,32 @@ def test_collator_contract_masks_select_the_same_answer_tokens():
     for b in range(2):
         assert torch.equal(stu[b][ms[b]], tea[b][mt[b]])            # the answer tokens and the EOS, identical in both rows
     assert stu[0][ms[0]].tolist()[-1] == EOS and len(stu[0][ms[0]]) == 4   # "a small dog" + EOS
+
+
+def test_schedule_helpers_match_transformers_and_reference_errors():
+    """lr schedule == transformers.get_cosine_schedule_with_warmup (ref:icv_src/icv_module.py:189-209); type errors as the
+    reference raises them (ref :66-67, :199-202).  Methods are exercised unbound on a stub (no engine needed)."""
+    import types
+    import torch
+    from transformers import get_cosine_schedule_with_warmup
+    from icv_src.icv_module import VQAICVModule
+    opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1.0)
+    sched = get_cosine_schedule_with_warmup(opt, num_warmup_steps=7, num_training_steps=50)
+    for step in range(55):
+        assert abs(sched.get_last_lr()[0] - VQAICVModule.lr_lambda(step, 7, 50)) <= 1e-12
+        opt.step(); sched.step()
+    cfg = types.SimpleNamespace(warm_steps=0.1, alpha_lr=1e-2, icv_lr=1e-4, weight_decay=1e-3, decay_per_step=-1, decay_ratio=-1)
+    stub = types.SimpleNamespace(module_cfg=cfg)
+    spec = VQAICVModule.optimizer_spec(stub, 200)
+    assert spec == dict(alpha_lr=1e-2, icv_lr=1e-4, weight_decay=1e-3, warm_steps=20.0, total_steps=200)
+    cfg.warm_steps = 15
+    assert VQAICVModule.optimizer_spec(stub, 200)["warm_steps"] == 15
+    cfg.warm_steps = "10"
+    with pytest.raises(ValueError, match="warm_steps should be int or float"):
+        VQAICVModule.optimizer_spec(stub, 200)
+    cfg.decay_per_step = 1.5
+    with pytest.raises(ValueError, match="decay_ratio must be an int or a float"):
+        VQAICVModule.setup_temperature_decay(stub, 100)
+    cfg.decay_per_step = 0.25
+    VQAICVModule.setup_temperature_decay(stub, 100)
+    assert stub.decay_per_step == 25
