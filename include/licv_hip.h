@@ -187,6 +187,12 @@ int licv_branch_grad(const float* dh, void* out_bf16, int64_t rows, int64_t dim,
  * dK/dV are written per QUERY head (n_heads*head_dim columns): with GQA reduce them with licv_head_group_sum */
 int licv_attn_bwd_small(const licv_attn_args* a, const void* dout_bf16, void* dq_bf16, int64_t dq_bs, int64_t dq_rs,
                         void* dk_bf16, void* dv_bf16, int64_t dkv_bs, int64_t dkv_rs, void* stream);
+/* cross-entropy rows (the "hard" loss, ref:icv_src/icv_module.py:94-95,111-117; HF ForCausalLMLoss upcasts to fp32):
+ * loss_rows[i] = logsumexp(logits[rows[i], :]) - logits[rows[i], labels[i]]  (may be NULL);
+ * grad[(grad_rows ? grad_rows[i] : i), :] (+)= grad_coef * (softmax - onehot), bf16 (may be NULL). */
+int licv_ce_rows(const void* logits, int dtype, const int64_t* rows, const int64_t* labels, int64_t n_rows, int64_t vocab,
+                 int64_t ld, float* loss_rows, float grad_coef, void* grad_bf16, int64_t ld_grad, const int64_t* grad_rows,
+                 int accumulate, void* stream);
 /* backward of repeat_kv (GQA): out[r, g*hd + d] = sum over the `rep` query heads of group g of src[r, (g*rep+j)*hd + d] */
 int licv_head_group_sum(const void* src_bf16, void* out_bf16, int64_t rows, int64_t n_groups, int64_t rep, int64_t head_dim,
                         int64_t ld_src, int64_t ld_out, void* stream);

@@ -370,6 +370,54 @@ extern "C" int licv_attn_bwd_small(const licv_attn_args* x, const void* dout, vo
     return LICV_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Cross-entropy rows ("hard" loss, ref:icv_src/icv_module.py:94-95,111-117 -> HF ForCausalLMLoss: logits upcast to fp32,
+// mean over the kept positions).  One workgroup per row: loss = logsumexp(z) - z[label]; gradient coef * (softmax(z) - onehot).
+// ------------------------------------------------------------------------------------------------
+template <bool BF>
+__global__ __launch_bounds__(256)
+void ce_rows_k(const void* __restrict__ logits, const int64_t* __restrict__ rows, const int64_t* __restrict__ labels, int64_t vocab,
+               int64_t ld, float* __restrict__ loss_out, float coef, bf16_t* __restrict__ grad, int64_t ld_g,
+               const int64_t* __restrict__ grad_rows, int accumulate) {
+    __shared__ float red[8];
+    const int64_t r = blockIdx.x;
+    const int64_t base = rows[r] * ld;
+    const int64_t label = labels[r];
+    auto ldv = [&](int64_t i) -> float {
+        return BF ? bf2f(reinterpret_cast<const bf16_t*>(logits)[base + i]) : reinterpret_cast<const float*>(logits)[base + i];
+    };
+    float mx = -INFINITY;
+    for (int64_t i = threadIdx.x; i < vocab; i += blockDim.x) mx = fmaxf(mx, ldv(i));
+    mx = blk_reduce(mx, true, red);
+    float z = 0.f;
+    for (int64_t i = threadIdx.x; i < vocab; i += blockDim.x) z += __expf(ldv(i) - mx);
+    z = blk_reduce(z, false, red);
+    if (loss_out && threadIdx.x == 0) loss_out[r] = logf(z) + mx - ldv(label);
+    if (grad) {
+        bf16_t* g = grad + (grad_rows ? grad_rows[r] : r) * ld_g;
+        const float inv = coef / z;
+        for (int64_t i = threadIdx.x; i < vocab; i += blockDim.x) {
+            float v = __expf(ldv(i) - mx) * inv - (i == label ? coef : 0.f);
+            if (accumulate) v += bf2f(g[i]);
+            g[i] = f2bf(v);
+        }
+    }
+}
+
+extern "C" int licv_ce_rows(const void* logits, int dtype, const int64_t* rows, const int64_t* labels, int64_t n_rows, int64_t vocab,
+                            int64_t ld, float* loss_rows, float grad_coef, void* grad_bf16, int64_t ld_grad, const int64_t* grad_rows,
+                            int accumulate, void* stream) {
+    LICV_CHECK_ARG(logits && rows && labels && (loss_rows || grad_bf16), "ce_rows: null pointer");
+    LICV_CHECK_ARG(dtype == LICV_BF16 || dtype == LICV_F32, "ce_rows: bad dtype");
+    LICV_CHECK_ARG(vocab > 0 && ld >= vocab && (!grad_bf16 || ld_grad >= vocab), "ce_rows: bad vocab / leading dims");
+    if (n_rows <= 0) return LICV_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == LICV_BF16) ce_rows_k<true><<<(unsigned)n_rows, 256, 0, st>>>(logits, rows, labels, vocab, ld, loss_rows, grad_coef, (bf16_t*)grad_bf16, ld_grad, grad_rows, accumulate);
+    else                    ce_rows_k<false><<<(unsigned)n_rows, 256, 0, st>>>(logits, rows, labels, vocab, ld, loss_rows, grad_coef, (bf16_t*)grad_bf16, ld_grad, grad_rows, accumulate);
+    LICV_LAUNCH_CHECK();
+    return LICV_OK;
+}
+
 // out[r, g*hd + d] = bf16( sum_{j < rep} src[r, (g*rep + j)*hd + d] )   (backward of repeat_kv, hf:mistral/modeling_mistral.py)
 __global__ __launch_bounds__(256)
 void head_group_sum_k(const bf16_t* __restrict__ src, bf16_t* __restrict__ out, int64_t rows, int n_groups, int rep, int hd,

@@ -63,6 +63,7 @@ def lib() -> C.CDLL:
             "licv_inject_renorm_fwd": [P, I, P, P, P, I64, I64, P, P, F, P],
             "licv_inject_renorm_add_fwd": [P, I, P, P, P, I, P, I64, I64, P, P, F, I, P],
             "licv_scatter_rows": [P, P, P, I64, I64, P],
+            "licv_ce_rows": [P, I, P, P, I64, I64, I64, P, F, P, I64, P, I, P],
             "licv_head_group_sum": [P, P, I64, I64, I64, I64, I64, I64, P],
             "licv_inject_renorm_bwd": [P, I, P, P, P, P, P, I64, I64, P],
             "licv_rmsnorm_fwd": [P, I, P, P, I64, I64, I64, I64, I64, F, I, P],

@@ -382,6 +382,19 @@ def attention_bwd_small(q, k, v, dout, B, Sq, Sk, n_heads, n_kv_heads, head_dim,
     return dq
 
 
+def ce_rows(logits: torch.Tensor, rows: torch.Tensor, labels: torch.Tensor, vocab: int, grad: Optional[torch.Tensor] = None,
+            grad_coef: float = 0.0, grad_rows: Optional[torch.Tensor] = None, accumulate: bool = False, want_loss: bool = True):
+    """Cross-entropy of logits[rows] against labels (fp32 maths).  Returns per-row losses (fp32) or None; optionally
+    writes / accumulates grad_coef * (softmax - onehot) into grad[(grad_rows or arange)] (bf16, row stride grad.stride(0))."""
+    assert logits.dim() == 2 and logits.stride(1) == 1 and rows.dtype == torch.int64 and labels.dtype == torch.int64
+    n = rows.numel()
+    out = torch.empty((n,), dtype=torch.float32, device=logits.device) if want_loss else None
+    check(_lib.lib().licv_ce_rows(_p(logits), _dt(logits), _p(rows.contiguous()), _p(labels.contiguous()), n, vocab, logits.stride(0), _p(out),
+                                  float(grad_coef), _p(grad), grad.stride(0) if grad is not None else 0,
+                                  _p(grad_rows.contiguous()) if grad_rows is not None else None, 1 if accumulate else 0, _stream(logits)))
+    return out
+
+
 def head_group_sum(src: torch.Tensor, out: torch.Tensor, rows: int, n_groups: int, rep: int, head_dim: int, ld_src: int, ld_out: int):
     """Backward of repeat_kv: sums each group of `rep` query heads (bf16 in, fp32 accumulate, bf16 out)."""
     check(_lib.lib().licv_head_group_sum(_p(src), _p(out), rows, n_groups, rep, head_dim, ld_src, ld_out, _stream(src)))

@@ -38,8 +38,7 @@ class ICVTrainer:
         """module: icv_src.icv_module.VQAICVModule on a native interface; state_dict: the HF-named LMM weights
         (needed once for the transposed copies the backward GEMMs use)."""
         self.m = module
-        if module.module_cfg.hard_loss_weight:
-            raise NotImplementedError("the native backward covers the KL objective (hard_loss_weight = 0, the reference default)")
+        self.hard_w = float(module.module_cfg.hard_loss_weight or 0.0)      # loss = kl + hard_w * ce (ref:icv_src/icv_module.py:111-117)
         eng = module.interface.engine
         if type(eng).__name__ == "Idefics2Engine":
             self.student = StudentPass2(eng, TrainWeights2(eng.w, state_dict))
@@ -81,15 +80,35 @@ class ICVTrainer:
         enc_out = m.icv_encoder()
         with torch.no_grad():
             tea = eng.forward(**t, logits_rows=t_rows)          # Idefics: image_attention_mask; Idefics2: pixel_attention_mask
+        n_kl = s_rows.numel()
+        idx_t = torch.arange(n_kl, device=dev)
+        if self.hard_w:
+            # CE over every position that predicts a real token (labels = input_ids shifted; pads masked by attention_mask, the
+            # behaviour of the transformers version the reference pins: SURVEY.md a19).  Student logits are needed on the union
+            # of the answer rows (KL) and those rows.
+            from lmm_icl_interface.interface import ce_rows_and_labels
+            ce_rows, ce_tok = ce_rows_and_labels(q["input_ids"], q["attention_mask"][:, 1:] != 0)
+            rows_all = torch.unique(torch.cat([s_rows, ce_rows]))                  # sorted
+            idx_kl, idx_ce = torch.searchsorted(rows_all, s_rows), torch.searchsorted(rows_all, ce_rows)
+        else:
+            rows_all, idx_kl = s_rows, idx_t
         stu, st = self.student.forward(**q, icv=enc_out.in_context_vector, hook_layers=self.layers, alpha=enc_out.alpha,
-                                       logits_rows=s_rows)
+                                       logits_rows=rows_all)
         V = eng.w.lm_head.shape[0]
-        idx = torch.arange(s_rows.numel(), device=dev)
         T, eps = float(m.temperature), float(m.module_cfg.kl_eps)
         stu2 = stu if stu.stride(1) == 1 else stu.contiguous()
         tea2 = tea if tea.stride(1) == 1 else tea.contiguous()
-        kl = ops.kl_rows(stu2, tea2, idx, idx, V, T, eps).mean() * T * T
-        dlogits = ops.kl_rows_bwd(stu2, tea2, idx, idx, V, T, eps, upstream=upstream)
+        kl = ops.kl_rows(stu2, tea2, idx_kl, idx_t, V, T, eps).mean() * T * T
+        dlogits = ops.kl_rows_bwd(stu2, tea2, idx_kl, idx_t, V, T, eps, upstream=upstream)      # (n_kl, V padded) in idx_kl order
+        self.last_ce = None
+        if self.hard_w:
+            full = torch.zeros((rows_all.numel(), dlogits.shape[1]), dtype=torch.bfloat16, device=dev)
+            full.index_copy_(0, idx_kl, dlogits)
+            n_ce = max(int(ce_rows.numel()), 1)
+            ce = ops.ce_rows(stu2, idx_ce, ce_tok, V, grad=full, grad_coef=self.hard_w * upstream / n_ce, grad_rows=idx_ce,
+                             accumulate=True).mean()
+            self.last_ce = ce
+            dlogits = full
         grad_v = self.student.backward(st, dlogits)                       # d loss / d (alpha*icv), (1, n, H)
         icv_eff = enc_out.alpha.unsqueeze(dim=-1) * enc_out.in_context_vector
         icv_eff.backward(grad_v)                                           # tiny torch graph: sigmoid, product (131 k floats)
@@ -122,4 +141,8 @@ class ICVTrainer:
         enc.icv.grad = None
         self._kl_sum.zero_()
         m.global_step = self.opt_step
-        return {"kl_loss": kl, "loss": kl, "grad_norm": norm, "lr_scale": lam}
+        log = {"kl_loss": kl, "loss": kl, "grad_norm": norm, "lr_scale": lam}
+        if self.hard_w and self.last_ce is not None:                       # this rank's last micro-batch CE (informational)
+            log["ce_loss"] = float(self.last_ce)
+            log["loss"] = kl + self.hard_w * log["ce_loss"]
+        return log

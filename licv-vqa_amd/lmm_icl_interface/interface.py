@@ -29,6 +29,23 @@ class _NativeModel(torch.nn.Module):
         return None
 
 
+def ce_rows_and_labels(labels: torch.Tensor, keep: torch.Tensor):
+    """Flat (b*S + t) row indices of the logits that predict a kept token, and those tokens: position t predicts labels[:, t+1]."""
+    B, S = labels.shape
+    t_idx = torch.arange(S - 1, device=labels.device).unsqueeze(0).expand(B, -1)
+    rows = (torch.arange(B, device=labels.device).unsqueeze(1) * S + t_idx)[keep]
+    return rows.contiguous(), labels[:, 1:][keep].contiguous()
+
+
+def _ce_shifted(logits: torch.Tensor, labels: torch.Tensor, keep: torch.Tensor) -> torch.Tensor:
+    """mean over kept positions of CE(logits[:, t], labels[:, t+1]) — the row reduction over the vocabulary is a HIP kernel."""
+    from licv import ops
+    B, S, V = logits.shape
+    rows, tok = ce_rows_and_labels(labels, keep)
+    flat = logits.as_strided((B * S, V), (logits.stride(1), 1))
+    return ops.ce_rows(flat, rows, tok, V).mean()
+
+
 class LMMInterface(torch.nn.Module):
     input_ids_field_name = "input_ids"
 
@@ -119,7 +136,7 @@ class IdeficsInterface(LMMInterface):
         if labels is not None:
             # shift-by-one CE with pads masked by attention_mask: transformers 4.38.2 Idefics behaviour
             keep = attention_mask[:, 1:].to(self._device) != 0
-            out["loss"] = torch.nn.functional.cross_entropy(logits[:, :-1][keep].float(), labels[:, 1:].to(self._device)[keep])
+            out["loss"] = _ce_shifted(logits, labels.to(self._device), keep)
         return out
 
     @torch.no_grad()
@@ -176,8 +193,8 @@ class Idefics2Interface(IdeficsInterface):
         out = LMMOutput(logits=logits)
         if labels is not None:
             # hf:idefics2/modeling_idefics2.py ForConditionalGeneration loss: plain shifted CE, ignore_index=-100
-            out["loss"] = torch.nn.functional.cross_entropy(logits[:, :-1].float().reshape(-1, logits.shape[-1]),
-                                                            labels[:, 1:].to(dev).reshape(-1), ignore_index=-100)
+            lab = labels.to(dev)
+            out["loss"] = _ce_shifted(logits, lab, lab[:, 1:] != -100)
         return out
 
     @torch.no_grad()

@@ -270,3 +270,36 @@ def test_g9_idefics2_kl_loss_and_grads(golden, dn, dt, temp):
     gtol = 1e-7 if dn == "f32" else 0.0
     assert (icv.grad - T(z[f"{key}_grad_icv"])).abs().max() <= gtol
     assert (alpha.grad - T(z[f"{key}_grad_alpha"])).abs().max() <= gtol
+
+
+@pytest.mark.parametrize("dn,dt", [("f32", torch.float32), ("bf16", torch.bfloat16)])
+def test_g10_hard_loss_and_grads(golden, dn, dt):
+    """loss = kl + hard_loss_weight * ce with the reference's own forward (HF computes the CE): value and grads of icv / alpha."""
+    z = golden("g10_hard_loss")
+    arch = IDEFICS_TINY.with_(additional_vocab_size=0)
+    sd32 = synth_idefics_weights(arch, seed=101, dtype=torch.float32)
+    assert weights_checksum(sd32) == float(z["weights_checksum"])
+    sd = {k: v.to(dt) for k, v in sd32.items()}
+    b = lambda n: dict(input_ids=T(z[f"{n}_input_ids"]), attention_mask=T(z[f"{n}_attention_mask"]),
+                       pixel_values=T(z[f"{n}_pixel_values"]).to(dt), image_attention_mask=T(z[f"{n}_image_attention_mask"]))
+    stu, tea = b("stu"), b("tea")
+    icv = T(z["enc_icv"]).clone().requires_grad_(True)
+    alpha = T(z["enc_alpha_param"]).clone().requires_grad_(True)
+    icv_eff = O.scale_icv(O.encoder_alpha(alpha, True), icv)
+    layers = list(range(arch.num_layers))
+    s_logits = R.forward(sd, arch, **stu, icv=icv_eff.detach() if False else icv_eff, hook_layers=layers)
+    with torch.no_grad():
+        t_logits = R.forward(sd, arch, **tea)
+    sm = O.get_mask(stu["input_ids"], T(z["query_x_length"]), arch.pad_token_id)
+    tm = O.get_mask(tea["input_ids"], T(z["in_context_length"]), arch.pad_token_id)
+    kl = O.kl_divergence(s_logits[sm].view(-1, s_logits.shape[-1]), t_logits[tm].view(-1, t_logits.shape[-1]), 1.0)
+    ce = O.ce_masked(s_logits, stu["input_ids"], stu["attention_mask"])
+    loss = kl + float(z["hard_loss_weight"]) * ce
+    loss.backward()
+    tol = 2e-6 if dn == "f32" else 0.0
+    assert abs(float(kl) - float(z[f"{dn}_kl"])) <= tol
+    # the CE is an fp32 reduction over (rows, vocab) in both paths; HF sums then divides, the oracle takes the mean: 1 fp32 ulp
+    assert abs(float(ce) - float(z[f"{dn}_ce"])) <= 2e-6 and abs(float(loss) - float(z[f"{dn}_loss"])) <= 2e-6
+    g_icv, g_alpha = T(z[f"{dn}_grad_icv"]), T(z[f"{dn}_grad_alpha"])
+    assert (icv.grad - g_icv).abs().max() <= (1e-7 if dn == "f32" else 2e-3 * g_icv.abs().max())
+    assert (alpha.grad - g_alpha).abs().max() <= (1e-7 if dn == "f32" else 2e-3 * g_alpha.abs().max())

@@ -131,3 +131,38 @@ def test_idefics2_native_backward_matches_reference_autograd(golden, temp):
     loss_dict, _ = mod({k: v.to(DEV) for k, v in b("stu_").items()}, {k: v.to(DEV) for k, v in b("tea_").items()},
                        T(z["query_x_length"]).to(DEV), T(z["in_context_length"]).to(DEV))
     assert abs(float(loss_dict["kl_loss"]) - float(kl)) <= 2e-2 * abs(float(kl)) + 1e-5
+
+
+def test_hard_loss_backward_matches_reference_autograd(golden):
+    """loss = kl + 0.5 * ce (ref:icv_src/icv_module.py:94-95,111-117): CE rows forward/backward kernels + the KL path, against the
+    reference module driving HF with labels (fixture g10: additional_vocab_size 0, full rows)."""
+    from icv_src.icv_module import VQAICVModule
+    from licv.trainer import ICVTrainer
+    from lmm_icl_interface import IdeficsInterface
+    z = golden("g10_hard_loss")
+    arch = IDEFICS_TINY.with_(additional_vocab_size=0)
+    sd = synth_idefics_weights(arch, seed=101, dtype=torch.float32)
+    iface = IdeficsInterface(state_dict=sd, arch=arch, device=DEV)
+    mod_cfg = dict(hard_loss_weight=float(z["hard_loss_weight"]), only_hard_loss=False, kl_eps=1e-6, init_temperature=1.0, learnable_t=False,
+                   decay_ratio=-1, decay_per_step=-1, min_tmeprature=1.0, alpha_lr=1e-2, icv_lr=1e-4, weight_decay=1e-3,
+                   warm_steps=0.1, icv_encoder=dict(use_sigmoid=True, alpha_learnable=True, alpha_init_value=0.3))
+    lmm_cfg = dict(intervention_layer=-1, layer_format=FMT, total_layers=arch.num_layers, hidden_size=arch.hidden_size)
+    mod = VQAICVModule(iface, mod_cfg, lmm_cfg).to(DEV)
+    with torch.no_grad():
+        mod.icv_encoder.icv.copy_(T(z["enc_icv"]))
+        mod.icv_encoder.alpha.copy_(T(z["enc_alpha_param"]))
+    tr = ICVTrainer(mod, sd, total_steps=20, accumulate_grad_batches=1, grad_clip=1.0)
+    stu, tea = _batch(z, "stu_"), _batch(z, "tea_")
+    kl = tr.loss_and_backward(stu, tea, T(z["query_x_length"]), T(z["in_context_length"]))
+    assert abs(float(kl) - float(z["f32_kl"])) <= 1.5 * abs(float(z["bf16_kl"]) - float(z["f32_kl"])) + 0.05 * float(z["f32_kl"])
+    assert abs(float(tr.last_ce) - float(z["f32_ce"])) <= 1.5 * abs(float(z["bf16_ce"]) - float(z["f32_ce"])) + 5e-3 * float(z["f32_ce"])
+    for name, got in (("grad_icv", mod.icv_encoder.icv.grad), ("grad_alpha", mod.icv_encoder.alpha.grad)):
+        g32, g16 = T(z[f"f32_{name}"]), T(z[f"bf16_{name}"])
+        spread, err, scale = (g16 - g32).abs().max(), (got.cpu() - g32).abs().max(), g32.abs().max()
+        assert err <= 1.5 * spread + 0.02 * scale, f"{name}: err {err:.3e} spread {spread:.3e} scale {scale:.3e}"
+        assert torch.nn.functional.cosine_similarity(got.cpu().reshape(1, -1), g32.reshape(1, -1)).item() > 0.99
+    # the module's forward (the reference's call shape) reports the same pieces
+    loss_dict, _ = mod({k: v.to(DEV) for k, v in stu.items()}, {k: v.to(DEV) for k, v in tea.items()},
+                       T(z["query_x_length"]).to(DEV), T(z["in_context_length"]).to(DEV))
+    assert abs(float(loss_dict["ce_loss"]) - float(tr.last_ce)) <= 1e-3 * float(tr.last_ce)
+    assert abs(float(loss_dict["loss"]) - (float(loss_dict["kl_loss"]) + 0.5 * float(loss_dict["ce_loss"]))) <= 1e-5

@@ -563,6 +563,62 @@ def g9_loss_idefics2():
     np.savez_compressed(OUT / "g9_loss_idefics2.npz", **out)
 
 
+def g10_hard_loss():
+    """The reference's objective with the CE ("hard") term: loss = kl + 0.5 * ce (ref:icv_src/icv_module.py:94-95,111-117), grads
+    of icv / alpha.  additional_vocab_size = 0 (HF 5.15's labels path raises with additional vocabulary) and full-length rows
+    (no padding), so the pinned 4.38.2 CE (pads masked by attention_mask) and 5.15's CE coincide."""
+    from icv_src.icv_encoder.global_icv_encoder import GlobalICVEncoder
+    from icv_src.icv_model.icv_intervention import LearnableICVInterventionLMM
+    methods = _reference_module_methods()
+    arch = IDEFICS_TINY.with_(additional_vocab_size=0)
+    seed = 101
+    sd32 = synth_idefics_weights(arch, seed=seed, dtype=torch.float32)
+    out = {"weights_checksum": np.array(weights_checksum(sd32))}
+    B, ans = 2, 3
+    tea = synth_vqa_batch(arch, B, 22, 3, seed=seed, min_len=22, dtype=torch.float32)
+    stu = synth_vqa_batch(arch, B, 10, 1, seed=seed + 1, min_len=10, dtype=torch.float32)
+    for b in range(B):
+        stu["input_ids"][b, 10 - ans:] = tea["input_ids"][b, 22 - ans:]
+    in_context_length = torch.full((B,), 22 - ans)
+    query_x_length = torch.full((B,), 10 - ans)
+    for name, d in (("tea", tea), ("stu", stu)):
+        for k, v in d.items():
+            out[f"{name}_{k}"] = np_(v)
+    out["in_context_length"], out["query_x_length"] = in_context_length.numpy(), query_x_length.numpy()
+    out["hard_loss_weight"] = np.array(0.5)
+
+    class Mod(torch.nn.Module):
+        pass
+    for k, f in methods.items():
+        setattr(Mod, k, f)
+    for dt_name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+        model = hf_model(arch, sd32, dt)
+        iface = Interface(model, arch.pad_token_id)
+        iface.requires_grad_(False)
+        mod = Mod()
+        mod.interface = iface
+        mod.module_cfg = types.SimpleNamespace(hard_loss_weight=0.5, only_hard_loss=False, kl_eps=1e-6)
+        mod.icv_model = LearnableICVInterventionLMM(iface, True, -1, "model.model.layers.<LAYER_NUM>", arch.num_layers)
+        torch.manual_seed(seed)
+        mod.icv_encoder = GlobalICVEncoder(arch.hidden_size, arch.num_layers, alpha_init_value=0.3, use_sigmoid=True)
+        with torch.no_grad():
+            mod.icv_encoder.icv.mul_(20.0)
+        mod.temperature = torch.nn.Parameter(torch.tensor(1.0), requires_grad=False)
+        q = {k: (v.to(dt) if v.is_floating_point() else v.clone()) for k, v in stu.items()}
+        t = {k: (v.to(dt) if v.is_floating_point() else v.clone()) for k, v in tea.items()}
+        loss_dict, enc_out = mod(q, t, query_x_length, in_context_length)
+        loss_dict["loss"].backward()
+        out[f"{dt_name}_kl"] = np_(loss_dict["kl_loss"])
+        out[f"{dt_name}_ce"] = np_(loss_dict["ce_loss"])
+        out[f"{dt_name}_loss"] = np_(loss_dict["loss"])
+        out[f"{dt_name}_grad_icv"] = np_(mod.icv_encoder.icv.grad)
+        out[f"{dt_name}_grad_alpha"] = np_(mod.icv_encoder.alpha.grad)
+        if dt_name == "f32":
+            out["enc_icv"] = np_(mod.icv_encoder.icv)
+            out["enc_alpha_param"] = np_(mod.icv_encoder.alpha)
+    np.savez_compressed(OUT / "g10_hard_loss.npz", **out)
+
+
 def g7_optim():
     """torch.optim.AdamW with the reference's two param groups + transformers cosine warm-up
     (ref:icv_src/icv_module.py:171-209; icv_module.yaml: alpha_lr 1e-2, icv_lr 1e-4, wd 1e-3, warm 0.1)."""
@@ -596,8 +652,8 @@ def main():
     import icv_src.icv_model.icv_intervention as _ri
     assert _ri.__file__.startswith(str(REF)), _ri.__file__
     torch.set_num_threads(4)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
-    fns = dict(g1=g1_encoder, g2=g2_intervention, g3=g3_idefics, g4=g4_idefics2, g5=g5_generate, g6=g6_loss, g7=g7_optim, g8=g8_generate_idefics2, g9=g9_loss_idefics2)
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
+    fns = dict(g1=g1_encoder, g2=g2_intervention, g3=g3_idefics, g4=g4_idefics2, g5=g5_generate, g6=g6_loss, g7=g7_optim, g8=g8_generate_idefics2, g9=g9_loss_idefics2, g10=g10_hard_loss)
     for w in which:
         print("generating", w, flush=True)
         fns[w]()
