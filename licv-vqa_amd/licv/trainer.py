@@ -39,6 +39,7 @@ class ICVTrainer:
         (needed once for the transposed copies the backward GEMMs use)."""
         self.m = module
         self.hard_w = float(module.module_cfg.hard_loss_weight or 0.0)      # loss = kl + hard_w * ce (ref:icv_src/icv_module.py:111-117)
+        self.only_hard = bool(getattr(module.module_cfg, "only_hard_loss", False))     # loss = ce alone, no teacher pass (ref :100-101)
         eng = module.interface.engine
         if type(eng).__name__ == "Idefics2Engine":
             self.student = StudentPass2(eng, TrainWeights2(eng.w, state_dict))
@@ -78,6 +79,20 @@ class ICVTrainer:
         t_rows = m.get_mask(t, in_context_length.to(dev)).reshape(-1).nonzero().squeeze(1)
         assert s_rows.numel() == t_rows.numel(), "student and teacher must mask the same number of answer tokens"
         enc_out = m.icv_encoder()
+        if self.only_hard:
+            from lmm_icl_interface.interface import ce_rows_and_labels
+            ce_rows, ce_tok = ce_rows_and_labels(q["input_ids"], q["attention_mask"][:, 1:] != 0)
+            stu, st = self.student.forward(**q, icv=enc_out.in_context_vector, hook_layers=self.layers, alpha=enc_out.alpha,
+                                           logits_rows=ce_rows)
+            V = eng.w.lm_head.shape[0]
+            stu2 = stu if stu.stride(1) == 1 else stu.contiguous()
+            full = torch.zeros((ce_rows.numel(), (V + 7) // 8 * 8), dtype=torch.bfloat16, device=dev)
+            idx = torch.arange(ce_rows.numel(), device=dev)
+            ce = ops.ce_rows(stu2, idx, ce_tok, V, grad=full, grad_coef=upstream / max(int(ce_rows.numel()), 1)).mean()
+            self.last_ce = ce
+            grad_v = self.student.backward(st, full)
+            (enc_out.alpha.unsqueeze(dim=-1) * enc_out.in_context_vector).backward(grad_v)
+            return ce
         with torch.no_grad():
             tea = eng.forward(**t, logits_rows=t_rows)          # Idefics: image_attention_mask; Idefics2: pixel_attention_mask
         n_kl = s_rows.numel()

@@ -166,3 +166,36 @@ def test_hard_loss_backward_matches_reference_autograd(golden):
                        T(z["query_x_length"]).to(DEV), T(z["in_context_length"]).to(DEV))
     assert abs(float(loss_dict["ce_loss"]) - float(tr.last_ce)) <= 1e-3 * float(tr.last_ce)
     assert abs(float(loss_dict["loss"]) - (float(loss_dict["kl_loss"]) + 0.5 * float(loss_dict["ce_loss"]))) <= 1e-5
+
+
+def test_only_hard_loss_gradient_matches_oracle_autograd(golden):
+    """only_hard_loss (ref:icv_src/icv_module.py:100-101): the objective is the student's CE alone; checked against torch autograd
+    through the CPU oracle on the g10 inputs."""
+    from icv_src.icv_module import VQAICVModule
+    from licv.trainer import ICVTrainer
+    from lmm_icl_interface import IdeficsInterface
+    from oracle import idefics_ref as R
+    z = golden("g10_hard_loss")
+    arch = IDEFICS_TINY.with_(additional_vocab_size=0)
+    sd = synth_idefics_weights(arch, seed=101, dtype=torch.float32)
+    iface = IdeficsInterface(state_dict=sd, arch=arch, device=DEV)
+    mod_cfg = dict(hard_loss_weight=1.0, only_hard_loss=True, kl_eps=1e-6, init_temperature=1.0, learnable_t=False,
+                   decay_ratio=-1, decay_per_step=-1, min_tmeprature=1.0, alpha_lr=1e-2, icv_lr=1e-4, weight_decay=1e-3,
+                   warm_steps=0.1, icv_encoder=dict(use_sigmoid=True, alpha_learnable=True, alpha_init_value=0.3))
+    lmm_cfg = dict(intervention_layer=-1, layer_format=FMT, total_layers=arch.num_layers, hidden_size=arch.hidden_size)
+    mod = VQAICVModule(iface, mod_cfg, lmm_cfg).to(DEV)
+    with torch.no_grad():
+        mod.icv_encoder.icv.copy_(T(z["enc_icv"]))
+        mod.icv_encoder.alpha.copy_(T(z["enc_alpha_param"]))
+    tr = ICVTrainer(mod, sd, total_steps=20, accumulate_grad_batches=1, grad_clip=1.0)
+    stu = _batch(z, "stu_")
+    ce = tr.loss_and_backward(stu, _batch(z, "tea_"), T(z["query_x_length"]), T(z["in_context_length"]))
+    icv = T(z["enc_icv"]).clone().requires_grad_(True)
+    alpha = T(z["enc_alpha_param"]).clone().requires_grad_(True)
+    lg = R.forward(sd, arch, **stu, icv=O.scale_icv(O.encoder_alpha(alpha, True), icv), hook_layers=list(range(arch.num_layers)))
+    ref = O.ce_masked(lg, stu["input_ids"], stu["attention_mask"])
+    ref.backward()
+    assert abs(float(ce) - float(ref)) <= 5e-3 * float(ref)
+    for got, want in ((mod.icv_encoder.icv.grad.cpu(), icv.grad), (mod.icv_encoder.alpha.grad.cpu(), alpha.grad)):
+        assert torch.nn.functional.cosine_similarity(got.reshape(1, -1), want.reshape(1, -1)).item() > 0.99
+        assert (got - want).abs().max() <= 0.05 * want.abs().max()
