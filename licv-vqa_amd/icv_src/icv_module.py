@@ -122,7 +122,9 @@ class VQAICVModule(torch.nn.Module):
         if self.module_cfg.decay_ratio < 0:
             return
         if self.global_step % self.decay_per_step == 0 and self.global_step != 0:
-            self.temperature = torch.clip(self.temperature * self.module_cfg.decay_ratio, min=self.module_cfg.min_tmeprature)
+            # (the reference re-binds the nn.Parameter attribute to a plain tensor here, which torch refuses; same value, in place)
+            with torch.no_grad():
+                self.temperature.copy_(torch.clip(self.temperature * self.module_cfg.decay_ratio, min=self.module_cfg.min_tmeprature))
 
     def optimizer_spec(self, estimated_stepping_batches: int):
         """The reference's recipe as plain numbers: alpha group lr, icv group lr, weight decay, warm-up steps."""

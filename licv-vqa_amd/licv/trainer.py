@@ -56,11 +56,16 @@ class ICVTrainer:
         self.flat_v = torch.zeros_like(self.flat_p)
         self.opt_step = 0
         self.micro = 0
+        module.setup_temperature_decay(total_steps)                        # ref:icv_src/icv_module.py:54-69
+        if not hasattr(module, "global_step"):
+            module.global_step = 0
         self.layers = list(module.icv_model.intervention_layers)
         self._kl_sum = torch.zeros((), device=dev)
 
     def micro_batch(self, query_inputs, inputs, query_x_length, in_context_length):
-        """One micro-batch of the accumulation window; returns the step's log dict when it closes the window."""
+        """One micro-batch of the accumulation window (= the reference's training_step, ref:icv_src/icv_module.py:160-169: the
+        temperature decay check runs first); returns the step's log dict when it closes the window."""
+        self.m.decay_temperature()
         kl = self.loss_and_backward(query_inputs, inputs, query_x_length, in_context_length, upstream=1.0 / self.accum)
         self._kl_sum += kl.detach() / self.accum
         self.micro += 1

@@ -163,3 +163,22 @@ def test_schedule_helpers_match_transformers_and_reference_errors():
     cfg.decay_per_step = 0.25
     VQAICVModule.setup_temperature_decay(stub, 100)
     assert stub.decay_per_step == 25
+
+
+def test_temperature_decay_schedule():
+    """decay_temperature (ref:icv_src/icv_module.py:150-158): T <- max(T * ratio, min) every decay_per_step optimiser steps."""
+    import types
+    import torch
+    from icv_src.icv_module import VQAICVModule
+    cfg = types.SimpleNamespace(decay_ratio=0.5, decay_per_step=2, min_tmeprature=0.3)
+    stub = types.SimpleNamespace(module_cfg=cfg, temperature=torch.nn.Parameter(torch.tensor(2.0), requires_grad=False), global_step=0)
+    VQAICVModule.setup_temperature_decay(stub, 100)
+    seen = []
+    for step in range(7):
+        stub.global_step = step
+        VQAICVModule.decay_temperature(stub)
+        seen.append(round(float(stub.temperature), 4))
+    assert seen == [2.0, 2.0, 1.0, 1.0, 0.5, 0.5, 0.3]
+    cfg.decay_ratio = -1
+    VQAICVModule.decay_temperature(stub)
+    assert float(stub.temperature) == pytest.approx(0.3)
