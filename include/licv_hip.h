@@ -104,6 +104,14 @@ typedef struct {
 
 int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
                    int64_t M, int64_t N, int64_t K, const licv_gemm_epilogue* ep, void* stream);
+/* Skinny GEMMs (M <= 256: student pass, decode steps): K is cut into `splits` ranges, each workgroup writes its fp32 partial tile
+ * to its own slice of a caller-provided workspace (no atomics: bit-reproducible), a second kernel sums the slices in order and
+ * applies the epilogue.  licv_gemm_splitk_plan returns splits <= 1 when the plain kernel should be used. */
+int licv_gemm_splitk_plan(int64_t M, int64_t N, int64_t K, int* splits, int64_t* workspace_bytes);
+int licv_gemm_bf16_splitk(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
+                          int64_t M, int64_t N, int64_t K, const licv_gemm_epilogue* e, int splits,
+                          void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- fp8 path (BASELINE configs[4]: "fp8 weights on CDNA4 MFMA"; no reference counterpart — parity bar in DESIGN.md) ----
  * q[r,k] = e4m3(x[r,k] / scale[r]), scale[r] = amax(x[r,:]) / 448 (OCP e4m3fn, round to nearest even).  Weights are quantised
  * once with the same kernel (rows = output channels); activations per call. */

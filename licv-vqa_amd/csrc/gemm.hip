@@ -1051,6 +1051,118 @@ void gemm_bf16_tile128_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t
     epilogue_staged<128, 128, 4, 4, 4>(acc, ep, C, ldc, M, N, m0, n0, wm * 64, wn * 64, wave, lane, smem);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Split-K for skinny GEMMs (M <= 256: the student pass of training, decode steps of generate).  With one or two tile
+// rows a 128 x 128 grid has 32-172 workgroups and each streams its whole weight slab alone: 134 us average on the
+// student's shapes against a 7-36 us weight-bandwidth floor.  Here blockIdx.y cuts K into `splits` ranges; every
+// workgroup writes its fp32 partial tile to its own slice of a caller-provided workspace ([split][M_pad][N_pad], no
+// atomics -> bit-reproducible), and a second kernel sums the slices in a fixed order and runs the usual epilogue.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2)
+void gemm_bf16_splitk_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw,
+                        float* __restrict__ ws, int M, int N, int K, int tiles_m, int tiles_n, int kt_per_split) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // [2 stages][A 16 KiB | W 16 KiB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    const int m0 = tm * 128, n0 = tn * 128;
+    const int64_t a_bytes = (int64_t)(M - m0) * lda * 2, w_bytes = (int64_t)(N - n0) * ldw * 2;
+    const int lim = 0x7ffffff0;
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (int64_t)m0 * lda), 0, (int)(a_bytes < lim ? a_bytes : lim), 0x00020000);
+    const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (int64_t)n0 * ldw), 0, (int)(w_bytes < lim ? w_bytes : lim), 0x00020000);
+    const int srow = tid >> 3, schunk = tid & 7;
+    u32x4 ra[4], rw[4];
+    auto load_tile = [&](int kt) {
+        const int k = kt * BK + schunk * 8;
+        const bool kin = k < K;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = srow + 32 * i;
+            const unsigned offA = kin ? (unsigned)(((int64_t)row * lda + k) * 2) : 0x80000000u;
+            const unsigned offW = kin ? (unsigned)(((int64_t)row * ldw + k) * 2) : 0x80000000u;
+            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, offA, 0, 0);
+            rw[i] = __builtin_amdgcn_raw_buffer_load_b128(rsW, offW, 0, 0);
+        }
+    };
+    auto store_tile = [&](int st) {
+        char* sa = smem + st * 32768;
+        char* sw = sa + 16384;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = srow + 32 * i;
+            *reinterpret_cast<u32x4*>(sa + lds_off(row, schunk)) = ra[i];
+            *reinterpret_cast<u32x4*>(sw + lds_off(row, schunk)) = rw[i];
+        }
+    };
+    floatx4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    const int nkt = (K + BK - 1) / BK;
+    const int kt0 = blockIdx.y * kt_per_split, kt1 = min(nkt, kt0 + kt_per_split);
+    if (kt0 < kt1) {
+        load_tile(kt0);
+        store_tile(0);
+        __syncthreads();
+        const int frow = lane & 15, fchunk = lane >> 4;
+        for (int kt = kt0; kt < kt1; ++kt) {
+            const int cur = (kt - kt0) & 1;
+            if (kt + 1 < kt1) load_tile(kt + 1);
+            const char* sa = smem + cur * 32768 + (wm * 64) * 128;
+            const char* sw = smem + cur * 32768 + 16384 + (wn * 64) * 128;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 fa[4], fw[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    fa[i] = *reinterpret_cast<const bf16x8*>(sa + lds_off(i * 16 + frow, kk * 4 + fchunk));
+                    fw[i] = *reinterpret_cast<const bf16x8*>(sw + lds_off(i * 16 + frow, kk * 4 + fchunk));
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
+            }
+            if (kt + 1 < kt1) store_tile(cur ^ 1);
+            __syncthreads();
+        }
+    }
+    // partial tile -> this split's workspace slice, accumulator layout: lane owns 4 consecutive columns of 16 rows
+    const int64_t np = (int64_t)tiles_n * 128;
+    float* slice = ws + (int64_t)blockIdx.y * ((int64_t)tiles_m * 128) * np;
+    const int rl = m0 + wm * 64 + (lane & 15), c0 = n0 + wn * 64 + (lane >> 4) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<floatx4*>(slice + (int64_t)(rl + i * 16) * np + c0 + j * 16) = acc[i][j];
+}
+
+__global__ __launch_bounds__(256, 2)
+void gemm_splitk_finalize_k(const float* __restrict__ ws, void* __restrict__ C, int64_t ldc, int M, int N, int tiles_m, int tiles_n,
+                            int splits, GemmEpi ep) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    const int m0 = tm * 128, n0 = tn * 128;
+    const int64_t np = (int64_t)tiles_n * 128, slice = ((int64_t)tiles_m * 128) * np;
+    const int rl = m0 + wm * 64 + (lane & 15), c0 = n0 + wn * 64 + (lane >> 4) * 4;
+    floatx4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float* p = ws + (int64_t)(rl + i * 16) * np + c0 + j * 16;
+            floatx4 v = *reinterpret_cast<const floatx4*>(p);
+            for (int sp = 1; sp < splits; ++sp) v += *reinterpret_cast<const floatx4*>(p + sp * slice);      // fixed order
+            acc[i][j] = v;
+        }
+    epilogue_staged<128, 128, 4, 4, 4>(acc, ep, C, ldc, M, N, m0, n0, wm * 64, wn * 64, wave, lane, smem);
+}
+
 // gate/up rows interleaved in blocks of 16: packed[32b + i] = gate[16b + i], packed[32b + 16 + i] = up[16b + i]
 __global__ __launch_bounds__(256)
 void pack_gate_up_k(const bf16_t* __restrict__ g, const bf16_t* __restrict__ u, bf16_t* __restrict__ out, int64_t inter, int64_t K) {
@@ -1164,6 +1276,62 @@ extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
         gemm_bf16_tile128_k<<<dim3(tiles_m * tiles_n), dim3(256), 65536, (hipStream_t)stream>>>(
             (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep);
     }
+    LICV_LAUNCH_CHECK();
+    return LICV_OK;
+}
+
+// splits and workspace bytes the skinny-M path wants for (M, N, K); splits <= 1 means "use licv_gemm_bf16"
+extern "C" int licv_gemm_splitk_plan(int64_t M, int64_t N, int64_t K, int* splits, int64_t* workspace_bytes) {
+    LICV_CHECK_ARG(splits && workspace_bytes, "gemm_splitk_plan: null pointer");
+    *splits = 1; *workspace_bytes = 0;
+    // measured (scratch/gemm_skinny.py): worth it from K ~ 8192 up (K = 11008: 132 -> 69 us at M = 256); at K = 4096 the extra
+    // fp32 round trip through the workspace and the second launch cancel the gain
+    if (M <= 0 || M > 256 || K < 8192 || K % 8 != 0 || N < 128) return LICV_OK;
+    const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    const int64_t nkt = (K + BK - 1) / BK;
+    int64_t sp = (512 + tiles - 1) / tiles;                       // aim at ~512 workgroups
+    if (sp > nkt / 4) sp = nkt / 4;                               // at least 4 K-tiles (256 K) per split
+    if (sp > 16) sp = 16;
+    if (sp < 2) return LICV_OK;
+    *splits = (int)sp;
+    *workspace_bytes = sp * ((M + 127) / 128 * 128) * ((N + 127) / 128 * 128) * 4;
+    return LICV_OK;
+}
+
+extern "C" int licv_gemm_bf16_splitk(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
+                                     int64_t M, int64_t N, int64_t K, const licv_gemm_epilogue* e, int splits,
+                                     void* workspace, int64_t workspace_bytes, void* stream) {
+    LICV_CHECK_ARG(A && W && C && e && workspace, "gemm_bf16_splitk: null pointer");
+    LICV_CHECK_ARG(M > 0 && N > 0 && K > 0 && splits >= 2, "gemm_bf16_splitk: bad shape / splits");
+    LICV_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0 && K % 8 == 0, "gemm_bf16_splitk: lda/ldw/K must be multiples of 8");
+    LICV_CHECK_ARG(ldc % 4 == 0, "gemm_bf16_splitk: ldc (%lld) must be a multiple of 4", (long long)ldc);
+    LICV_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)C & 15) == 0 && ((uintptr_t)workspace & 15) == 0,
+                   "gemm_bf16_splitk: pointers must be 16-byte aligned");
+    LICV_CHECK_ARG(e->out_dtype == LICV_BF16 || e->out_dtype == LICV_F32, "gemm_bf16_splitk: bad out dtype");
+    LICV_CHECK_ARG(e->act >= 0 && e->act <= 3, "gemm_bf16_splitk: bad activation %d", e->act);
+    LICV_CHECK_ARG(!e->swiglu || (N % 32 == 0 && !e->bias_bf16 && !e->act), "gemm_bf16_splitk: swiglu needs N %% 32 == 0, no bias/act");
+    LICV_CHECK_ARG(!e->residual || (e->ld_res % 4 == 0 && ((uintptr_t)e->residual & 15) == 0), "gemm_bf16_splitk: residual misaligned");
+    const int tiles_m = (int)((M + 127) / 128), tiles_n = (int)((N + 127) / 128);
+    const int64_t need = (int64_t)splits * tiles_m * 128 * (int64_t)tiles_n * 128 * 4;
+    LICV_CHECK_ARG(workspace_bytes >= need, "gemm_bf16_splitk: workspace %lld B < %lld B", (long long)workspace_bytes, (long long)need);
+    const int nkt = (int)((K + BK - 1) / BK);
+    const int per = (nkt + splits - 1) / splits;
+    GemmEpi ep;
+    ep.bias = (const bf16_t*)e->bias_bf16; ep.row_gate = e->row_gate; ep.residual = e->residual;
+    ep.residual_dtype = e->residual_dtype; ep.ld_res = e->ld_res; ep.act = e->act; ep.swiglu = e->swiglu;
+    ep.use_scale = e->use_scale; ep.scale = e->scale; ep.out_dtype = e->out_dtype;
+    ep.a_scale = nullptr; ep.w_scale = nullptr;
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute((const void*)gemm_bf16_splitk_k, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        hipFuncSetAttribute((const void*)gemm_splitk_finalize_k, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        attr = true;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    gemm_bf16_splitk_k<<<dim3(tiles_m * tiles_n, splits), dim3(256), 65536, st>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw,
+        (float*)workspace, (int)M, (int)N, (int)K, tiles_m, tiles_n, per);
+    gemm_splitk_finalize_k<<<dim3(tiles_m * tiles_n), dim3(256), 65536, st>>>((const float*)workspace, C, ldc, (int)M, (int)N,
+        tiles_m, tiles_n, splits, ep);
     LICV_LAUNCH_CHECK();
     return LICV_OK;
 }

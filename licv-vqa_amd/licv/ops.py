@@ -152,6 +152,30 @@ def rotary_(buf: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, position_id
 
 
 # ------------------------------------------------------------------------------------------ GEMM
+SPLITK = True               # False: never take the split-K path (A/B timing, kernel-agreement tests)
+_plans: dict = {}
+_ws: dict = {}
+
+
+def _splitk_plan(M: int, N: int, K: int):
+    key = (M, N, K)
+    if key not in _plans:
+        sp, nb = C.c_int(1), C.c_int64(0)
+        check(_lib.lib().licv_gemm_splitk_plan(M, N, K, C.byref(sp), C.byref(nb)))
+        _plans[key] = (sp.value, nb.value)
+    return _plans[key]
+
+
+def _workspace(device, nbytes: int) -> torch.Tensor:
+    """Grow-only scratch for split-K partial tiles; launches on one stream serialise, so consecutive GEMMs may share it."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty((max(nbytes, 1 << 20),), dtype=torch.uint8, device=device)
+        _ws[key] = buf
+    return buf
+
+
 def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act=None, swiglu: bool = False,
            row_gate: Optional[torch.Tensor] = None, scale: Optional[float] = None, residual: Optional[torch.Tensor] = None,
            out: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None, M: Optional[int] = None,
@@ -186,8 +210,14 @@ def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     ep.use_scale = 0 if scale is None else 1
     ep.scale = 0.0 if scale is None else float(scale)
     ep.out_dtype = _dt(out)
-    _timed("gemm", 2.0 * M * N * K, lambda: check(_lib.lib().licv_gemm_bf16(
-        _p(a), lda, _p(w), K, _p(out), ldc, M, N, K, C.byref(ep), _stream(a))), label=(M, N, K))
+    splits, ws_bytes = _splitk_plan(M, N, K) if SPLITK else (1, 0)
+    if splits > 1:                      # skinny GEMM (student pass, decode steps): deterministic split-K through a workspace
+        ws = _workspace(a.device, ws_bytes)
+        _timed("gemm", 2.0 * M * N * K, lambda: check(_lib.lib().licv_gemm_bf16_splitk(
+            _p(a), lda, _p(w), K, _p(out), ldc, M, N, K, C.byref(ep), splits, _p(ws), ws.numel(), _stream(a))), label=(M, N, K))
+    else:
+        _timed("gemm", 2.0 * M * N * K, lambda: check(_lib.lib().licv_gemm_bf16(
+            _p(a), lda, _p(w), K, _p(out), ldc, M, N, K, C.byref(ep), _stream(a))), label=(M, N, K))
     return out if ret is None else ret
 
 

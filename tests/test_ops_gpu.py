@@ -498,3 +498,33 @@ def test_attention_bwd_small_matches_closed_form(B, nh, Sq, Sk, hd, mode):
     for name, g_, r_ in zip(("dQ", "dK", "dV"), got, ref):
         tol = 2 * 2.0 ** -8 * float(r_.abs().max())
         assert float((g_ - r_).abs().max()) <= tol, f"{name}: {float((g_ - r_).abs().max()):.3e} > {tol:.3e}"
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(256, 4096, 8192, "none"), (24, 2050, 9216, "bias"), (200, 1408, 8192, "swiglu"),
+                                       (256, 1024, 11008, "res32"), (130, 384, 22016, "res16")])
+def test_gemm_splitk_matches_plain_kernel_and_is_reproducible(M, N, K, epi):
+    """Skinny-M split-K path (student pass, decode): same results as the single-pass kernel up to the order of the fp32
+    partial sums (<= 1 bf16 ulp of the output scale), bit-identical from run to run (no atomics)."""
+    from licv import ops as O_
+    gen = g(M + N + K)
+    a = torch.randn(M, K, generator=gen).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(N, K, generator=gen) * 0.03).to(torch.bfloat16).to(DEV)
+    kw = {}
+    if epi == "bias":
+        kw = dict(bias=(torch.randn(N, generator=gen) * 0.1).to(torch.bfloat16).to(DEV))
+    elif epi == "swiglu":
+        kw = dict(swiglu=True)
+    elif epi == "res32":
+        kw = dict(residual=torch.randn(M, N, generator=gen).to(DEV))
+    elif epi == "res16":
+        kw = dict(residual=torch.randn(M, N, generator=gen).to(torch.bfloat16).to(DEV))
+    assert O_._splitk_plan(M, N, K)[0] > 1
+    y1 = O_.linear(a, w, **kw).clone()
+    y2 = O_.linear(a, w, **kw).clone()
+    assert torch.equal(y1, y2)
+    try:
+        O_.SPLITK = False
+        ref = O_.linear(a, w, **kw).clone()
+    finally:
+        O_.SPLITK = True
+    assert (y1.float() - ref.float()).abs().max() <= 2.0 ** -7 * ref.float().abs().max()
