@@ -32,6 +32,8 @@ WORKLOADS = {
     "idefics9b_32shot_bs8": ("idefics-9b", 8, 800, 33, 720),
     "idefics9b_student_bs8": ("idefics-9b", 8, 32, 1, 24),
     "idefics_mid_debug": ("idefics-mid", 4, 96, 5, 80),
+    # ref:inference.py:300-321 shape: hooked generate on the query-only prompt, 3 beams, 5 new tokens (ref:config/inference.yaml:26-30)
+    "idefics9b_generate_bs8": ("idefics-9b", 8, 32, 1, 32),
     # BASELINE configs[2]: L-ICV training step = teacher (32-shot, no grad) + student (query only, with grad) + KL +
     # backward + [every 2nd micro-batch] all-reduce + clipped AdamW.  (arch, B, S_teacher, n_img_teacher, min_len)
     "idefics9b_train_bs8": ("idefics-9b", 8, 800, 33, 720),
@@ -241,9 +243,17 @@ def main():
     layers = list(range(arch.num_layers))
     hooks = {} if args.no_hooks else dict(icv=icv, alpha=alpha, hook_layers=layers)
 
+    generating = "generate" in args.workload
+    if generating:
+        from licv.generation import generate as native_generate
+        gen_hooks = {} if args.no_hooks else dict(icv=alpha.unsqueeze(-1) * icv, hook_layers=layers)
+
     def step():
         if training:
             return trainer.micro_batch(*train_args)
+        if generating:
+            return native_generate(eng, batch["input_ids"], batch["attention_mask"], batch["pixel_values"], batch["image_attention_mask"],
+                                   max_new_tokens=5, num_beams=3, length_penalty=0.0, **gen_hooks)
         return eng.forward(**batch, **hooks)
 
     def fence():
@@ -289,6 +299,7 @@ def main():
         "metric": (f"VQA questions/sec (whole node), Idefics2-8B-base {'32' if n_img > 2 else '1'}-shot L-ICV training micro-batch" if is2 and training else
                    f"VQA questions/sec (whole node), Idefics2-8B-base {'32' if n_img > 2 else '1'}-shot ICV forward" if is2 else
                    "VQA questions/sec (whole node), Idefics-9B 32-shot L-ICV training micro-batch" if training else
+                   "VQA questions/sec (whole node), Idefics-9B hooked generate (query-only prompt, 3 beams, 5 new tokens)" if generating else
                    "VQA questions/sec (whole node), Idefics-9B 32-shot ICV forward"),
         "value": qps, "unit": "questions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
