@@ -488,7 +488,7 @@ extern "C" int licv_attn_fwd(const licv_attn_args* x, void* stream) {
             hipStream_t rst = (hipStream_t)stream;
             const bool small = (int64_t)skp * (dpk / 8) <= 8 * 512;
 #define RES_LAUNCH(DK, DV, MI) do { static bool attr_##DK##_##DV##_##MI = false; \
-                if (!attr_##DK##_##DV##_##MI) { hipFuncSetAttribute((const void*)attn_resident_k<DK, DV, MI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_##DK##_##DV##_##MI = true; } \
+                if (!attr_##DK##_##DV##_##MI) { (void)hipFuncSetAttribute((const void*)attn_resident_k<DK, DV, MI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_##DK##_##DV##_##MI = true; } \
                 attn_resident_k<DK, DV, MI><<<rgrid, rblock, lds, rst>>>(p, skp, n_items); } while (0)
             if (dpk == 64)      { if (small) RES_LAUNCH(64, 64, 8); else RES_LAUNCH(64, 64, 10); }
             else if (dpv == 80) { if (small) RES_LAUNCH(96, 80, 8); else RES_LAUNCH(96, 80, 10); }

@@ -364,7 +364,7 @@ extern "C" int licv_attn_bwd_small(const licv_attn_args* x, const void* dout, vo
     p.n_img = (int)x->n_img; p.img_len = (int)x->img_len; p.want_dkv = want;
     const size_t lds = (size_t)2 * x->Sq * x->Sk * sizeof(float);
     static bool attr = false;
-    if (!attr) { hipFuncSetAttribute((const void*)attn_bwd_small_k, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); attr = true; }
+    if (!attr) { (void)hipFuncSetAttribute((const void*)attn_bwd_small_k, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); attr = true; }
     attn_bwd_small_k<<<(unsigned)(x->B * x->n_heads), 256, lds, (hipStream_t)stream>>>(p);
     LICV_LAUNCH_CHECK();
     return LICV_OK;

@@ -25,7 +25,7 @@ void dbg_tile_write_k(bf16_t* C, int64_t ldc, int M, int N, int tiles_n, int mod
 extern "C" int licv_dbg_tile_write(void* C, int64_t ldc, int64_t M, int64_t N, int mode, int lds_bytes, void* stream) {
     if (!C || ldc < N || M <= 0 || N <= 0 || lds_bytes < 0 || lds_bytes > 163840) return LICV_E_BADARG;
     const int tiles_m = (int)((M + 255) / 256), tiles_n = (int)((N + 255) / 256);
-    hipFuncSetAttribute((const void*)dbg_tile_write_k, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    (void)hipFuncSetAttribute((const void*)dbg_tile_write_k, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
     dbg_tile_write_k<<<tiles_m * tiles_n, 512, lds_bytes, (hipStream_t)stream>>>((bf16_t*)C, ldc, (int)M, (int)N, tiles_n, mode);
     return LICV_OK;
 }

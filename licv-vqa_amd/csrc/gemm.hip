@@ -1218,17 +1218,17 @@ extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
             g_num_cus = cus;
-        hipFuncSetAttribute((const void*)gemm_bf16_tile128_k, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        hipFuncSetAttribute((const void*)gemm_bf16_persist_k, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
-        hipFuncSetAttribute((const void*)gemm_bf16_pingpong_k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
-        hipFuncSetAttribute((const void*)gemm_bf16_pingpong_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
-        hipFuncSetAttribute((const void*)gemm_bf16_pingpong_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
-        hipFuncSetAttribute((const void*)gemm_bf16_pingpong_k<3>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
-        hipFuncSetAttribute((const void*)gemm_bf16_pingpong_k<4>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
-        hipFuncSetAttribute((const void*)gemm_bf16_ring_k, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
-        hipFuncSetAttribute((const void*)gemm_bf16_tile256_k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, T256_LDS);
-        hipFuncSetAttribute((const void*)gemm_bf16_tile256_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, T256_LDS);
-        hipFuncSetAttribute((const void*)gemm_bf16_tile256_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, T256_LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_tile128_k, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_persist_k, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_pingpong_k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_pingpong_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_pingpong_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_pingpong_k<3>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_pingpong_k<4>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_ring_k, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_tile256_k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, T256_LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_tile256_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, T256_LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_tile256_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, T256_LDS);
         attr_set = true;
     }
     const bool can256 = (K % BK == 0);
@@ -1323,8 +1323,8 @@ extern "C" int licv_gemm_bf16_splitk(const void* A, int64_t lda, const void* W, 
     ep.a_scale = nullptr; ep.w_scale = nullptr;
     static bool attr = false;
     if (!attr) {
-        hipFuncSetAttribute((const void*)gemm_bf16_splitk_k, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        hipFuncSetAttribute((const void*)gemm_splitk_finalize_k, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_splitk_k, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        (void)hipFuncSetAttribute((const void*)gemm_splitk_finalize_k, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
         attr = true;
     }
     hipStream_t st = (hipStream_t)stream;
@@ -1354,7 +1354,7 @@ extern "C" int licv_gemm_fp8(const void* Aq, int64_t lda, const float* a_scale, 
     ep.use_scale = e->use_scale; ep.scale = e->scale; ep.out_dtype = e->out_dtype;
     ep.a_scale = a_scale; ep.w_scale = w_scale;
     static bool attr = false;
-    if (!attr) { hipFuncSetAttribute((const void*)gemm_fp8_pingpong_k, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES); attr = true; }
+    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_fp8_pingpong_k, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES); attr = true; }
     const int tiles_m = (int)((M + 255) / 256), tiles_n = (int)((N + 255) / 256);
     gemm_fp8_pingpong_k<<<dim3(tiles_m * tiles_n), dim3(512), RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>(
         (const char*)Aq, lda, (const char*)Wq, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep);
