@@ -649,8 +649,10 @@ void gemm_bf16_pingpong_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_
     long long* ts = (g_dbg_ts && tid == 0) ? g_dbg_ts + (int64_t)blockIdx.x * 8 : nullptr;
     if (ts) ts[0] = wall_clock64();
     int tm, tn;
-    tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn, group);
+    tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn, ABL == 5 ? 8 : group);
     const int m0 = tm * 256, n0 = tn * 256;
+    // ABL 5 = split-K producer: blockIdx.y selects a range of `group` K stages; C is the fp32 workspace ([split][M_pad][N_pad])
+    const int kbase = ABL == 5 ? (int)blockIdx.y * group : 0;
 
     const bf16_t* srcA[2];
     const bf16_t* srcW[2];
@@ -661,7 +663,7 @@ void gemm_bf16_pingpong_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_
         srcA[i] = A + (int64_t)min(m0 + row, M - 1) * lda + chunk * 8;
         srcW[i] = W + (int64_t)min(n0 + row, N - 1) * ldw + chunk * 8;
     }
-    const int ns = K / 32;                                   // >= 4 (host guarantees K >= 128)
+    const int ns = ABL == 5 ? min(group, K / 32 - kbase) : K / 32;   // stages this workgroup runs (>= 4, host-guaranteed)
     // First-round start stagger by XCD (blockIdx % 8): every tile of a GEMM takes the same time, so all 256 CUs reach
     // their epilogue together and its HBM traffic arrives as one burst (measured 3.5-3.9 TB/s for 8-38 us per tile while
     // the MFMA pipes idle).  Offsetting the XCDs by an eighth of a tile time each spreads the bursts; later workgroups
@@ -674,7 +676,7 @@ void gemm_bf16_pingpong_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_
         char* sa = smem + (s % RING_STAGES) * RING_STAGE_BYTES + wave * 32 * 64;
         char* sw = sa + 16384;
         if (ABL == 2) return;                                    // timing-only ablation: no operand stream at all
-        const int64_t koff = (int64_t)s * 32, koffw = koff;
+        const int64_t koff = (int64_t)(kbase + s) * 32, koffw = koff;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + koff),
@@ -742,6 +744,17 @@ void gemm_bf16_pingpong_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(acc[i][j]));
+        return;
+    }
+    if (ABL == 5) {                                          // fp32 partial tile -> this split's workspace slice
+        const int64_t np = (int64_t)tiles_n * 256;
+        float* slice = reinterpret_cast<float*>(C) + (int64_t)blockIdx.y * ((int64_t)tiles_m * 256) * np;
+        const int rl = m0 + wm * 128 + (lane & 15), c0 = n0 + wn * 64 + (lane >> 4) * 4;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<floatx4*>(slice + (int64_t)(rl + i * 16) * np + c0 + j * 16) = acc[i][j];
         return;
     }
     epilogue_staged<256, 256, 8, 8, 4>(acc, ep, C, ldc, M, N, m0, n0, wm * 128, wn * 64, wave, lane, smem, ts);
@@ -1284,6 +1297,20 @@ extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
 extern "C" int licv_gemm_splitk_plan(int64_t M, int64_t N, int64_t K, int* splits, int64_t* workspace_bytes) {
     LICV_CHECK_ARG(splits && workspace_bytes, "gemm_splitk_plan: null pointer");
     *splits = 1; *workspace_bytes = 0;
+    if (M > 256) {
+        // few 256 x 256 tiles and a long K (Idefics2 1-shot down-projection: 1376 x 4096 x 14336 = 96 tiles on 256 CUs, 257 us):
+        // the ping-pong kernel itself produces the partials (workspace padded to 256)
+        const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256);
+        if (M >= 512 && N >= 256 && K >= 8192 && K % 64 == 0 && t256 <= 128) {
+            int64_t sp = 320 / t256;
+            if (sp > 4) sp = 4;
+            if (sp >= 2) {
+                *splits = (int)sp;
+                *workspace_bytes = sp * ((M + 255) / 256 * 256) * ((N + 255) / 256 * 256) * 4;
+            }
+        }
+        return LICV_OK;
+    }
     // measured (scratch/gemm_skinny.py): worth it from K ~ 8192 up (K = 11008: 132 -> 69 us at M = 256); at K = 4096 the extra
     // fp32 round trip through the workspace and the second launch cancel the gain
     if (M <= 0 || M > 256 || K < 8192 || K % 8 != 0 || N < 128) return LICV_OK;
@@ -1311,9 +1338,13 @@ extern "C" int licv_gemm_bf16_splitk(const void* A, int64_t lda, const void* W, 
     LICV_CHECK_ARG(e->act >= 0 && e->act <= 3, "gemm_bf16_splitk: bad activation %d", e->act);
     LICV_CHECK_ARG(!e->swiglu || (N % 32 == 0 && !e->bias_bf16 && !e->act), "gemm_bf16_splitk: swiglu needs N %% 32 == 0, no bias/act");
     LICV_CHECK_ARG(!e->residual || (e->ld_res % 4 == 0 && ((uintptr_t)e->residual & 15) == 0), "gemm_bf16_splitk: residual misaligned");
+    const bool big = M > 256;                                  // partials from the 256 x 256 ping-pong kernel
+    const int pad = big ? 256 : 128;
     const int tiles_m = (int)((M + 127) / 128), tiles_n = (int)((N + 127) / 128);
-    const int64_t need = (int64_t)splits * tiles_m * 128 * (int64_t)tiles_n * 128 * 4;
+    const int64_t mp = (M + pad - 1) / pad * pad, npad = (N + pad - 1) / pad * pad;
+    const int64_t need = (int64_t)splits * mp * npad * 4;
     LICV_CHECK_ARG(workspace_bytes >= need, "gemm_bf16_splitk: workspace %lld B < %lld B", (long long)workspace_bytes, (long long)need);
+    LICV_CHECK_ARG(!big || (K % 64 == 0 && (K / 32) / splits >= 8), "gemm_bf16_splitk: K too short for %d splits of the 256-tile kernel", splits);
     const int nkt = (int)((K + BK - 1) / BK);
     const int per = (nkt + splits - 1) / splits;
     GemmEpi ep;
@@ -1328,10 +1359,22 @@ extern "C" int licv_gemm_bf16_splitk(const void* A, int64_t lda, const void* W, 
         attr = true;
     }
     hipStream_t st = (hipStream_t)stream;
-    gemm_bf16_splitk_k<<<dim3(tiles_m * tiles_n, splits), dim3(256), 65536, st>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw,
-        (float*)workspace, (int)M, (int)N, (int)K, tiles_m, tiles_n, per);
-    gemm_splitk_finalize_k<<<dim3(tiles_m * tiles_n), dim3(256), 65536, st>>>((const float*)workspace, C, ldc, (int)M, (int)N,
-        tiles_m, tiles_n, splits, ep);
+    if (big) {
+        static bool attr5 = false;
+        if (!attr5) { (void)hipFuncSetAttribute((const void*)gemm_bf16_pingpong_k<5>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES); attr5 = true; }
+        const int t256m = (int)(mp / 256), t256n = (int)(npad / 256);
+        const int stages = (int)(K / 32), per32 = (stages + splits - 1) / splits;
+        gemm_bf16_pingpong_k<5><<<dim3(t256m * t256n, splits), dim3(512), RING_STAGES * RING_STAGE_BYTES, st>>>(
+            (const bf16_t*)A, lda, (const bf16_t*)W, ldw, workspace, 0, (int)M, (int)N, (int)K, t256m, t256n, ep, 0, per32);
+        // the finalize kernel walks 128 x 128 tiles of the same [split][M_pad][N_pad] workspace
+        gemm_splitk_finalize_k<<<dim3((int)(mp / 128) * (int)(npad / 128)), dim3(256), 65536, st>>>((const float*)workspace, C, ldc, (int)M, (int)N,
+            (int)(mp / 128), (int)(npad / 128), splits, ep);
+    } else {
+        gemm_bf16_splitk_k<<<dim3(tiles_m * tiles_n, splits), dim3(256), 65536, st>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw,
+            (float*)workspace, (int)M, (int)N, (int)K, tiles_m, tiles_n, per);
+        gemm_splitk_finalize_k<<<dim3(tiles_m * tiles_n), dim3(256), 65536, st>>>((const float*)workspace, C, ldc, (int)M, (int)N,
+            tiles_m, tiles_n, splits, ep);
+    }
     LICV_LAUNCH_CHECK();
     return LICV_OK;
 }

@@ -71,11 +71,22 @@ def test_fullsize_hook_properties(full):
     assert cap["edited"][-1].dtype == torch.bfloat16
     assert float((off.float() - lg.float()).abs().max()) > 1e-2 * scale
     del cap
-    # P2: rows 0 and 5 alone (their own images, masks and lengths)
+    # P2: rows 0 and 5 alone (their own images, masks and lengths).  A single question is 800 rows: its K = 11008 down-projections
+    # take the split-K path (64 tiles on 256 CUs otherwise), which adds the fp32 partial sums in another order than the one-pass
+    # kernel of the batch of 8 -> bit-exact with that path off, within the model's bf16 noise floor with it on.
+    from licv import ops
     for b in (0, 5):
         one = {k: v[b:b + 1].contiguous() for k, v in batch.items()}
         alone = eng.forward(**one, icv=scaled, hook_layers=layers)
-        assert torch.equal(alone[0], lg[b]), f"row {b} depends on its batch neighbours"
+        d = alone[0].float() - lg[b].float()
+        assert float(d.norm() / lg[b].float().norm()) <= 6e-2 and float(d.abs().max()) <= 0.15 * scale
+        try:
+            ops.SPLITK = False
+            alone = eng.forward(**one, icv=scaled, hook_layers=layers)
+            whole = eng.forward(**ins, icv=scaled, hook_layers=layers) if b == 0 else whole
+        finally:
+            ops.SPLITK = True
+        assert torch.equal(alone[0], whole[b]), f"row {b} depends on its batch neighbours"
 
 
 def test_fullsize_idefics2_properties():
@@ -118,9 +129,10 @@ def test_fullsize_idefics2_properties():
         try:
             ops.SPLITK = False
             alone = eng.forward(**one, icv=scaled, hook_layers=layers)
+            whole = eng.forward(**batch, icv=scaled, hook_layers=layers) if b == 0 else whole
         finally:
             ops.SPLITK = True
-        assert torch.equal(alone[0], lg[b]), f"row {b} depends on its batch neighbours"
+        assert torch.equal(alone[0], whole[b]), f"row {b} depends on its batch neighbours"
 
 
 def test_fullsize_training_micro_batch_properties(full):

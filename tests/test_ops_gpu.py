@@ -501,7 +501,8 @@ def test_attention_bwd_small_matches_closed_form(B, nh, Sq, Sk, hd, mode):
 
 
 @pytest.mark.parametrize("M,N,K,epi", [(256, 4096, 8192, "none"), (24, 2050, 9216, "bias"), (200, 1408, 8192, "swiglu"),
-                                       (256, 1024, 11008, "res32"), (130, 384, 22016, "res16")])
+                                       (256, 1024, 11008, "res32"), (130, 384, 22016, "res16"),
+                                       (1376, 4096, 14336, "res32"), (600, 512, 8192, "bias"), (800, 2048, 11008, "swiglu")])
 def test_gemm_splitk_matches_plain_kernel_and_is_reproducible(M, N, K, epi):
     """Skinny-M split-K path (student pass, decode): same results as the single-pass kernel up to the order of the fp32
     partial sums (<= 1 bf16 ulp of the output scale), bit-identical from run to run (no atomics)."""
