@@ -1,23 +1,23 @@
 """Output record + base class of the ICV encoders (API of ref:icv_src/icv_encoder/base_icv_encoder.py:7-23)."""
-from dataclasses import dataclass
-from typing import Optional
+from typing import NamedTuple, Optional
 
 import torch
 
 
-@dataclass
-class ICVEncoderOutput:
-    """What an encoder hands to the intervention: the per-layer vectors and their scales."""
-    in_context_feature: Optional[torch.Tensor]      # unused by the global encoder (always None)
-    in_context_vector: Optional[torch.Tensor]       # (1, n_layers, hidden) fp32
-    alpha: Optional[torch.Tensor]                   # (1, n_layers) fp32, post-sigmoid when enabled
+class ICVEncoderOutput(NamedTuple):
+    """What an encoder hands to the intervention (fields and their order as in the reference's record)."""
+    in_context_feature: Optional[torch.Tensor] = None      # unused by the global encoder
+    in_context_vector: Optional[torch.Tensor] = None       # (1, n_layers, hidden) fp32
+    alpha: Optional[torch.Tensor] = None                   # (1, n_layers) fp32, post-sigmoid when enabled
 
 
 class BaseICVEncoder(torch.nn.Module):
+    """Encoders own ``alpha`` (per-layer scale) and whatever produces the vectors; subclasses implement ``forward``."""
+
     def __init__(self) -> None:
         super().__init__()
-        self.alpha = None
-        self.icv_encoder = None
+        for slot in ("alpha", "icv_encoder"):
+            setattr(self, slot, None)
 
     def forward(self, *args, **kwargs) -> ICVEncoderOutput:
-        raise NotImplementedError
+        raise NotImplementedError(f"{type(self).__name__} does not implement forward()")

@@ -18,54 +18,55 @@ import torch.nn as nn
 from licv.intervention import NativeIntervention
 
 
+def _layer_list(spec: Union[int, List[int]], total: int) -> List[int]:
+    """-1 -> every layer; an int -> that layer; a list -> itself (ref:icv_src/icv_model/icv_intervention.py:36-43)."""
+    if isinstance(spec, int):
+        return list(range(total)) if spec == -1 else [spec]
+    return spec
+
+
 class LearnableICVInterventionLMM(nn.Module):
     def __init__(self, lmm: nn.Module, enable_intervention=True, intervention_layer: Union[int, List[int]] = None,
                  layer_format: str = None, total_layers: int = None):
         super().__init__()
         self.lmm = lmm
-        if not enable_intervention:
-            return
-        self.total_layers = total_layers
-        self.intervention_layers = self._prepare_layers(intervention_layer)
-        self.intervention_layer_names = [layer_format.replace("<LAYER_NUM>", str(i)) for i in self.intervention_layers]
-        self.layer_to_icv_index = {int(layer): int(slot) for slot, layer in enumerate(self.intervention_layers)}
-        self.intervention_enabled = True
+        if enable_intervention:
+            self.total_layers = total_layers
+            self.intervention_layers = _layer_list(intervention_layer, total_layers)
+            self.intervention_layer_names = [layer_format.replace("<LAYER_NUM>", str(i)) for i in self.intervention_layers]
+            self.layer_to_icv_index = {int(layer): int(slot) for slot, layer in enumerate(self.intervention_layers)}
+            self.intervention_enabled = True
 
-    def _prepare_layers(self, layers):
-        if layers == -1:
-            return list(range(self.total_layers))
-        if isinstance(layers, int):
-            return [layers]
-        return layers
+    def _prepare_layers(self, layers):                      # kept: callers of the reference's private helper
+        return _layer_list(layers, self.total_layers)
 
-    @property
-    def device(self):
-        return self.lmm.device
+    device = property(lambda self: self.lmm.device)
 
-    @property
-    def intervention_status(self) -> bool:
+    def _get_status(self) -> bool:
         return self.intervention_enabled
 
-    @intervention_status.setter
-    def intervention_status(self, value: bool):
-        if not isinstance(value, bool):
+    def _set_status(self, value: bool) -> None:
+        if type(value) is not bool:
             raise ValueError("Intervention status must be a boolean value.")
         self.intervention_enabled = value
 
+    intervention_status = property(_get_status, _set_status)
+
     def toggle_intervention(self, enable: bool):
-        self.intervention_status = enable
+        self._set_status(enable)
 
     def _get_context_manager(self, icv=None, retain_grad=False):
-        if getattr(self, "intervention_enabled", False):
-            return NativeIntervention(self.lmm, self.intervention_layer_names, self.layer_to_icv_index, icv,
-                                      retain_grad=retain_grad)
-        return nullcontext()
+        if not getattr(self, "intervention_enabled", False):
+            return nullcontext()
+        return NativeIntervention(self.lmm, self.intervention_layer_names, self.layer_to_icv_index, icv, retain_grad=retain_grad)
+
+    def _run(self, fn, icv, retain_grad, args, kwargs):
+        with self._get_context_manager(icv, retain_grad=retain_grad):
+            return fn(*args, **kwargs)
 
     def forward(self, icv=None, *args, **kwargs):
         """``icv``: (1, n_hooked, hidden), already alpha-scaled (ref:icv_src/icv_module.py:89-92); the rest goes to the LMM."""
-        with self._get_context_manager(icv, retain_grad=True):
-            return self.lmm(*args, **kwargs)
+        return self._run(self.lmm, icv, True, args, kwargs)
 
     def generate(self, icv=None, *args, **kwargs):
-        with self._get_context_manager(icv, retain_grad=False):
-            return self.lmm.generate(*args, **kwargs)
+        return self._run(self.lmm.generate, icv, False, args, kwargs)
