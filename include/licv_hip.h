@@ -130,6 +130,8 @@ int licv_gemm_select(int which);
 int licv_gemm_stagger(int on);
 /* A/B timing knobs of the default kernel (0: per-XCD start stagger in percent, 1: tile-rows per XCD patch); off by default */
 int licv_gemm_experiment(int knob, int value);
+/* roofline probe: `blocks` workgroups of 4 waves each issue iters*8 register-only v_mfma_f32_16x16x32_bf16 (16384 FLOP each) */
+int licv_probe_mfma_loop(void* sink_f32, int blocks, int iters, void* stream);
 /* timing instrumentation: when non-NULL, wave 0 of every workgroup of the default kernel stores 5 wall_clock64() stamps
  * (start, pipeline filled, main loop done, output image in LDS, end) at dev_buffer[8 * blockIdx.x ...] (int64) */
 int licv_gemm_debug_timestamps(void* dev_buffer);
