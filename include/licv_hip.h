@@ -201,15 +201,17 @@ int licv_attn_bwd_small(const licv_attn_args* a, const void* dout_bf16, void* dq
  * loss_rows[i] = logsumexp(logits[rows[i], :]) - logits[rows[i], labels[i]]  (may be NULL);
  * grad[(grad_rows ? grad_rows[i] : i), :] (+)= grad_coef * (softmax - onehot), bf16 (may be NULL). */
 int licv_ce_rows(const void* logits, int dtype, const int64_t* rows, const int64_t* labels, int64_t n_rows, int64_t vocab,
-                 int64_t ld, float* loss_rows, float grad_coef, void* grad_bf16, int64_t ld_grad, const int64_t* grad_rows,
-                 int accumulate, void* stream);
+                 int64_t ld, float* loss_rows, float grad_coef, const float* grad_coef_dev, void* grad_bf16, int64_t ld_grad,
+                 const int64_t* grad_rows, int accumulate, void* stream);
 /* backward of repeat_kv (GQA): out[r, g*hd + d] = sum over the `rep` query heads of group g of src[r, (g*rep+j)*hd + d] */
 int licv_head_group_sum(const void* src_bf16, void* out_bf16, int64_t rows, int64_t n_groups, int64_t rep, int64_t head_dim,
                         int64_t ld_src, int64_t ld_out, void* stream);
-/* d loss / d student logits for the masked-KL rows: (n_rows, ld_grad >= vocab) bf16, scaled by upstream * T^2 / n_rows */
+/* d loss / d student logits for the masked-KL rows: (n_rows, ld_grad >= vocab) bf16, scaled by upstream * T^2 / n_rows
+ * (times *upstream_dev when that device pointer is given: the autograd path's incoming gradient, read without a host sync;
+ * licv_ce_rows' grad_coef_dev works the same way). */
 int licv_kl_rows_bwd(const void* stu_logits, const void* tea_logits, int dtype, const int64_t* stu_rows, const int64_t* tea_rows,
                      int64_t n_rows, int64_t vocab, int64_t ld_stu, int64_t ld_tea, float temperature, float eps, float upstream,
-                     void* grad_rows_bf16, int64_t ld_grad, void* stream);
+                     const float* upstream_dev, void* grad_rows_bf16, int64_t ld_grad, void* stream);
 
 /* ---- loss + optimiser (ref:icv_src/icv_module.py:121-134, :171-209) ---- */
 /* per-row KL(teacher||student) with eps inside the log, rows gathered by index; out_rows fp32 (n_rows). */

@@ -270,10 +270,11 @@ template <bool BF>
 __global__ __launch_bounds__(256)
 void kl_rows_bwd_k(const void* __restrict__ stu, const void* __restrict__ tea, const int64_t* __restrict__ srows,
                    const int64_t* __restrict__ trows, int64_t vocab, int64_t ld_s, int64_t ld_t, float T, float eps,
-                   float coef, bf16_t* __restrict__ grad, int64_t ld_g) {
+                   float coef, const float* __restrict__ coef_dev, bf16_t* __restrict__ grad, int64_t ld_g) {
     __shared__ float red[8];
     const int64_t row = blockIdx.x;
     const int64_t sb = srows[row] * ld_s, tb = trows[row] * ld_t;
+    if (coef_dev) coef *= *coef_dev;                      // upstream gradient that lives on the device (autograd path)
     auto ld = [&](const void* p, int64_t i) -> float {
         return BF ? bf2f(reinterpret_cast<const bf16_t*>(p)[i]) : reinterpret_cast<const float*>(p)[i];
     };
@@ -377,9 +378,10 @@ extern "C" int licv_attn_bwd_small(const licv_attn_args* x, const void* dout, vo
 template <bool BF>
 __global__ __launch_bounds__(256)
 void ce_rows_k(const void* __restrict__ logits, const int64_t* __restrict__ rows, const int64_t* __restrict__ labels, int64_t vocab,
-               int64_t ld, float* __restrict__ loss_out, float coef, bf16_t* __restrict__ grad, int64_t ld_g,
+               int64_t ld, float* __restrict__ loss_out, float coef, const float* __restrict__ coef_dev, bf16_t* __restrict__ grad, int64_t ld_g,
                const int64_t* __restrict__ grad_rows, int accumulate) {
     __shared__ float red[8];
+    if (coef_dev) coef *= *coef_dev;
     const int64_t r = blockIdx.x;
     const int64_t base = rows[r] * ld;
     const int64_t label = labels[r];
@@ -405,15 +407,15 @@ void ce_rows_k(const void* __restrict__ logits, const int64_t* __restrict__ rows
 }
 
 extern "C" int licv_ce_rows(const void* logits, int dtype, const int64_t* rows, const int64_t* labels, int64_t n_rows, int64_t vocab,
-                            int64_t ld, float* loss_rows, float grad_coef, void* grad_bf16, int64_t ld_grad, const int64_t* grad_rows,
-                            int accumulate, void* stream) {
+                            int64_t ld, float* loss_rows, float grad_coef, const float* grad_coef_dev, void* grad_bf16, int64_t ld_grad,
+                            const int64_t* grad_rows, int accumulate, void* stream) {
     LICV_CHECK_ARG(logits && rows && labels && (loss_rows || grad_bf16), "ce_rows: null pointer");
     LICV_CHECK_ARG(dtype == LICV_BF16 || dtype == LICV_F32, "ce_rows: bad dtype");
     LICV_CHECK_ARG(vocab > 0 && ld >= vocab && (!grad_bf16 || ld_grad >= vocab), "ce_rows: bad vocab / leading dims");
     if (n_rows <= 0) return LICV_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == LICV_BF16) ce_rows_k<true><<<(unsigned)n_rows, 256, 0, st>>>(logits, rows, labels, vocab, ld, loss_rows, grad_coef, (bf16_t*)grad_bf16, ld_grad, grad_rows, accumulate);
-    else                    ce_rows_k<false><<<(unsigned)n_rows, 256, 0, st>>>(logits, rows, labels, vocab, ld, loss_rows, grad_coef, (bf16_t*)grad_bf16, ld_grad, grad_rows, accumulate);
+    if (dtype == LICV_BF16) ce_rows_k<true><<<(unsigned)n_rows, 256, 0, st>>>(logits, rows, labels, vocab, ld, loss_rows, grad_coef, grad_coef_dev, (bf16_t*)grad_bf16, ld_grad, grad_rows, accumulate);
+    else                    ce_rows_k<false><<<(unsigned)n_rows, 256, 0, st>>>(logits, rows, labels, vocab, ld, loss_rows, grad_coef, grad_coef_dev, (bf16_t*)grad_bf16, ld_grad, grad_rows, accumulate);
     LICV_LAUNCH_CHECK();
     return LICV_OK;
 }
@@ -449,15 +451,15 @@ extern "C" int licv_head_group_sum(const void* src, void* out, int64_t rows, int
 
 extern "C" int licv_kl_rows_bwd(const void* stu_logits, const void* tea_logits, int dtype, const int64_t* stu_rows, const int64_t* tea_rows,
                                 int64_t n_rows, int64_t vocab, int64_t ld_stu, int64_t ld_tea, float temperature, float eps, float upstream,
-                                void* grad_rows_bf16, int64_t ld_grad, void* stream) {
+                                const float* upstream_dev, void* grad_rows_bf16, int64_t ld_grad, void* stream) {
     LICV_CHECK_ARG(stu_logits && tea_logits && stu_rows && tea_rows && grad_rows_bf16, "kl_rows_bwd: null pointer");
     LICV_CHECK_ARG(dtype == LICV_BF16 || dtype == LICV_F32, "kl_rows_bwd: bad dtype");
     LICV_CHECK_ARG(ld_grad >= vocab, "kl_rows_bwd: ld_grad smaller than vocab");
     if (n_rows <= 0) return LICV_OK;
     const float coef = upstream * temperature * temperature / (float)n_rows;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == LICV_BF16) kl_rows_bwd_k<true><<<(unsigned)n_rows, 256, 0, st>>>(stu_logits, tea_logits, stu_rows, tea_rows, vocab, ld_stu, ld_tea, temperature, eps, coef, (bf16_t*)grad_rows_bf16, ld_grad);
-    else                    kl_rows_bwd_k<false><<<(unsigned)n_rows, 256, 0, st>>>(stu_logits, tea_logits, stu_rows, tea_rows, vocab, ld_stu, ld_tea, temperature, eps, coef, (bf16_t*)grad_rows_bf16, ld_grad);
+    if (dtype == LICV_BF16) kl_rows_bwd_k<true><<<(unsigned)n_rows, 256, 0, st>>>(stu_logits, tea_logits, stu_rows, tea_rows, vocab, ld_stu, ld_tea, temperature, eps, coef, upstream_dev, (bf16_t*)grad_rows_bf16, ld_grad);
+    else                    kl_rows_bwd_k<false><<<(unsigned)n_rows, 256, 0, st>>>(stu_logits, tea_logits, stu_rows, tea_rows, vocab, ld_stu, ld_tea, temperature, eps, coef, upstream_dev, (bf16_t*)grad_rows_bf16, ld_grad);
     LICV_LAUNCH_CHECK();
     return LICV_OK;
 }

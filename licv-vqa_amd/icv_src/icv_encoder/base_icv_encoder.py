@@ -1,14 +1,17 @@
 """Output record + base class of the ICV encoders (API of ref:icv_src/icv_encoder/base_icv_encoder.py:7-23)."""
-from typing import NamedTuple, Optional
+from dataclasses import dataclass
+from typing import Optional
 
 import torch
 
 
-class ICVEncoderOutput(NamedTuple):
-    """What an encoder hands to the intervention (fields and their order as in the reference's record)."""
-    in_context_feature: Optional[torch.Tensor] = None      # unused by the global encoder
-    in_context_vector: Optional[torch.Tensor] = None       # (1, n_layers, hidden) fp32
-    alpha: Optional[torch.Tensor] = None                   # (1, n_layers) fp32, post-sigmoid when enabled
+@dataclass
+class ICVEncoderOutput:
+    """What an encoder hands to the intervention: a mutable dataclass with the reference's three fields, in its order
+    (positional construction and attribute assignment both behave as there)."""
+    in_context_feature: Optional[torch.Tensor]      # unused by the global encoder
+    in_context_vector: Optional[torch.Tensor]       # (1, n_layers, hidden) fp32
+    alpha: Optional[torch.Tensor]                   # (1, n_layers) fp32, post-sigmoid when enabled
 
 
 class BaseICVEncoder(torch.nn.Module):

@@ -10,12 +10,13 @@ One deliberate deviation: with ``enable_intervention=False`` the reference raise
 forward/generate (``intervention_enabled`` is never set, ref :22 vs :89); here that case runs un-hooked,
 which is what ref:inference.py:110 (the ICL baseline) needs.
 """
+import re
 from contextlib import nullcontext
 from typing import List, Union
 
 import torch.nn as nn
 
-from licv.intervention import NativeIntervention
+from licv.intervention import ICVHookFn, NativeIntervention
 
 
 def _layer_list(spec: Union[int, List[int]], total: int) -> List[int]:
@@ -54,6 +55,24 @@ class LearnableICVInterventionLMM(nn.Module):
 
     def toggle_intervention(self, enable: bool):
         self._set_status(enable)
+
+    def apply_icv_intervention(self, edit_layers, icv):
+        """The reference's edit-function factory (ref :61-86): returns ``fn(output, layer_name)`` that applies
+        h' = (h+v)/||h+v||*||h|| with v = icv[:, layer_to_icv_index[layer]] to a tensor output, or to element 0 of a tuple
+        output, for layer names in ``edit_layers``; other outputs pass through.  The arithmetic is the fused HIP kernel
+        (differentiable w.r.t. h and icv); outputs must live on the GPU."""
+        names = set(edit_layers)
+
+        def intervention_function(output, layer_name):
+            if layer_name not in names:
+                return output
+            slot = self.layer_to_icv_index[int(re.findall(r"\d+", layer_name)[0])]
+            if isinstance(output, tuple):
+                hidden_states, *rest = output
+                return (ICVHookFn.apply(hidden_states, icv, slot),) + tuple(rest)
+            return ICVHookFn.apply(output, icv, slot)
+
+        return intervention_function
 
     def _get_context_manager(self, icv=None, retain_grad=False):
         if not getattr(self, "intervention_enabled", False):

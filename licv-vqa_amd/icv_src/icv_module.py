@@ -3,9 +3,12 @@
 Kept from ref:icv_src/icv_module.py:15-216: constructor ``(interface, module_cfg, lmm_cfg)``; sub-modules
 ``icv_model`` / ``icv_encoder`` (state-dict keys ``icv_encoder.alpha`` / ``icv_encoder.icv``); ``temperature``;
 ``forward(query_inputs, inputs, query_x_length, in_context_length) -> (loss_dict, ICVEncoderOutput)``;
-``calculate_kl_divergence``; ``get_mask``; ``decay_temperature``; the optimiser recipe of ``configure_optimizers``
-(two lr groups, AdamW, cosine warm-up).  PyTorch-Lightning / Hydra / DeepSpeed are not used: configs are plain
-attribute namespaces (or dicts) with the reference's key names, and the trainer is ``licv.trainer``.
+``calculate_kl_divergence``; ``get_mask``; ``decay_temperature``; ``training_step``; ``configure_optimizers`` (two lr
+groups, AdamW, cosine warm-up); ``on_save_checkpoint``.  PyTorch-Lightning / Hydra / DeepSpeed are not used: configs are
+plain attribute namespaces (or dicts) with the reference's key names; ``licv.trainer.ICVTrainer`` is the data-parallel
+loop, and a caller that drives the module the Lightning way (``loss = training_step(batch, i); loss.backward();
+optimizer.step(); scheduler.step()``) gets the same numbers: the returned loss is differentiable w.r.t. ``icv`` / ``alpha``
+through ``licv.autograd`` (explicit HIP backward behind autograd nodes).
 
 Teacher and student forwards, the masked KL rows and AdamW run as HIP kernels.  CE is computed here with pads
 masked by ``attention_mask`` (the pinned transformers 4.38.2 Idefics behaviour).
@@ -71,16 +74,13 @@ class VQAICVModule(torch.nn.Module):
                            idx, idx, V, float(self.temperature), float(self.module_cfg.kl_eps))
         return rows.to(stu_logits.dtype).mean() * self.temperature ** 2
 
-    def _kl_from_masks(self, stu_logits, tea_logits, stu_mask, tea_mask):
-        """Same value as calculate_kl_divergence(stu[mask], tea[mask]) without materialising the gathered rows."""
-        B, Ss, V = stu_logits.shape
-        s_rows = stu_mask.reshape(-1).nonzero().squeeze(1)
-        t_rows = tea_mask.reshape(-1).nonzero().squeeze(1)
+    def _kl_from_rows(self, stu_logits, tea_logits, s_rows, t_rows):
+        """Same value as calculate_kl_divergence(stu[mask], tea[mask]) without materialising the gathered rows; differentiable
+        w.r.t. the student logits (licv.autograd.MaskedKLFn).  ``temperature`` enters as a constant (``learnable_t`` has no
+        native gradient)."""
+        from licv.autograd import MaskedKLFn
         assert s_rows.numel() == t_rows.numel(), "student and teacher must mask the same number of answer tokens"
-        s2 = stu_logits.as_strided((B * Ss, V), (stu_logits.stride(1), 1))
-        t2 = tea_logits.as_strided((tea_logits.shape[0] * tea_logits.shape[1], V), (tea_logits.stride(1), 1))
-        rows = ops.kl_rows(s2, t2, s_rows, t_rows, V, float(self.temperature), float(self.module_cfg.kl_eps))
-        return rows.to(stu_logits.dtype).mean() * self.temperature ** 2
+        return MaskedKLFn.apply(stu_logits, tea_logits, s_rows, t_rows, float(self.temperature), float(self.module_cfg.kl_eps))
 
     # ------------------------------------------------------------------ forward (ref :71-119)
     def forward(self, query_inputs, inputs, query_x_length, in_context_length):
@@ -91,13 +91,22 @@ class VQAICVModule(torch.nn.Module):
         if self.module_cfg.hard_loss_weight:
             query_inputs["labels"] = query_inputs["input_ids"]
         self.icv_model.toggle_intervention(True)
-        icv_outputs = self.icv_model(**query_inputs, icv=icv.detach())
+        icv_outputs = self.icv_model(**query_inputs, icv=icv)
         if _get(self.module_cfg, "only_hard_loss", False):
             return {"loss": icv_outputs["loss"]}, enc
+        s_rows = zero_shot_mask.reshape(-1).nonzero().squeeze(1)
+        t_rows = icl_context_mask.reshape(-1).nonzero().squeeze(1)
         with torch.no_grad():
             self.icv_model.toggle_intervention(False)
-            ice_logits = self.icv_model(**{k: v for k, v in inputs.items() if k != "labels"})["logits"]
-        kl_loss = self._kl_from_masks(icv_outputs["logits"], ice_logits, zero_shot_mask, icl_context_mask)
+            tea_kw = {k: v for k, v in inputs.items() if k != "labels"}
+            if getattr(self.interface, "supports_logits_rows", False):
+                # only the answer rows of the teacher enter the loss (ref :108-110): the LM head runs on those rows alone
+                ice_logits = self.icv_model(**tea_kw, logits_rows=t_rows.to(self.interface.device))["logits"]
+                t_rows = torch.arange(t_rows.numel(), device=ice_logits.device)
+            else:
+                ice_logits = self.icv_model(**tea_kw)["logits"]
+        dev = icv_outputs["logits"].device
+        kl_loss = self._kl_from_rows(icv_outputs["logits"], ice_logits, s_rows.to(dev), t_rows.to(dev))
         loss = 0.0 + kl_loss
         loss_dict = {"kl_loss": kl_loss}
         if self.module_cfg.hard_loss_weight:
@@ -105,6 +114,51 @@ class VQAICVModule(torch.nn.Module):
             loss_dict["ce_loss"] = icv_outputs["loss"]
         loss_dict["loss"] = loss
         return loss_dict, enc
+
+    # ------------------------------------------------------------------ Lightning-shaped hooks (ref :160-169, :171-216)
+    def log_dict(self, values, **_):                 # Lightning's logger is replaced by a plain record of the last values
+        self.logged = getattr(self, "logged", {})
+        self.logged.update({k: (v.detach() if torch.is_tensor(v) else v) for k, v in values.items()})
+
+    def log(self, name, value, **_):
+        self.log_dict({name: value})
+
+    def training_step(self, batch, batch_idx=0):
+        self.decay_temperature()
+        loss_dict, icv_encoder_output = self(**batch)
+        self.log_dict(loss_dict, sync_dist=True, prog_bar=True)
+        if _get(self.module_cfg, "log_alpha", False):
+            alpha = icv_encoder_output.alpha.squeeze()
+            for i in range(len(alpha)):
+                self.log(f"alpha/alpha-{i}", alpha[i])
+        self.log("temperature", self.temperature)
+        return loss_dict["loss"]
+
+    def configure_optimizers(self, estimated_stepping_batches: int = None):
+        """Two lr groups (names containing "alpha" get alpha_lr), AdamW with weight decay, cosine schedule with warm-up stepped
+        per optimiser step.  The optimiser is ``licv.optim.FusedAdamW`` (a ``torch.optim.Optimizer`` whose ``step`` is the HIP
+        AdamW kernel; replaces torch AdamW / DeepSpeedCPUAdam, ref :181-192)."""
+        from licv.optim import FusedAdamW
+        params = []
+        for name, param in self.icv_encoder.named_parameters():
+            if not param.requires_grad:
+                continue
+            if "alpha" in name:
+                params.append({"params": param, "lr": self.module_cfg.alpha_lr})
+            else:
+                params.append({"params": param})
+        optimizer = FusedAdamW(params, lr=self.module_cfg.icv_lr, weight_decay=self.module_cfg.weight_decay)
+        if estimated_stepping_batches is None:
+            estimated_stepping_batches = self.trainer.estimated_stepping_batches
+        spec = self.optimizer_spec(estimated_stepping_batches)
+        warm, total = spec["warm_steps"], spec["total_steps"]
+        scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer, lambda step: self.lr_lambda(step, warm, total))
+        return {"optimizer": optimizer, "lr_scheduler": {"scheduler": scheduler, "interval": "step"}}
+
+    def on_save_checkpoint(self, checkpoint):
+        for name in list(checkpoint["state_dict"].keys()):       # only the icv weights are kept (ref :211-216)
+            if name.startswith("model"):
+                checkpoint["state_dict"].pop(name)
 
     # ------------------------------------------------------------------ schedule helpers (ref :54-69, :150-158, :171-209)
     def setup_temperature_decay(self, estimated_stepping_batches: int):

@@ -63,7 +63,7 @@ def lib() -> C.CDLL:
             "licv_inject_renorm_fwd": [P, I, P, P, P, I64, I64, P, P, F, P],
             "licv_inject_renorm_add_fwd": [P, I, P, P, P, I, P, I64, I64, P, P, F, I, P],
             "licv_scatter_rows": [P, P, P, I64, I64, P],
-            "licv_ce_rows": [P, I, P, P, I64, I64, I64, P, F, P, I64, P, I, P],
+            "licv_ce_rows": [P, I, P, P, I64, I64, I64, P, F, P, P, I64, P, I, P],
             "licv_head_group_sum": [P, P, I64, I64, I64, I64, I64, I64, P],
             "licv_inject_renorm_bwd": [P, I, P, P, P, P, P, I64, I64, P],
             "licv_rmsnorm_fwd": [P, I, P, P, I64, I64, I64, I64, I64, F, I, P],
@@ -91,7 +91,7 @@ def lib() -> C.CDLL:
             "licv_swiglu_bwd": [P, P, P, I64, I64, P],
             "licv_branch_grad": [P, P, I64, I64, F, I, P, P],
             "licv_attn_bwd_small": [C.POINTER(AttnArgs), P, P, I64, I64, P, P, I64, I64, P],
-            "licv_kl_rows_bwd": [P, P, I, P, P, I64, I64, I64, I64, F, F, F, P, I64, P],
+            "licv_kl_rows_bwd": [P, P, I, P, P, I64, I64, I64, I64, F, F, F, P, P, I64, P],
             "licv_kl_rows_fwd": [P, P, I, P, P, I64, I64, I64, I64, F, F, P, P],
             "licv_adamw_step": [P, P, P, P, I64, I64, F, F, F, F, F, F, I64, F, P],
         }

@@ -413,14 +413,16 @@ def attention_bwd_small(q, k, v, dout, B, Sq, Sk, n_heads, n_kv_heads, head_dim,
 
 
 def ce_rows(logits: torch.Tensor, rows: torch.Tensor, labels: torch.Tensor, vocab: int, grad: Optional[torch.Tensor] = None,
-            grad_coef: float = 0.0, grad_rows: Optional[torch.Tensor] = None, accumulate: bool = False, want_loss: bool = True):
+            grad_coef: float = 0.0, grad_rows: Optional[torch.Tensor] = None, accumulate: bool = False, want_loss: bool = True,
+            grad_coef_dev: Optional[torch.Tensor] = None):
     """Cross-entropy of logits[rows] against labels (fp32 maths).  Returns per-row losses (fp32) or None; optionally
-    writes / accumulates grad_coef * (softmax - onehot) into grad[(grad_rows or arange)] (bf16, row stride grad.stride(0))."""
+    writes / accumulates grad_coef * (softmax - onehot) into grad[(grad_rows or arange)] (bf16, row stride grad.stride(0));
+    grad_coef_dev: optional 1-element fp32 device tensor multiplied into grad_coef inside the kernel (no host sync)."""
     assert logits.dim() == 2 and logits.stride(1) == 1 and rows.dtype == torch.int64 and labels.dtype == torch.int64
     n = rows.numel()
     out = torch.empty((n,), dtype=torch.float32, device=logits.device) if want_loss else None
     check(_lib.lib().licv_ce_rows(_p(logits), _dt(logits), _p(rows.contiguous()), _p(labels.contiguous()), n, vocab, logits.stride(0), _p(out),
-                                  float(grad_coef), _p(grad), grad.stride(0) if grad is not None else 0,
+                                  float(grad_coef), _p(grad_coef_dev), _p(grad), grad.stride(0) if grad is not None else 0,
                                   _p(grad_rows.contiguous()) if grad_rows is not None else None, 1 if accumulate else 0, _stream(logits)))
     return out
 
@@ -431,11 +433,12 @@ def head_group_sum(src: torch.Tensor, out: torch.Tensor, rows: int, n_groups: in
     return out
 
 
-def kl_rows_bwd(stu, tea, stu_rows, tea_rows, vocab, temperature, eps, upstream=1.0) -> torch.Tensor:
-    """Returns (n_rows, vocab_padded_to_8) bf16 with zero pad columns (so it can feed the head's dgrad GEMM directly)."""
+def kl_rows_bwd(stu, tea, stu_rows, tea_rows, vocab, temperature, eps, upstream=1.0, upstream_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Returns (n_rows, vocab_padded_to_8) bf16 with zero pad columns (so it can feed the head's dgrad GEMM directly).
+    upstream_dev: optional 1-element fp32 device tensor multiplied into the coefficient inside the kernel."""
     n = stu_rows.numel()
     ld = (vocab + 7) // 8 * 8
     grad = torch.zeros((n, ld), dtype=torch.bfloat16, device=stu.device)
     check(_lib.lib().licv_kl_rows_bwd(_p(stu), _p(tea), _dt(stu), _p(stu_rows), _p(tea_rows), n, vocab, stu.stride(0), tea.stride(0),
-                                      float(temperature), float(eps), float(upstream), _p(grad), ld, _stream(stu)))
+                                      float(temperature), float(eps), float(upstream), _p(upstream_dev), _p(grad), ld, _stream(stu)))
     return grad

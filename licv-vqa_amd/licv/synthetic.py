@@ -118,6 +118,23 @@ def synth_idefics_weights(arch: IdeficsArch, seed: int = 426, dtype=torch.bfloat
     return sd
 
 
+_BRANCH_OUT = ("self_attn.o_proj.weight", "self_attn.out_proj.weight", "cross_attn.o_proj.weight", "mlp.down_proj.weight",
+               "mlp.fc2.weight", ".c_proj.weight", ".output_proj.weight", "modality_projection.down_proj.weight")
+
+
+def trained_like_(sd: Dict[str, torch.Tensor], depth: int) -> Dict[str, torch.Tensor]:
+    """Scale every residual-branch OUTPUT projection by 1/sqrt(2*depth), in place (the GPT-2 / Llama-family initialisation
+    that trained checkpoints keep the order of magnitude of): with all linears ~N(0, 0.02) a branch at width 4096 writes
+    as much into the stream as the stream holds, and a 32-layer random model amplifies one bf16 ulp to percent-level
+    logit differences — a property of the random init, not of any kernel.  Applied after generation, so the RNG stream
+    (and every committed fixture) is unchanged."""
+    f = 1.0 / math.sqrt(2.0 * max(depth, 1))
+    for k, v in sd.items():
+        if k.endswith(_BRANCH_OUT):
+            v.mul_(f)
+    return sd
+
+
 def weights_checksum(sd: Dict[str, torch.Tensor]) -> float:
     """Order-independent fingerprint used by fixtures to detect RNG drift."""
     tot = 0.0

@@ -24,20 +24,27 @@ def _t(w: torch.Tensor) -> torch.Tensor:
     return w.t().contiguous()
 
 
+def _unpack_gate_up(packed: torch.Tensor) -> torch.Tensor:
+    """Inverse of ops.pack_gate_up: the engine keeps gate|up interleaved in 16-row blocks for the SwiGLU epilogue; the
+    backward wants (2I, H) = [gate ; up] (so the student pass can be built from the engine's weights alone)."""
+    two_i, K = packed.shape
+    blk = packed.view(two_i // 32, 2, 16, K)
+    return torch.cat([blk[:, 0].reshape(two_i // 2, K), blk[:, 1].reshape(two_i // 2, K)]).contiguous()
+
+
 class TrainWeights:
     """Transposed / unfused copies of the language-stack weights needed by the backward (built lazily, once)."""
 
-    def __init__(self, w: IdeficsWeights, sd: Dict[str, torch.Tensor]):
+    def __init__(self, w: IdeficsWeights, sd: Optional[Dict[str, torch.Tensor]] = None):
+        """``sd`` (the HF-named state dict) is optional: without it the unfused gate|up copy is recovered from the engine's
+        packed buffer (bit-identical rows)."""
         dev = w.device
-        g = lambda k: sd[k].detach().to(device=dev, dtype=torch.bfloat16).contiguous()
         self.dec, self.xat = [], []
         for i, D in enumerate(w.dec):
-            p = f"model.layers.{i}."
-            gu = torch.cat([g(p + "mlp.gate_proj.weight"), g(p + "mlp.up_proj.weight")]).contiguous()      # (2I, H) gate | up
+            gu = _unpack_gate_up(D.gu_w)                                                                 # (2I, H) gate | up
             self.dec.append(dict(gu=gu, gu_T=_t(gu), down_T=_t(D.down_w), o_T=_t(D.o_w), qkv_T=_t(D.qkv_w)))
         for j, X in enumerate(w.xat):
-            p = f"model.gated_cross_attn_layers.{j}."
-            gu = torch.cat([g(p + "mlp.gate_proj.weight"), g(p + "mlp.up_proj.weight")]).contiguous()
+            gu = _unpack_gate_up(X.gu_w)
             self.xat.append(dict(gu=gu, gu_T=_t(gu), down_T=_t(X.down_w), o_T=_t(X.o_w), q_T=_t(X.q_w)))
         V = w.lm_head.shape[0]
         head_T = torch.zeros((w.lm_head.shape[1], (V + 7) // 8 * 8), dtype=torch.bfloat16, device=dev)     # (H, V padded to 8)
@@ -199,13 +206,11 @@ class StudentPass:
 class TrainWeights2:
     """Transposed / unfused copies of the Mistral stack's weights for the backward (Idefics2)."""
 
-    def __init__(self, w, sd: Dict[str, torch.Tensor]):
+    def __init__(self, w, sd: Optional[Dict[str, torch.Tensor]] = None):
         dev = w.device
-        g = lambda k: sd[k].detach().to(device=dev, dtype=torch.bfloat16).contiguous()
         self.text = []
         for i, L in enumerate(w.text):
-            p = f"model.text_model.layers.{i}."
-            gu = torch.cat([g(p + "mlp.gate_proj.weight"), g(p + "mlp.up_proj.weight")]).contiguous()      # (2I, H) gate | up
+            gu = _unpack_gate_up(L.gu_w)                                                                 # (2I, H) gate | up
             self.text.append(dict(gu=gu, gu_T=_t(gu), down_T=_t(L.down_w), o_T=_t(L.o_w), qkv_T=_t(L.qkv_w)))
         V = w.lm_head.shape[0]
         head_T = torch.zeros((w.lm_head.shape[1], (V + 7) // 8 * 8), dtype=torch.bfloat16, device=dev)

@@ -14,7 +14,6 @@ from typing import Dict, Optional
 import torch
 
 from . import ops
-from .train_engine import StudentPass, StudentPass2, TrainWeights, TrainWeights2
 
 
 def shard_indices(n: int, rank: int, world: int, drop_last: bool = True):
@@ -33,18 +32,14 @@ def allreduce_mean_(flat: torch.Tensor, group=None) -> torch.Tensor:
 
 
 class ICVTrainer:
-    def __init__(self, module, state_dict: Dict[str, torch.Tensor], total_steps: int, accumulate_grad_batches: int = 1,
-                 grad_clip: float = 1.0, group=None):
-        """module: icv_src.icv_module.VQAICVModule on a native interface; state_dict: the HF-named LMM weights
-        (needed once for the transposed copies the backward GEMMs use)."""
+    def __init__(self, module, state_dict: Optional[Dict[str, torch.Tensor]] = None, total_steps: int = 1,
+                 accumulate_grad_batches: int = 1, grad_clip: float = 1.0, group=None):
+        """module: icv_src.icv_module.VQAICVModule on a native interface; state_dict: unused, kept for callers of the first
+        version (the backward's transposed weight copies are now derived from the engine's own buffers)."""
         self.m = module
         self.hard_w = float(module.module_cfg.hard_loss_weight or 0.0)      # loss = kl + hard_w * ce (ref:icv_src/icv_module.py:111-117)
         self.only_hard = bool(getattr(module.module_cfg, "only_hard_loss", False))     # loss = ce alone, no teacher pass (ref :100-101)
-        eng = module.interface.engine
-        if type(eng).__name__ == "Idefics2Engine":
-            self.student = StudentPass2(eng, TrainWeights2(eng.w, state_dict))
-        else:
-            self.student = StudentPass(eng, TrainWeights(eng.w, state_dict))
+        self.student = module.interface.student_pass()                     # shared with the autograd path (one set of transposed weights)
         self.accum, self.clip, self.group = accumulate_grad_batches, grad_clip, group
         spec = module.optimizer_spec(total_steps)
         self.spec = spec

@@ -38,20 +38,42 @@ def ce_rows_and_labels(labels: torch.Tensor, keep: torch.Tensor):
 
 
 def _ce_shifted(logits: torch.Tensor, labels: torch.Tensor, keep: torch.Tensor) -> torch.Tensor:
-    """mean over kept positions of CE(logits[:, t], labels[:, t+1]) — the row reduction over the vocabulary is a HIP kernel."""
-    from licv import ops
-    B, S, V = logits.shape
+    """mean over kept positions of CE(logits[:, t], labels[:, t+1]) — the row reduction over the vocabulary is a HIP kernel
+    (forward and, when the logits carry gradient, backward)."""
+    from licv.autograd import ShiftedCEFn
     rows, tok = ce_rows_and_labels(labels, keep)
-    flat = logits.as_strided((B * S, V), (logits.stride(1), 1))
-    return ops.ce_rows(flat, rows, tok, V).mean()
+    return ShiftedCEFn.apply(logits, rows, tok)
 
 
 class LMMInterface(torch.nn.Module):
     input_ids_field_name = "input_ids"
+    supports_logits_rows = True          # forward(..., logits_rows=flat b*S+t indices) returns only those rows' logits (R, V)
 
     def __init__(self):
         super().__init__()
         self._plan = None
+        self._student_pass = None
+
+    def student_pass(self):
+        """The forward-with-saved-activations + explicit backward (licv.train_engine), built on first use: it keeps transposed
+        copies of the language stack's weights (+17 GB at 9B), which inference never needs."""
+        if self._student_pass is None:
+            from licv.train_engine import StudentPass, StudentPass2, TrainWeights, TrainWeights2
+            if isinstance(self.engine, Idefics2Engine):
+                self._student_pass = StudentPass2(self.engine, TrainWeights2(self.engine.w))
+            else:
+                self._student_pass = StudentPass(self.engine, TrainWeights(self.engine.w))
+        return self._student_pass
+
+    def _run_lmm(self, inputs: dict, logits_rows=None):
+        """Hooked (or plain) forward.  When the installed ``icv`` carries gradient the pass runs behind an autograd node whose
+        backward is the explicit HIP backward through the frozen LMM (ref:icv_src/icv_module.py:97-98 is then differentiable)."""
+        hooks = self._hooks()
+        icv = hooks.get("icv")
+        if icv is not None and torch.is_grad_enabled() and icv.requires_grad:
+            from licv.autograd import HookedStudentFn
+            return HookedStudentFn.apply(icv, self.student_pass(), inputs, hooks["hook_layers"], logits_rows)
+        return self.engine.forward(**inputs, **hooks, logits_rows=logits_rows)
 
 
 class IdeficsInterface(LMMInterface):
@@ -129,9 +151,11 @@ class IdeficsInterface(LMMInterface):
         layers, icv = self._plan
         return dict(icv=icv, hook_layers=layers)
 
-    def forward(self, input_ids=None, attention_mask=None, pixel_values=None, image_attention_mask=None, labels=None, **_):
-        logits = self.engine.forward(input_ids.to(self._device), attention_mask.to(self._device), pixel_values.to(self._device),
-                                     image_attention_mask.to(self._device), **self._hooks())
+    def forward(self, input_ids=None, attention_mask=None, pixel_values=None, image_attention_mask=None, labels=None,
+                logits_rows=None, **_):
+        dev = self._device
+        logits = self._run_lmm(dict(input_ids=input_ids.to(dev), attention_mask=attention_mask.to(dev),
+                                    pixel_values=pixel_values.to(dev), image_attention_mask=image_attention_mask.to(dev)), logits_rows)
         out = LMMOutput(logits=logits)
         if labels is not None:
             # shift-by-one CE with pads masked by attention_mask: transformers 4.38.2 Idefics behaviour
@@ -185,11 +209,13 @@ class Idefics2Interface(IdeficsInterface):
             raise LookupError(str(e).replace("model.model.layers.<", "model.model.text_model.layers.<").replace(">)", ">.mlp)")
                               .replace("Idefics engine", "Idefics2 engine")) from None
 
-    def forward(self, input_ids=None, attention_mask=None, pixel_values=None, pixel_attention_mask=None, labels=None, **_):
+    def forward(self, input_ids=None, attention_mask=None, pixel_values=None, pixel_attention_mask=None, labels=None,
+                logits_rows=None, **_):
         dev = self._device
-        logits = self.engine.forward(input_ids.to(dev), attention_mask.to(dev) if attention_mask is not None else None,
-                                     pixel_values.to(dev) if pixel_values is not None else None,
-                                     pixel_attention_mask.to(dev) if pixel_attention_mask is not None else None, **self._hooks())
+        logits = self._run_lmm(dict(input_ids=input_ids.to(dev), attention_mask=attention_mask.to(dev) if attention_mask is not None else None,
+                                    pixel_values=pixel_values.to(dev) if pixel_values is not None else None,
+                                    pixel_attention_mask=pixel_attention_mask.to(dev) if pixel_attention_mask is not None else None),
+                               logits_rows)
         out = LMMOutput(logits=logits)
         if labels is not None:
             # hf:idefics2/modeling_idefics2.py ForConditionalGeneration loss: plain shifted CE, ignore_index=-100

@@ -145,10 +145,31 @@ def image_features(pixel_values, pixel_attention_mask, sd, arch):
 
 
 # ----------------------------------------------------------------------------- Mistral text model
+def fp8_linear(x, w):
+    """CPU restatement of the build's fp8 text-stack projection (BASELINE configs[4]; the reference has no fp8 mode, so this
+    pins the ARITHMETIC the HIP path claims, csrc/rowwise.hip quantize_rows_fp8_k + csrc/gemm.hip gemm_fp8_pingpong_k):
+    per-row dynamic activation scale amax/448 and per-output-channel weight scale amax/448, both operands rounded to OCP
+    e4m3 (round to nearest even), exact products accumulated in fp32, scales applied to the accumulator, one rounding to the
+    activation dtype."""
+    if torch.is_autocast_enabled("cpu"):                 # autocast hands a linear bf16 operands, and returns bf16
+        x, w = x.to(torch.bfloat16), w.to(torch.bfloat16)
+    dt = x.dtype
+    with torch.autocast("cpu", enabled=False):
+        xf, wf = x.float(), w.float()
+        sx = xf.abs().amax(-1, keepdim=True).clamp_min(1e-12) / 448.0
+        sw = wf.abs().amax(-1, keepdim=True).clamp_min(1e-12) / 448.0
+        xq = (xf / sx).to(torch.float8_e4m3fn).float()
+        wq = (wf / sw).to(torch.float8_e4m3fn).float()
+        y = (xq @ wq.t()) * sx * sw.t()
+    return y.to(dt)
+
+
 def forward(sd: Dict[str, torch.Tensor], arch, input_ids, attention_mask, pixel_values=None, pixel_attention_mask=None,
             icv: Optional[torch.Tensor] = None, hook_layers: Optional[Sequence[int]] = None, capture: Optional[dict] = None,
-            image_hidden_states: Optional[torch.Tensor] = None, position_ids: Optional[torch.Tensor] = None):
-    """logits (B, S, V).  icv (1, n_hooked, H) fp32, already alpha-scaled; the hook edits the MLP output of text layer l."""
+            image_hidden_states: Optional[torch.Tensor] = None, position_ids: Optional[torch.Tensor] = None,
+            fp8_text: bool = False):
+    """logits (B, S, V).  icv (1, n_hooked, H) fp32, already alpha-scaled; the hook edits the MLP output of text layer l.
+    fp8_text: the four projections of every text layer run through ``fp8_linear`` (the build's configs[4] mode)."""
     tp = "model.text_model."
     B, S = input_ids.shape
     h = F.embedding(input_ids, sd[tp + "embed_tokens.weight"])
@@ -170,19 +191,21 @@ def forward(sd: Dict[str, torch.Tensor], arch, input_ids, attention_mask, pixel_
     allowed = torch.tril(torch.ones(S, S, dtype=torch.bool))[None, None] & attention_mask.bool()[:, None, None, :]
     causal = torch.where(allowed, torch.zeros((), dtype=dtype), minv)
     idx_of = {int(l): i for i, l in enumerate(hook_layers)} if (icv is not None and hook_layers is not None) else {}
+    lin = (lambda x_, sd_, name: fp8_linear(x_, sd_[name + ".weight"])) if fp8_text else _lin
+    mlp = (lambda x_, sd_, p_: lin(F.silu(lin(x_, sd_, p_ + "gate_proj")) * lin(x_, sd_, p_ + "up_proj"), sd_, p_ + "down_proj")) if fp8_text else _mlp
     for l in range(arch.num_layers):
         lp = f"{tp}layers.{l}."
         res = h
         x = rms_norm(h, sd[lp + "input_layernorm.weight"], arch.rms_eps)
-        q = _lin(x, sd, lp + "self_attn.q_proj").view(B, S, nh, hd).transpose(1, 2)
-        k = _lin(x, sd, lp + "self_attn.k_proj").view(B, S, nkv, hd).transpose(1, 2)
-        v = _lin(x, sd, lp + "self_attn.v_proj").view(B, S, nkv, hd).transpose(1, 2)
+        q = lin(x, sd, lp + "self_attn.q_proj").view(B, S, nh, hd).transpose(1, 2)
+        k = lin(x, sd, lp + "self_attn.k_proj").view(B, S, nkv, hd).transpose(1, 2)
+        v = lin(x, sd, lp + "self_attn.v_proj").view(B, S, nkv, hd).transpose(1, 2)
         c, s_ = cos.to(q.dtype), sin.to(q.dtype)
         q, k = (q * c) + (rotate_half(q) * s_), (k * c) + (rotate_half(k) * s_)
         o = eager_attention(q, repeat_kv(k, nh // nkv), repeat_kv(v, nh // nkv), causal.to(q.dtype), hd ** -0.5).reshape(B, S, -1).contiguous()
-        h = res + _lin(o, sd, lp + "self_attn.o_proj")
+        h = res + lin(o, sd, lp + "self_attn.o_proj")
         res = h
-        m = _mlp(rms_norm(h, sd[lp + "post_attention_layernorm.weight"], arch.rms_eps), sd, lp + "mlp.")
+        m = mlp(rms_norm(h, sd[lp + "post_attention_layernorm.weight"], arch.rms_eps), sd, lp + "mlp.")
         if capture is not None:
             capture.setdefault("mlp_raw", []).append(m)
         if l in idx_of:

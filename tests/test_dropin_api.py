@@ -182,3 +182,24 @@ def test_temperature_decay_schedule():
     cfg.decay_ratio = -1
     VQAICVModule.decay_temperature(stub)
     assert float(stub.temperature) == pytest.approx(0.3)
+
+
+def test_encoder_output_is_the_reference_dataclass_shape():
+    """ref:icv_src/icv_encoder/base_icv_encoder.py:7-11 — a mutable @dataclass with three positional fields."""
+    import dataclasses
+    assert dataclasses.is_dataclass(ICVEncoderOutput)
+    assert [f.name for f in dataclasses.fields(ICVEncoderOutput)] == ["in_context_feature", "in_context_vector", "alpha"]
+    out = ICVEncoderOutput(None, torch.zeros(1, 2, 4), torch.ones(1, 2))
+    out.alpha = out.alpha * 2                                   # attribute assignment works (a NamedTuple would refuse)
+    assert float(out.alpha.sum()) == 4.0
+    with pytest.raises(TypeError):
+        ICVEncoderOutput()                                      # no defaults, like the reference
+
+
+def test_wrapper_exposes_the_reference_methods():
+    w = LearnableICVInterventionLMM(torch.nn.Identity(), True, [1], "l.<LAYER_NUM>", 2)
+    for name in ("apply_icv_intervention", "_get_context_manager", "_prepare_layers", "toggle_intervention", "forward", "generate"):
+        assert callable(getattr(w, name)), name
+    fn = w.apply_icv_intervention(w.intervention_layer_names, torch.zeros(1, 1, 4))
+    x = torch.randn(2, 3, 4)
+    assert fn(x, "l.0") is x                                    # a layer that is not edited passes through untouched (CPU ok)
