@@ -128,10 +128,16 @@ int licv_gemm_fp8(const void* Aq, int64_t lda, const float* a_scale, const void*
 int licv_gemm_select(int which);
 /* A/B switch for the persistent kernel's per-XCD start stagger (default on). */
 int licv_gemm_stagger(int on);
-/* A/B timing knobs of the default kernel (0: per-XCD start stagger in percent, 1: tile-rows per XCD patch); off by default */
+/* A/B timing knobs of the default kernel (0: per-XCD start stagger in percent, 1: tile-rows per XCD patch; both off by default;
+ * 2: take the persistent "flow" kernel — register-direct asynchronous epilogue — for plain / bias / activation / SwiGLU bf16
+ * epilogues in auto mode).  licv_gemm_select(20) forces the flow kernel wherever it is eligible. */
 int licv_gemm_experiment(int knob, int value);
+/* 1 if the flow kernel may be dispatched (its code objects use no scratch memory: its counted waits rely on that), else 0 */
+int licv_gemm_flow_available(void);
 /* roofline probe: `blocks` workgroups of 4 waves each issue iters*8 register-only v_mfma_f32_16x16x32_bf16 (16384 FLOP each) */
 int licv_probe_mfma_loop(void* sink_f32, int blocks, int iters, void* stream);
+/* semantics probe: one wave writes {a', b'} = v_permlane16_swap(a = lane, b = 100 + lane) to out[2*lane], out[2*lane+1] (uint32) */
+int licv_probe_permlane16_swap(void* out_u32_128, void* stream);
 /* timing instrumentation: when non-NULL, wave 0 of every workgroup of the default kernel stores 5 wall_clock64() stamps
  * (start, pipeline filled, main loop done, output image in LDS, end) at dev_buffer[8 * blockIdx.x ...] (int64) */
 int licv_gemm_debug_timestamps(void* dev_buffer);

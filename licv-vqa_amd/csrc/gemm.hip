@@ -984,6 +984,223 @@ void gemm_bf16_persist_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t
 }
 
 // ------------------------------------------------------------------------------------------------
+// "flow" kernel: the ping-pong main loop made persistent, with an ASYNCHRONOUS epilogue straight from the accumulators.
+//
+// What the staged epilogue costs on a short-K tile (K = 1280: 40 stages = 30 us): 2.6-4.4 us pipeline fill + 2-4 us
+// phase A + 4.5-11 us phase B, none of it overlapped with MFMA work, and every CU reaches it at the same time, so
+// the 128 KiB per CU arrive at HBM as one 33 MB burst.  Here, for the epilogue families that need nothing but the
+// accumulators (plain / bias / activation / SwiGLU, bf16 out):
+//   * after a tile's last stage the NEXT tile's first four K stages are issued into the (now free) ring at once;
+//   * the epilogue is register-direct: bf16(acc + bias) [activation | SwiGLU pairing of the interleaved gate|up
+//     accumulators, which sit in the same lane], two v_permlane16_swap per 16 x 32 block so that a lane owns 8
+//     consecutive columns, one 16-byte buffer store (a wave-instruction writes 16 rows x 64 contiguous bytes; rows
+//     past M fall outside the buffer descriptor and are dropped by the hardware, so every store instruction always
+//     issues and the count below is exact); no LDS image, no barrier, no wait;
+//   * the next main loop starts while those stores drain: vector-memory operations retire in issue order, so the
+//     counted waits of the first three stages simply leave the NST stores (issued after stages 0-3, before stage 4)
+//     in flight as well: s_waitcnt vmcnt(12 + NST) instead of vmcnt(12).  From stage 3 on the usual counts apply (the
+//     stage-4 pieces were issued behind the stores: by then they have had ~3 stages + the fill to drain).
+//   * the bias row of a wave (64 columns = 128 bytes) comes through the scalar cache (s_load, lgkmcnt): no vector
+//     load that would either drain the pipeline or disturb the vmcnt arithmetic.
+// Same tiles, same per-tile K order, same rounding points as gemm_bf16_pingpong_k + epilogue_staged: results are
+// bit-identical (tests/test_ops_gpu.py kernels-agree test).
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(16))) uint32_t u32x16;
+
+__device__ __forceinline__ void wait_vmcnt4(int n4) {              // waits vmcnt(4 * n4); n4 is wave-uniform, 0..7
+    switch (n4) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(28)" ::: "memory"); break;
+    }
+}
+
+__device__ __forceinline__ uint32_t pack_bf2(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
+
+// rows (16-lane groups) 1 and 3 of `a` trade places with rows 0 and 2 of `b`: afterwards an even-row lane holds
+// {its own a, its odd neighbour's a} and an odd-row lane {its even neighbour's b, its own b}
+__device__ __forceinline__ void swap16(uint32_t& a, uint32_t& b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    a = r[0]; b = r[1];
+}
+
+template <int EPI>      // 0 plain/bias, 1 GELU(erf), 2 GELU(tanh), 3 ReLU, 4 SwiGLU (N/2 output columns)
+__global__ __launch_bounds__(512, 2)
+void gemm_bf16_flow_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw,
+                      bf16_t* __restrict__ C, int ldc, int M, int N, int K, int tiles_m, int tiles_n,
+                      const bf16_t* __restrict__ bias, int group) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // [5 stages][A 16 KiB | W 16 KiB]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int ntiles = tiles_m * tiles_n;
+    const int ns = K / 32;                                   // >= 4
+    const int fo = ring_off(lane & 15, lane >> 4);
+    constexpr int NST = (EPI == 4) ? 8 : 16;                 // epilogue store instructions per wave and tile
+    const auto crs = __builtin_amdgcn_make_buffer_rsrc((void*)C, 0, (int)((int64_t)M * ldc * 2), 0x00020000);
+
+    const bf16_t* srcA[2];
+    const bf16_t* srcW[2];
+    int m0 = 0, n0 = 0;
+    auto set_tile = [&](int t) {
+        int tm, tn;
+        tile_coords(t, tiles_m, tiles_n, tm, tn, group);
+        m0 = tm * 256; n0 = tn * 256;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = wave * 32 + i * 16 + (lane >> 2);
+            const int chunk = (lane & 3) ^ (((row >> 2) & 1) << 1);
+            srcA[i] = A + (int64_t)min(m0 + row, M - 1) * lda + chunk * 8;
+            srcW[i] = W + (int64_t)min(n0 + row, N - 1) * ldw + chunk * 8;
+        }
+    };
+    auto issue = [&](int s) {
+        char* sa = smem + (s % RING_STAGES) * RING_STAGE_BYTES + wave * 32 * 64;
+        char* sw = sa + 16384;
+        const int64_t koff = (int64_t)s * 32;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + koff),
+                                             (__attribute__((address_space(3))) void*)(sa + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[i] + koff),
+                                             (__attribute__((address_space(3))) void*)(sw + i * 1024), 16, 0, 0);
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    set_tile(tile);
+    issue(0); issue(1); issue(2); issue(3);
+    int extra4 = 0;                                          // (stores of the previous tile still queued behind stages 0-3) / 4
+    for (;;) {
+        const int cm0 = m0, cn0 = n0;                        // coordinates of the tile being computed
+        floatx4 acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+        bf16x8 fa[8], fw[4];
+        wait_vmcnt4(3 + extra4);                             // my pieces of stage 0 have landed
+        __builtin_amdgcn_s_barrier();                        // stage 0 published
+        if (wm == 1) __builtin_amdgcn_s_barrier();           // trailing group starts half a stage later
+        for (int s = 0; s < ns; ++s) {
+            {
+                const char* sa = smem + (s % RING_STAGES) * RING_STAGE_BYTES + (wm * 128) * 64 + fo;
+                const char* sw = smem + (s % RING_STAGES) * RING_STAGE_BYTES + 16384 + (wn * 64) * 64 + fo;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fw[j] = *reinterpret_cast<const bf16x8*>(sw + j * 16 * 64);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 64);
+                if (s + 4 < ns) issue(s + 4);
+                // retire my pieces of stage s+1; stages 0-3 were issued BEFORE the previous tile's stores, stage 4 onwards behind them
+                wait_vmcnt4(max(0, min(3, ns - 2 - s)) + (s <= 2 ? extra4 : 0));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        }
+        if (wm == 0) __builtin_amdgcn_s_barrier();           // leading group: match the barrier count
+        // every wave retired its last fragment reads (lgkmcnt(0)) before that barrier: the whole ring is free
+
+        const int next = tile + gridDim.x;
+        const bool more = next < ntiles;
+        if (more) { set_tile(next); issue(0); issue(1); issue(2); issue(3); }
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- register-direct epilogue of tile (cm0, cn0)
+        const int colbase = cn0 + wn * 64;                   // wave-uniform; N % 64 == 0 -> a wave is all in or all out
+        extra4 = 0;
+        if (colbase < N) {
+            const int fr = lane & 15, fq = lane >> 4;
+            float bv[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bv[j][r] = 0.f;
+            if (EPI != 4 && bias) {
+                // the wave's 64 bias values through the scalar cache, 32 columns (16 dwords) at a time
+                const bf16_t* bp = bias + colbase;
+                static_for<0, 2>([&](auto hc) {
+                    constexpr int h = decltype(hc)::value;
+                    u32x16 sv;
+                    asm volatile("s_load_dwordx16 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(sv) : "s"(bp), "i"(h * 64) : "memory");
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                        for (int d = 0; d < 2; ++d) {        // lane needs dword j*8 + fq*2 + d of the wave's 32
+                            const int b = jj * 8 + d;
+                            const uint32_t w01 = (fq & 1) ? sv[b + 2] : sv[b];
+                            const uint32_t w23 = (fq & 1) ? sv[b + 6] : sv[b + 4];
+                            const uint32_t wv = (fq & 2) ? w23 : w01;
+                            bv[2 * h + jj][2 * d] = __uint_as_float(wv << 16);
+                            bv[2 * h + jj][2 * d + 1] = __uint_as_float(wv & 0xffff0000u);
+                        }
+                });
+            }
+            if (EPI != 4) {
+                const uint32_t off0 = (uint32_t)(((cm0 + wm * 128 + fr) * ldc + colbase + (fq & 1) * 16 + (fq >> 1) * 8) * 2);
+                static_for<0, 8>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    static_for<0, 2>([&](auto pc) {
+                        constexpr int p = decltype(pc)::value;
+                        float y[2][4];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float v = acc[i][2 * p + h][r] + bv[2 * p + h][r];
+                                y[h][r] = EPI == 0 ? v : act_apply(rbf(v), EPI);
+                            }
+                        uint32_t a0 = pack_bf2(y[0][0], y[0][1]), a1 = pack_bf2(y[0][2], y[0][3]);
+                        uint32_t b0 = pack_bf2(y[1][0], y[1][1]), b1 = pack_bf2(y[1][2], y[1][3]);
+                        swap16(a0, b0);
+                        swap16(a1, b1);
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{a0, a1, b0, b1}, crs,
+                                                               off0 + (uint32_t)(i * 16 * ldc * 2 + p * 64), 0, 0);
+                    });
+                });
+            } else {
+                // packed column blocks of 16: acc[.][0] gate / acc[.][1] up of output block 2b, acc[.][2] / acc[.][3] of 2b+1
+                const uint32_t off0 = (uint32_t)(((cm0 + wm * 128 + fr) * ldc + (colbase >> 1) + (fq & 1) * 16 + (fq >> 1) * 8) * 2);
+                static_for<0, 8>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    float y[2][4];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            y[h][r] = rbf(silu_fast(rbf(acc[i][2 * h][r]))) * rbf(acc[i][2 * h + 1][r]);
+                    uint32_t a0 = pack_bf2(y[0][0], y[0][1]), a1 = pack_bf2(y[0][2], y[0][3]);
+                    uint32_t b0 = pack_bf2(y[1][0], y[1][1]), b1 = pack_bf2(y[1][2], y[1][3]);
+                    swap16(a0, b0);
+                    swap16(a1, b1);
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{a0, a1, b0, b1}, crs, off0 + (uint32_t)(i * 16 * ldc * 2), 0, 0);
+                });
+            }
+            extra4 = NST / 4;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!more) break;
+        tile = next;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // 128 x 128 x 64, 4 waves, register staged (general shapes)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2)
@@ -1193,18 +1410,38 @@ static int g_stagger = 0;        // per-XCD start stagger of the persistent kern
 // (A rotated K traversal per tile was also tried: -3 ... -25 %, lockstep K sweeps are what makes L2 sharing work.)
 static int g_pp_stagger = 0;
 static int g_pp_group = 0;      // experiment knob: tile-rows per XCD patch group (0 = heuristic)
+static int g_flow_default = 1;  // auto mode takes the flow kernel where it is eligible and measured faster (knob 2 of licv_gemm_experiment)
 extern "C" int licv_gemm_stagger(int on) { g_stagger = on; return LICV_OK; }
 // A/B timing knobs of the default (ping-pong) kernel, all measured neutral-to-negative and off by default:
 //   knob 0: per-XCD first-round start stagger, percent of an eighth of the estimated tile time (0 = off)
 //   knob 1: tile-rows per XCD patch group (0 = the default 8)
 extern "C" int licv_gemm_experiment(int knob, int value) {
-    if (knob == 0) g_pp_stagger = value; else if (knob == 1) g_pp_group = value;
+    if (knob == 0) g_pp_stagger = value; else if (knob == 1) g_pp_group = value; else if (knob == 2) g_flow_default = value;
     else return licv_set_error(LICV_E_BADARG, "gemm_experiment: unknown knob %d", knob);
     return LICV_OK;
 }
 static int g_num_cus = 256;        // persistent grid size (queried once)
-static int g_force_kernel = 0;     // 0 auto, 1 tile128, 2 tile256 (tests / A-B timing)
+static int g_force_kernel = 0;     // 0 auto, 1 tile128, 2 tile256 (tests / A-B timing), 20 flow kernel where eligible
 extern "C" int licv_gemm_select(int which) { g_force_kernel = which; return LICV_OK; }
+
+// The flow kernel's counted s_waitcnt vmcnt(N) assume that the ONLY vector-memory operations a wave issues are its LDS-DMA
+// pieces and its epilogue stores.  A register spill would add scratch loads/stores to that queue and silently break the
+// count, so the kernel is used only if the code object reports no private segment for every instantiation.
+static bool flow_scratch_free() {
+    static int ok = -1;
+    if (ok < 0) {
+        ok = 1;
+        const void* fns[5] = {(const void*)gemm_bf16_flow_k<0>, (const void*)gemm_bf16_flow_k<1>, (const void*)gemm_bf16_flow_k<2>,
+                              (const void*)gemm_bf16_flow_k<3>, (const void*)gemm_bf16_flow_k<4>};
+        for (const void* f : fns) {
+            hipFuncAttributes at;
+            if (hipFuncGetAttributes(&at, f) != hipSuccess || at.localSizeBytes != 0) ok = 0;
+        }
+    }
+    return ok == 1;
+}
+
+extern "C" int licv_gemm_flow_available(void) { return flow_scratch_free() ? 1 : 0; }
 
 extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
                               int64_t M, int64_t N, int64_t K, const licv_gemm_epilogue* e, void* stream) {
@@ -1246,8 +1483,32 @@ extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
     }
     const bool can256 = (K % BK == 0);
     const bool big = can256 && M >= 512 && N >= 256;
+    // flow kernel: epilogues that need only the accumulators (and a bias row), bf16 out, whole waves in or out of N
+    const bool flow_ok = can256 && K >= 128 && M >= 512 && N >= 256 && N % 64 == 0 && e->out_dtype == LICV_BF16 && !e->residual && !e->row_gate &&
+                         !e->use_scale && (int64_t)(M + 256) * ldc * 2 < (1ll << 31) && ldc % 8 == 0 &&
+                         (!e->bias_bf16 || ((uintptr_t)e->bias_bf16 & 3) == 0);
     const bool use256 = g_force_kernel >= 2 ? can256 : (g_force_kernel == 1 ? false : big);
-    if (use256) {
+    // auto mode takes it where it measured faster than the staged epilogue: short K (the epilogue is a large share of the tile:
+    // ViT QKV / fc1, cross-attention K|V; +3-5 %), not the K = 4096 shapes (-4 ... 0 %)
+    const bool flow_auto = g_flow_default && K <= 2048 && !e->swiglu;
+    if (use256 && flow_ok && flow_scratch_free() && (g_force_kernel == 20 || (g_force_kernel == 0 && flow_auto))) {
+        const int tiles_m = (int)((M + 255) / 256), tiles_n = (int)((N + 255) / 256);
+        const int pp_group = g_pp_group > 0 ? g_pp_group : (tiles_n <= 6 ? 2 : 8);
+        const dim3 grid(min(tiles_m * tiles_n, g_num_cus)), block(512);
+        static bool flow_attr = false;
+        if (!flow_attr) {
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_flow_k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_flow_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_flow_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_flow_k<3>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_flow_k<4>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
+            flow_attr = true;
+        }
+#define FLOW(E) gemm_bf16_flow_k<E><<<grid, block, RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>( \
+            (const bf16_t*)A, lda, (const bf16_t*)W, ldw, (bf16_t*)C, (int)ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep.bias, pp_group)
+        if (e->swiglu) FLOW(4); else if (e->act == 1) FLOW(1); else if (e->act == 2) FLOW(2); else if (e->act == 3) FLOW(3); else FLOW(0);
+#undef FLOW
+    } else if (use256) {
         const int tiles_m = (int)((M + 255) / 256), tiles_n = (int)((N + 255) / 256);
         const dim3 grid(tiles_m * tiles_n), block(512);
         // estimated tile time: K/32 stages x ~0.85 us + ~15 us of fill/epilogue, in 10 ns ticks; an eighth of it per XCD
@@ -1279,7 +1540,7 @@ extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
                 (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep,
                 // one tile ~ K/32 stages x ~1300 cycles; s_sleep 64 = 4096 cycles; an eighth of a tile per XCD group
                 (tiles_m * tiles_n > g_num_cus && g_stagger) ? (int)((K / 32) * 1300 / 8 / 4096 + 1) : 0);
-        else if ((g_force_kernel == 0 || g_force_kernel == 9) && K >= 128)
+        else if ((g_force_kernel == 0 || g_force_kernel == 9 || g_force_kernel == 20) && K >= 128)
             gemm_bf16_pingpong_k<0><<<grid, block, RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>(
                 (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, pp_ticks, pp_group);
         else LAUNCH256(0);

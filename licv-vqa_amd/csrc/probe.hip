@@ -30,3 +30,17 @@ extern "C" int licv_probe_mfma_loop(void* sink, int blocks, int iters, void* str
     LICV_LAUNCH_CHECK();
     return LICV_OK;
 }
+
+// semantics probe for v_permlane16_swap as the flow GEMM's epilogue uses it: out[lane] = {a', b'} for a = lane, b = 100 + lane
+__global__ void permlane16_swap_probe_k(uint32_t* __restrict__ out) {
+    const uint32_t a = threadIdx.x, b = 100 + threadIdx.x;
+    const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    out[2 * threadIdx.x] = r[0];
+    out[2 * threadIdx.x + 1] = r[1];
+}
+extern "C" int licv_probe_permlane16_swap(void* out_u32_128, void* stream) {
+    LICV_CHECK_ARG(out_u32_128, "probe_permlane16_swap: null pointer");
+    permlane16_swap_probe_k<<<1, 64, 0, (hipStream_t)stream>>>((uint32_t*)out_u32_128);
+    LICV_LAUNCH_CHECK();
+    return LICV_OK;
+}

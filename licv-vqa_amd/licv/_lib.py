@@ -76,6 +76,8 @@ def lib() -> C.CDLL:
             "licv_gemm_splitk_plan": [I64, I64, I64, P, P],
             "licv_gemm_bf16_splitk": [P, I64, P, I64, P, I64, I64, I64, I64, P, I, P, I64, P],
             "licv_probe_mfma_loop": [P, I, I, P],
+            "licv_probe_permlane16_swap": [P, P],
+            "licv_gemm_flow_available": [],
             "licv_gemm_select": [I],
             "licv_gemm_stagger": [I],
             "licv_gemm_experiment": [I, I],

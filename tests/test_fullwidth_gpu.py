@@ -7,7 +7,8 @@ accumulation, head_dim 80 at 257 keys, the 32002-wide head, S = 800 tiling or th
   W2  Idefics2-8B widths (SigLIP 1152/4304 at 972 patches per image, modality projection to 14336, GQA perceiver 16q/4kv x 96,
       Mistral 32q/8kv x 128, I 14336, V 32003) at truncated depth (2 SigLIP, 2 perceiver, 2 text layers), B = 1, S = 512,
       2 images of 378 x 504: connector output, per-layer MLP branch / layer outputs, logits, in bf16 — and the text stack on
-      fp8 operands held to the derived fp8 bar of tests/test_idefics2_gpu.py against the ORACLE (not against our own bf16).
+      fp8 operands: every projection at full width within one bf16 ulp of the oracle's restatement of the fp8 arithmetic on
+      identical inputs, the whole truncated model within the quantisation-noise bar against the ORACLE (fp8 and plain bf16).
   W3  BASELINE configs[0], the plumbing run: Idefics-9B at FULL depth, bs = 1, 1-shot (teacher S = 56 with 2 images, student
       = the bare query with 1 image), driven through icv_src.icv_module.VQAICVModule.forward; teacher logits, hooked student
       logits and the KL loss against the oracle on the host cores (wall times printed).
@@ -131,41 +132,44 @@ def test_w2_idefics2_8b_widths_truncated_depth_vs_oracle(fp8):
         _check(lg, gold["bf16"]["logits"], gold["f32"]["logits"], "logits", rep)
     else:
         # No reference fp8 mode exists; the oracle restates the build's fp8 arithmetic (oracle/idefics2_ref.py fp8_linear:
-        # e4m3 operands, per-row / per-channel amax/448 scales, fp32 accumulate) and the HIP path is held to THAT.  An e4m3
-        # operand has 3 mantissa bits, so upstream bf16 noise flips quantisation buckets and every further fp8 GEMM amplifies
-        # it; the tight comparison is therefore made where both sides see (nearly) the same inputs: a TEXT-ONLY batch, first
-        # text layer (its input is the embedding rows, bit-identical on both sides).
+        # e4m3 operands, per-row / per-channel amax/448 scales, fp32 accumulate) and the HIP path is held to THAT.
+        # (a) per projection, at full width, on IDENTICAL inputs: within one bf16 ulp, >= 97 % bit-identical.  This is where
+        #     parity can be tight: e4m3 rounding is a step function of its input, so two model-level runs whose inputs differ
+        #     by bf16 noise eps come out ~0.3*sqrt(eps) apart after every fp8 GEMM (measured below: 7e-2 after one layer from
+        #     4e-3), whichever implementation produced them.
+        from licv import ops
         s = _cpu(sd, torch.bfloat16)
         g = torch.Generator().manual_seed(914)
-        ids = torch.randint(3, arch.image_token_id - 1, (1, 512), generator=g)
-        am = torch.ones(1, 512, dtype=torch.long)
-        capt = {}
-        lgt = eng.forward(ids.to(DEV), am.to(DEV), icv=icv.to(DEV), hook_layers=layers, capture=capt).float().cpu()
-        c8, c16, c32 = {}, {}, {}
-        with torch.no_grad():
-            with torch.autocast("cpu", dtype=torch.bfloat16):
-                g8 = R2.forward(s, arch, ids, am, icv=icv, hook_layers=layers, capture=c8, fp8_text=True).float()
-                R2.forward(s, arch, ids, am, icv=icv, hook_layers=layers, capture=c16)
-            R2.forward({k: v.float() for k, v in s.items()}, arch, ids, am, icv=icv, hook_layers=layers, capture=c32)
-        for what, key in (("first text layer, MLP branch (pre-hook)", "mlp_raw"), ("first text layer, output", "layer_out")):
-            got, ref = capt[key][0].float().cpu(), c8[key][0].float()
-            noise = c16[key][0].float() - c32[key][0].float()              # plain bf16 path's own noise at this point
-            scale = float(ref.abs().max())
-            err, spread = float((got - ref).abs().max()), float(noise.abs().max())
-            rel, rel_noise = float((got - ref).norm() / ref.norm()), float(noise.norm() / ref.norm())
-            rep.append(f"fp8 {what}: max|hip - oracle_fp8| {err / scale:.2e} of scale (plain-bf16 noise {spread / scale:.2e}); "
-                       f"relative L2 {rel:.2e} (plain-bf16 noise {rel_noise:.2e})")
-            assert err <= max(1.5e-2 * scale, 1.5 * spread), rep[-1]
-            assert rel <= 1.25 * rel_noise + 1e-4, rep[-1]
-        rel8 = float((lgt - g8).norm() / g8.norm())
-        rep.append(f"fp8 logits after 2 text layers, text-only: relative L2 |hip - oracle_fp8| {rel8:.3f}")
-        # with images (connector in bf16, text stack in fp8): deviation from the plain bf16 oracle = the quantisation noise itself
+        tp = "model.text_model.layers.0."
+        L0 = eng.w.text[0]
+        for name, keys, K in (("qkv", ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj"), arch.hidden_size),
+                              ("o", ("self_attn.o_proj",), arch.hidden_size), ("down", ("mlp.down_proj",), arch.intermediate_size),
+                              ("gate|up + SwiGLU", ("mlp.gate_proj", "mlp.up_proj"), arch.hidden_size)):
+            x = torch.randn(512, K, generator=g).to(torch.bfloat16)
+            wq, ws = L0.q8[{"qkv": "qkv_w", "o": "o_w", "down": "down_w"}.get(name, "gu_w")]
+            xq, xs = ops.quantize_fp8(x.to(DEV))
+            got = ops.linear_fp8(xq, xs, wq, ws, swiglu=name.startswith("gate")).float().cpu()
+            with torch.no_grad():
+                outs = [R2.fp8_linear(x, s[tp + k + ".weight"]) for k in keys]
+                ref = (torch.nn.functional.silu(outs[0].float()).to(torch.bfloat16) * outs[1]).float() if name.startswith("gate") \
+                    else torch.cat(outs, dim=-1).float()
+            same = float((got == ref).float().mean())
+            tol = (ref.abs() * 2.0 ** -7 + ref.abs().max() * 2.0 ** -9) * 1.001      # one bf16 ulp (the bar of tests/test_ops_gpu.py close_bf16)
+            worst = float(((got - ref).abs() / tol).max())
+            rep.append(f"fp8 {name} projection ({x.shape[0]} x {ref.shape[1]} x {K}): {100 * same:.2f} % bit-identical, worst {worst:.2f} of one bf16 ulp")
+            assert same >= 0.97 and worst <= 1.0, rep[-1]            # the only freedom is the order of the fp32 accumulation over K
+        # (b) whole truncated model: deviation from the fp8 oracle and from the plain bf16 oracle (= the quantisation noise itself)
+        kw = dict(batch)
+        kw["pixel_values"] = batch["pixel_values"].to(torch.bfloat16)
+        with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+            g8 = R2.forward(s, arch, **kw, icv=icv, hook_layers=layers, fp8_text=True).float()
         valid = batch["attention_mask"].bool()
-        a, b = gold["bf16"]["logits"], lg.float().cpu()
-        rel = float((a - b)[valid].norm() / a[valid].norm())
-        cos = torch.nn.functional.cosine_similarity(a[valid], b[valid], dim=-1)
-        rep.append(f"fp8 text stack vs plain bf16 oracle (quantisation noise, 2 images + text): relative L2 {rel:.3f}, min cosine {float(cos.min()):.4f}")
-        assert rel8 <= 0.2 and rel <= 0.2 and float(cos.min()) >= 0.97, rep[-1]
+        b = lg.float().cpu()
+        for what, a in (("fp8 oracle", g8), ("plain bf16 oracle (quantisation noise)", gold["bf16"]["logits"])):
+            rel = float((a - b)[valid].norm() / a[valid].norm())
+            cos = torch.nn.functional.cosine_similarity(a[valid], b[valid], dim=-1)
+            rep.append(f"fp8 text stack, logits after 2 layers vs {what}: relative L2 {rel:.3f}, min cosine {float(cos.min()):.4f}")
+            assert rel <= 0.2 and float(cos.min()) >= 0.97, rep[-1]
         assert all(set(L.q8) == {"qkv_w", "o_w", "gu_w", "down_w"} for L in eng.w.text)
     print("\n  W2 " + "\n  W2 ".join(rep))
 

@@ -254,6 +254,42 @@ def test_gemm_large_tile_kernels_match_general_kernel(variant, M, N, K):
         assert (outs[6][:32].float() - ref).abs().max() <= 2 ** -7 * ref.abs().max()
 
 
+@pytest.mark.parametrize("variant", ["plain", "bias", "bias_gelu", "bias_gelu_tanh", "bias_relu", "swiglu"])
+@pytest.mark.parametrize("M,N,K", [(700, 576, 192), (1030, 1280, 1280), (4200, 4352, 128), (2304, 3840, 1280)])
+def test_gemm_flow_kernel_matches_general_kernel(variant, M, N, K):
+    """The persistent "flow" kernel (select 20: register-direct epilogue, stores left in flight under the next tile's main
+    loop, next tile's K stages issued before the epilogue) against the general 128x128 kernel (select 1): bit-identical,
+    for every epilogue family it takes, with ragged M, a partial last tile column (N % 256 != 0), the minimum K (4 stages)
+    and more tiles than CUs (289: a second tile per workgroup, so the counted vmcnt waits see the previous tile's stores)."""
+    from licv import _lib
+    o = ops()
+    assert _lib.lib().licv_gemm_flow_available() == 1, "flow kernel unavailable (scratch in its code object?)"
+    a = torch.randn(M, K, generator=g(43)).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(N, K, generator=g(44)) * 0.05).to(torch.bfloat16).to(DEV)
+    kw = {}
+    if variant.startswith("bias"):
+        kw["bias"] = (torch.randn(N, generator=g(45)) * 0.1).to(torch.bfloat16).to(DEV)
+    if variant.endswith("gelu"):
+        kw["act"] = "gelu"
+    elif variant.endswith("gelu_tanh"):
+        kw["act"] = "gelu_tanh"
+    elif variant.endswith("relu"):
+        kw["act"] = "relu"
+    elif variant == "swiglu":
+        kw["swiglu"] = True
+    outs = {}
+    try:
+        for sel in (1, 20, 20):
+            _lib.lib().licv_gemm_select(sel)
+            outs.setdefault(sel, []).append(o.linear(a, w, **kw).clone())
+    finally:
+        _lib.lib().licv_gemm_select(0)
+    assert torch.equal(outs[1][0], outs[20][0]) and torch.equal(outs[20][0], outs[20][1])
+    ref = (a[:32].float() @ w.float().t())
+    if variant == "plain":
+        assert (outs[20][0][:32].float() - ref).abs().max() <= 2 ** -7 * ref.abs().max()
+
+
 def test_gemm_linearity_at_headline_shape():
     # size-independent property at the full decoder shape (M = 8*800): f(a1 + a2) == f(a1) + f(a2) in fp32 out
     M, N, K = 6400, 4096, 4096
