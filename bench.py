@@ -3,8 +3,10 @@
 (BASELINE.json configs[1]; SURVEY.md §8d shape "H") on N MI355X, one process per GPU.
 
     python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus N ...                      (starts its own N ranks: a child `torch.distributed.run`, before this
+                                                       process has touched the GPU, and exits with the child's code)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W        (the driver's form: RANK / LOCAL_RANK / WORLD_SIZE from the environment)
 
 A step = one full hooked forward over one batch resident in HBM: ViT-H/14 on B*33 images, perceiver,
 32 decoder + 8 gated cross-attention layers with the ICV hook on every decoder layer, LM head (logits for all
@@ -65,18 +67,14 @@ def _host_cores() -> int:
     return n
 
 
-def cpu_baseline(arch, S, n_img):
-    """The oracle (CPU restatement of the reference path, bf16 like the reference model) timed on this box's host
-    cores on a BOUNDED sample: one question at full width through ONE layer of each kind (ViT layer on all images,
-    perceiver block, gated cross-attention layer, hooked decoder layer, LM head), scaled by the layer counts."""
+def _cpu_baseline_one(arch, S, n_img, dtype):
+    """One question at full width through ONE layer of each kind in the CPU oracle at `dtype`; returns (s/question, timings)."""
     from licv.synthetic import synth_idefics_weights, synth_vqa_batch
     from oracle import icv_ref as O
     from oracle import idefics_ref as R
-    cores = _host_cores()
-    torch.set_num_threads(cores)
     small = arch.with_(v_layers=1, r_depth=1, num_layers=1, cross_layer_interval=1)
-    sd = synth_idefics_weights(small, seed=1, dtype=torch.bfloat16)
-    batch = synth_vqa_batch(small, 1, S, n_img, seed=2, min_len=S, dtype=torch.bfloat16)
+    sd = synth_idefics_weights(small, seed=1, dtype=dtype)
+    batch = synth_vqa_batch(small, 1, S, n_img, seed=2, min_len=S, dtype=dtype)
     icv = torch.randn(1, 1, arch.hidden_size) * 0.01
     tm = {}
 
@@ -90,22 +88,60 @@ def cpu_baseline(arch, S, n_img):
         pv = batch["pixel_values"].view(n_img, *batch["pixel_values"].shape[2:])
         x = timed("vit_layer", lambda: R.vision_tower(pv, sd, small))
         img = timed("perceiver_block", lambda: R.perceiver(x, sd, small)).view(1, -1, arch.v_embed)
-        pos, causal, img_mask, gate = R.build_masks(batch["attention_mask"], batch["image_attention_mask"], arch.image_seq_len,
-                                                    torch.bfloat16)
-        cos, sin = R.rotary_tables(arch.head_dim, arch.max_positions, arch.rope_base, torch.bfloat16)
+        pos, causal, img_mask, gate = R.build_masks(batch["attention_mask"], batch["image_attention_mask"], arch.image_seq_len, dtype)
+        cos, sin = R.rotary_tables(arch.head_dim, arch.max_positions, arch.rope_base, dtype)
         h = R.decoupled_embedding(batch["input_ids"], sd, arch.vocab_size)
         h = timed("xattn_layer", lambda: R.gated_xattn_layer(h, sd, 0, small, img, img_mask, gate))
         h = timed("decoder_layer+hook", lambda: O.inject_renorm(R.decoder_layer(h, sd, 0, small, causal, pos, cos, sin), icv[:, 0]))
-        timed("norm+lm_head", lambda: R.lm_head(R.rms_norm(h, sd["model.norm.weight"], arch.rms_eps), sd))
+        timed("norm+lm_head", lambda: R.lm_head(R.rms_norm(h.to(dtype), sd["model.norm.weight"], arch.rms_eps), sd))
     full = (tm["vit_layer"] * arch.v_layers + tm["perceiver_block"] * arch.r_depth + tm["xattn_layer"] * arch.num_cross_layers
             + tm["decoder_layer+hook"] * arch.num_layers + tm["norm+lm_head"])
+    return full, tm
+
+
+def cpu_baseline(arch, S, n_img):
+    """The oracle (CPU restatement of the reference path) timed on this box's host cores on a BOUNDED sample: one question at
+    full width through ONE layer of each kind (ViT layer on all images, perceiver block, gated cross-attention layer, hooked
+    decoder layer, LM head), scaled by the layer counts — in fp32 AND in bf16 (the reference's model dtype; without AMX/
+    AVX512-BF16 a CPU runs bf16 slower than fp32, so `value` is the FASTER of the two: the baseline is what the host can do)."""
+    cores = _host_cores()
+    torch.set_num_threads(cores)
+    res = {}
+    for name, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        res[name] = _cpu_baseline_one(arch, S, n_img, dt)
+    best = min(res, key=lambda k: res[k][0])
+    full, tm = res[best]
     return {
-        "value": 1.0 / full, "unit": "questions/s", "cores": cores, "kind": "port",
-        "sample": (f"1 question (S={S}, {n_img} images) through the CPU oracle in bf16, one layer of each kind: "
+        "value": 1.0 / full, "unit": "questions/s", "cores": cores, "kind": "port", "dtype": best,
+        "value_fp32": 1.0 / res["fp32"][0], "value_bf16": 1.0 / res["bf16"][0],
+        "sample": (f"1 question (S={S}, {n_img} images) through the CPU oracle, one layer of each kind, fp32 and bf16 "
+                   f"(fp32 {res['fp32'][0]:.1f} s/question, bf16 {res['bf16'][0]:.1f} s/question; value = {best}): "
                    + ", ".join(f"{k} {v:.2f}s" for k, v in tm.items())
                    + f"; scaled by layer counts ({arch.v_layers} ViT, {arch.r_depth} perceiver, {arch.num_cross_layers} x-attn, "
                    f"{arch.num_layers} decoder) = {full:.1f} s/question"),
     }
+
+
+def gpu_unfused_baseline(arch, sd, batch, icv_eff, layers, B, steps=3):
+    """"Reference on GPU" denominator: the SAME restatement of the reference path that
+    serves as the oracle, run unfused on this GPU through PyTorch-ROCm's own kernels (rocBLAS/hipBLASLt GEMMs, eager attention,
+    one ATen launch per elementwise op, the hook as the reference's 7 ATen ops) at the headline shape, full depth, bf16.
+    A reported baseline only: nothing of the product path goes through it."""
+    from oracle import idefics_ref as R
+    kw = {k: v for k, v in batch.items()}
+    times = []
+    with torch.no_grad(), torch.device(batch["input_ids"].device):       # factory calls inside the oracle land on the GPU
+        for i in range(steps + 1):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = R.forward(sd, arch, **kw, icv=icv_eff, hook_layers=layers)
+            torch.cuda.synchronize()
+            if i:                                                           # first pass = warm-up (library handles, autotune)
+                times.append(time.perf_counter() - t0)
+            del out
+    t = sorted(times)[len(times) // 2]
+    return {"value": B / t, "unit": "questions/s", "ms_per_step": 1e3 * t, "steps": steps, "kind": "oracle restatement on device=cuda (unfused PyTorch-ROCm)",
+            "dtype": "bf16 weights, fp32 residual stream after the first hook (as the reference)"}
 
 
 def cpu_baseline_idefics2(arch, S, n_img, hw):
@@ -185,15 +221,27 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="idefics9b_32shot_bs8", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gpu-baseline", action="store_true", help="skip the unfused PyTorch-ROCm run of the oracle on the GPU (row G0)")
     ap.add_argument("--no-hooks", action="store_true", help="teacher shape: same forward with the intervention off")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; default).  'gloo' only to rehearse the multi-rank code path "
                     "on a box with fewer GPUs than ranks (ranks then share devices: timings are meaningless)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: start N ranks as fresh child processes (one per GPU, RCCL) BEFORE this process has
+        # made any GPU call, and hand their exit code back
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+        sys.exit(subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))).returncode)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     assert torch.cuda.is_available(), "bench.py needs a GPU: the L-ICV hot path has no CPU fallback"
     if args.dist_backend != "nccl":
         local = local % torch.cuda.device_count()
@@ -231,7 +279,10 @@ def main():
         eng = Idefics2Engine(Idefics2Weights(sd, arch, dev, fp8_text="fp8" in args.workload))
     else:
         eng = IdeficsEngine(IdeficsWeights(sd, arch, dev))
-    del sd
+    want_g0 = (rank == 0 and world == 1 and not is2 and not training and "generate" not in args.workload and not args.no_gpu_baseline
+               and not args.no_hooks)
+    if not want_g0:
+        del sd
     torch.cuda.empty_cache()
     if is2:
         ih, iw = IDEFICS2_IMAGE[preset]
@@ -265,18 +316,23 @@ def main():
         step()
     prof = []
     ops.set_profiler(prof)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         out = step()
+        marks[i + 1].record()                                          # per-step boundaries on the stream (no sync): median below
     fence()
     elapsed = time.perf_counter() - t0
     ops.set_profiler(None)
     del out
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2])
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed, median_ms], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
+        elapsed, median_ms = float(t[0]), float(t[1])
 
     ms_per_step = 1e3 * elapsed / args.steps
     qps = B * world * args.steps / elapsed
@@ -289,9 +345,12 @@ def main():
     # algorithmic bytes of the GEMM launches (operands once + output once; bf16 operands, output/residual in their dtype is
     # not known here -> bf16 output assumed, a lower bound) and the PMC-measured L2<->fabric traffic of the same launches
     gemm_alg = sum(2.0 * (m * k + n * k + m * n) for rec in prof if rec[0] == "gemm" and len(rec) > 4 for (m, n, k) in [rec[4]])
+    # roofline.traffic comes from PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over THIS command: a profiler cannot run inside
+    # the timed region); the newest committed summary is used and named, with the commit it was measured at
     pmc = None
-    pmc_file = ROOT / "profiles" / "r01_pmc_headline_gemm.json"
-    if args.workload == "idefics9b_32shot_bs8" and not args.no_hooks and pmc_file.exists():
+    pmc_files = sorted((ROOT / "profiles").glob("r*_pmc_headline_gemm.json"))
+    if args.workload == "idefics9b_32shot_bs8" and not args.no_hooks and pmc_files:
+        pmc_file = pmc_files[-1]
         pmc = json.loads(pmc_file.read_text())
     ti, by, ni = agg("inject")
     fq = {"total": fl / max(args.steps, 1) / B} if is2 else flops_per_question(arch, S, n_img)   # Idefics2: GEMM flops as launched
@@ -302,15 +361,17 @@ def main():
                    "VQA questions/sec (whole node), Idefics-9B hooked generate (query-only prompt, 3 beams, 5 new tokens)" if generating else
                    "VQA questions/sec (whole node), Idefics-9B 32-shot ICV forward"),
         "value": qps, "unit": "questions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": ms_per_step, "ms_per_step_median": median_ms, "value_at_median": B * world / (median_ms * 1e-3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "fp8 e4m3 text-stack GEMM operands (fp32 accumulate), bf16 elsewhere" if "fp8" in args.workload else "bf16", "data": f"synthetic (random-init {preset} weights, seeded image+text batches)",
         "config": {"workload": args.workload, "arch": preset, "questions_per_gpu": B, "seq_len": S, "images_per_question": n_img,
                    "hooked_layers": 0 if args.no_hooks else arch.num_layers, "parallelism": f"dp{world}",
                    **({"train": "teacher fwd + student fwd/bwd + KL; accumulate 2; 1 all-reduce of 131 105 fp32 + AdamW per optimiser step"} if training else {})},
-        "roofline": {"bound": "mfma", "kernel": "gemm_bf16_pingpong_k (256x256 LDS-DMA ring; small shapes: gemm_bf16_tile128_k)", "achieved": fl / tg / 1e12 if tg else None,
+        "roofline": {"bound": "mfma", "kernel": "gemm_bf16_pingpong_k / gemm_bf16_flow_k (256x256 LDS-DMA ring; small shapes: gemm_bf16_tile128_k)", "achieved": fl / tg / 1e12 if tg else None,
                      "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": (fl / tg / 1e12) / PEAK_BF16_TFLOPS if tg else None,
                      "traffic": pmc["traffic_bytes_per_launch"] / 1e9 if pmc else None, "traffic_unit": "GB per launch (average over the step's GEMM launches)",
-                     "traffic_source": ("profiles/r01_pmc_headline_gemm.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command; "
+                     "traffic_source": (f"profiles/{pmc_file.name} (measured at commit {pmc.get('commit', 'of round 1')}, kernels {pmc.get('kernel')}): "
+                                        "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command, summed over the GEMM launches; "
                                         "FETCH_SIZE x2 (gfx950), counts Infinity-Cache hits as well as HBM") if pmc else None,
                      "algorithmic_GB_per_launch": gemm_alg / ng / 1e9 if ng else None,
                      "achieved_GBps_algorithmic": gemm_alg / tg / 1e9 if tg else None,
@@ -324,6 +385,15 @@ def main():
                               "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": by / ti / 1e9 / PEAK_HBM_GBS,
                               "launches_per_step": ni // max(args.steps, 1), "avg_launch_us": 1e6 * ti / ni,
                               "algorithmic_MB_per_question": by / max(args.steps, 1) / B / 1e6}
+    if want_g0:
+        del eng
+        torch.cuda.empty_cache()
+        g0 = gpu_unfused_baseline(arch, sd, batch, (alpha.unsqueeze(-1) * icv), layers, B)
+        g0["native_over_unfused"] = qps / g0["value"]
+        res["gpu_unfused_baseline"] = g0
+        res["vs_baseline_note"] = ("null: BASELINE.md holds no published number for this metric; the measured 'reference on GPU' denominator "
+                                   "(row G0) is gpu_unfused_baseline, native/unfused = %.2fx" % g0["native_over_unfused"])
+        del sd
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline_idefics2(arch, S, n_img, IDEFICS2_IMAGE[preset]) if is2 else cpu_baseline(arch, S, n_img)
     if rank == 0:

@@ -146,7 +146,10 @@ def _decode(model, a, input_ids: torch.Tensor, attention_mask: torch.Tensor, max
     # ---- beam search (GenerationMixin._beam_search, transformers 5.x)
     keep = 2 * nb                                                      # max(2, 1 + n_eos) * num_beams
     top_mask = torch.cat([torch.ones(nb, dtype=torch.bool), torch.zeros(keep - nb, dtype=torch.bool)]).to(dev)
-    running = torch.full((B, nb, max_len), pad, dtype=torch.long, device=dev)
+    # hf:generation/utils.py:3319 — `output_fill_value = pad_token_id or eos_token_id[0]`: a pad id of 0 (Idefics' <unk>) is falsy
+    # there, so finished beams are padded with EOS, not with the pad id (greedy above does use the pad id)
+    fill = pad if (pad or eos is None) else eos
+    running = torch.full((B, nb, max_len), fill, dtype=torch.long, device=dev)
     running[:, :, :P] = input_ids[:, None, :]
     finished = running.clone()
     run_scores = torch.zeros((B, nb), dtype=torch.float, device=dev)

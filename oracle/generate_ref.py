@@ -46,16 +46,20 @@ class _Idefics2Model:
         self.sd, self.arch, self.hooks, self.nb = sd, arch, hooks, nb
         self.img = R2.image_features(pixel_values, pixel_attention_mask, sd, arch)          # (n_real*L, H), rows in batch order
         self.ids = self.pos = None
+        self.prompt_len = None
 
     def _fwd(self, am):
         B = self.ids.shape[0] // self.nb
-        per_row = (self.ids[:: self.nb] == self.arch.image_token_id).sum(1)                # image rows per original question
+        P = self.prompt_len
+        per_row = (self.ids[:: self.nb, :P] == self.arch.image_token_id).sum(1)            # image rows per original question (prompt only)
         chunks = torch.split(self.img, per_row.tolist())
         img = torch.cat([c for c in chunks for _ in range(self.nb)]) if self.nb > 1 else self.img
-        return R2.forward(self.sd, self.arch, self.ids, am, image_hidden_states=img, position_ids=self.pos, **self.hooks)[:, -1, :].float()
+        return R2.forward(self.sd, self.arch, self.ids, am, image_hidden_states=img, position_ids=self.pos, scatter_len=P,
+                          **self.hooks)[:, -1, :].float()
 
     def prefill(self, ids, am):
         self.ids = ids
+        self.prompt_len = ids.shape[1]
         self.pos = (am.long().cumsum(-1) - 1).masked_fill(am == 0, 0)
         return self._fwd(am)
 
@@ -116,7 +120,9 @@ def _decode(model, arch, input_ids, attention_mask, max_new_tokens=5, num_beams=
 
     keep = 2 * nb
     top_mask = torch.cat([torch.ones(nb, dtype=torch.bool), torch.zeros(keep - nb, dtype=torch.bool)])
-    running = torch.full((B, nb, max_len), pad, dtype=torch.long)
+    # hf:generation/utils.py:3319 — `output_fill_value = pad_token_id or eos_token_id[0]`: pad id 0 is falsy, EOS fills instead
+    fill = pad if (pad or eos is None) else eos
+    running = torch.full((B, nb, max_len), fill, dtype=torch.long)
     running[:, :, :P] = input_ids[:, None, :]
     finished = running.clone()
     run_scores = torch.zeros((B, nb)); run_scores[:, 1:] = -1e9

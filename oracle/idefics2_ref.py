@@ -167,17 +167,21 @@ def fp8_linear(x, w):
 def forward(sd: Dict[str, torch.Tensor], arch, input_ids, attention_mask, pixel_values=None, pixel_attention_mask=None,
             icv: Optional[torch.Tensor] = None, hook_layers: Optional[Sequence[int]] = None, capture: Optional[dict] = None,
             image_hidden_states: Optional[torch.Tensor] = None, position_ids: Optional[torch.Tensor] = None,
-            fp8_text: bool = False):
+            fp8_text: bool = False, scatter_len: Optional[int] = None):
     """logits (B, S, V).  icv (1, n_hooked, H) fp32, already alpha-scaled; the hook edits the MLP output of text layer l.
-    fp8_text: the four projections of every text layer run through ``fp8_linear`` (the build's configs[4] mode)."""
+    fp8_text: the four projections of every text layer run through ``fp8_linear`` (the build's configs[4] mode).
+    scatter_len: only `<image>` tokens at positions < scatter_len receive image features (a cache-less decode re-runs the whole
+    prefix; HF merges image features in the prefill only, so an `<image>` id that was GENERATED keeps its table embedding)."""
     tp = "model.text_model."
     B, S = input_ids.shape
     h = F.embedding(input_ids, sd[tp + "embed_tokens.weight"])
     if image_hidden_states is None and pixel_values is not None:
         image_hidden_states = image_features(pixel_values, pixel_attention_mask, sd, arch)
     if image_hidden_states is not None:
-        special = (input_ids == arch.image_token_id).unsqueeze(-1)
-        h = h.masked_scatter(special, image_hidden_states.to(h.dtype))
+        special = input_ids == arch.image_token_id
+        if scatter_len is not None:
+            special = special & (torch.arange(S)[None, :] < scatter_len)
+        h = h.masked_scatter(special.unsqueeze(-1), image_hidden_states.to(h.dtype))
     dtype = h.dtype
     nh, nkv, hd = arch.num_heads, arch.num_kv_heads, arch.head_dim
     # rotary from position_ids = arange(S) (hf:mistral/modeling_mistral.py MistralModel.forward), fp32 maths, cast to the model dtype

@@ -157,7 +157,8 @@ def test_w2_idefics2_8b_widths_truncated_depth_vs_oracle(fp8):
             tol = (ref.abs() * 2.0 ** -7 + ref.abs().max() * 2.0 ** -9) * 1.001      # one bf16 ulp (the bar of tests/test_ops_gpu.py close_bf16)
             worst = float(((got - ref).abs() / tol).max())
             rep.append(f"fp8 {name} projection ({x.shape[0]} x {ref.shape[1]} x {K}): {100 * same:.2f} % bit-identical, worst {worst:.2f} of one bf16 ulp")
-            assert same >= 0.97 and worst <= 1.0, rep[-1]            # the only freedom is the order of the fp32 accumulation over K
+            # the only freedom is the order of the fp32 accumulation over K (the SwiGLU form rounds twice: silu, product)
+            assert same >= 0.97 and worst <= (2.0 if name.startswith("gate") else 1.0), rep[-1]
         # (b) whole truncated model: deviation from the fp8 oracle and from the plain bf16 oracle (= the quantisation noise itself)
         kw = dict(batch)
         kw["pixel_values"] = batch["pixel_values"].to(torch.bfloat16)

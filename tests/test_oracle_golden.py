@@ -303,3 +303,46 @@ def test_g10_hard_loss_and_grads(golden, dn, dt):
     g_icv, g_alpha = T(z[f"{dn}_grad_icv"]), T(z[f"{dn}_grad_alpha"])
     assert (icv.grad - g_icv).abs().max() <= (1e-7 if dn == "f32" else 2e-3 * g_icv.abs().max())
     assert (alpha.grad - g_alpha).abs().max() <= (1e-7 if dn == "f32" else 2e-3 * g_alpha.abs().max())
+
+
+@pytest.mark.parametrize("model", ["idefics", "idefics2"])
+def test_oracle_bf16_decode_equals_reference_bf16_generate(golden, model):
+    """g11 / g12: the reference wrapper driving HF generate in its bf16 regime, 16 prompts per padding side, beams 3 / greedy /
+    hooks off.  The oracle's decode (oracle/generate_ref.py) must reproduce every id: this is what pins the bf16 search path
+    the GPU tests compare with."""
+    import torch
+    from oracle import generate_ref as G
+    T = torch.from_numpy
+    if model == "idefics":
+        from licv.config import IDEFICS_TINY
+        from licv.synthetic import synth_idefics_weights
+        z = golden("g11_generate_bf16")
+        arch = IDEFICS_TINY.with_(additional_vocab_size=0)
+        sd = synth_idefics_weights(arch, seed=121, dtype=torch.float32)
+        sd["model.embed_tokens.weight"] *= float(z["embed_scale"])
+        keys, gen, mask_key = ("input_ids", "attention_mask", "pixel_values", "image_attention_mask"), G.generate, None
+    else:
+        from licv.config import IDEFICS2_TINY
+        from licv.synthetic import synth_idefics2_weights
+        z = golden("g12_generate_idefics2_bf16")
+        arch = IDEFICS2_TINY
+        sd = synth_idefics2_weights(arch, seed=181, dtype=torch.float32)
+        sd["model.text_model.embed_tokens.weight"] *= float(z["embed_scale"])
+        for l in range(arch.num_layers):
+            sd[f"model.text_model.layers.{l}.mlp.down_proj.weight"] *= float(z["down_scale"])
+        keys, gen = ("input_ids", "attention_mask", "pixel_values", "pixel_attention_mask"), G.generate_idefics2
+    sd["lm_head.weight"] *= float(z["head_scale"])
+    sd = {k: v.to(torch.bfloat16) for k, v in sd.items()}
+    icv, layers = T(z["icv"]), list(range(arch.num_layers))
+    kw = dict(max_new_tokens=5, length_penalty=0.0, min_new_tokens=0)
+    import contextlib
+    ctx = torch.autocast("cpu", dtype=torch.bfloat16) if model == "idefics2" else contextlib.nullcontext()
+    for side in ("left", "right"):
+        cb = {k: T(z[f"{side}_in_{k}"]) for k in keys}
+        cb["pixel_values"] = cb["pixel_values"].to(torch.bfloat16)
+        with ctx:
+            outs = dict(beam=gen(sd, arch, **cb, icv=icv, hook_layers=layers, num_beams=3, **kw),
+                        greedy=gen(sd, arch, **cb, icv=icv, hook_layers=layers, num_beams=1, **kw),
+                        greedy_off=gen(sd, arch, **cb, num_beams=1, **kw))
+        for tag, got in outs.items():
+            assert torch.equal(got, T(z[f"{side}_bf16_{tag}_ids"])), f"{model} {side} {tag}"

@@ -433,6 +433,117 @@ def g8_generate_idefics2():
     np.savez_compressed(OUT / "g8_generate_idefics2.npz", **out)
 
 
+JITTER_SIGMA, JITTER_TRIALS = 0.01, 12
+
+
+def _gen_with_margins(w, icv, batch, num_beams, prompt_len, n_rows):
+    """Reference generate (through the reference's wrapper, its own call shape: ref:inference.py:313,
+    ref:config/inference.yaml:26-30) returning the ids plus, per row, how ROBUST that decode is to bf16-level noise:
+    the same reference call is repeated JITTER_TRIALS times with N(0, JITTER_SIGMA) added to the next-token scores of every
+    step (a transformers LogitsProcessor; sigma = 0.01: the reference's own bf16-vs-fp32 logit difference on these
+    models is 0.0075 RMS / 0.027 max at |logit| <= 6.3, i.e. about one bf16 ulp) and the
+    fraction of trials that reproduce the row's ids is stored.  A row with stability 1.0 is decided by more than bf16
+    noise — every candidate comparison of the search, not only the final one — and an implementation computing in bf16
+    must reproduce it exactly; rows below 1.0 are the reference's own near-ties."""
+    from transformers import LogitsProcessor, LogitsProcessorList
+
+    class Jitter(LogitsProcessor):
+        def __init__(self, seed):
+            self.g = torch.Generator().manual_seed(seed)
+
+        def __call__(self, input_ids, scores):
+            return scores + JITTER_SIGMA * torch.randn(scores.shape, generator=self.g).to(scores.dtype)
+
+    plain = dict(max_new_tokens=5, do_sample=False)
+    if num_beams > 1:
+        plain.update(num_beams=num_beams, length_penalty=0.0, min_new_tokens=0)
+    with torch.inference_mode():
+        ids = w.generate(icv=icv, **batch, **plain)
+        hits = torch.zeros(n_rows)
+        for t in range(JITTER_TRIALS):
+            alt = w.generate(icv=icv, **batch, **plain, logits_processor=LogitsProcessorList([Jitter(1000 + t)]))
+            n = min(alt.shape[1], ids.shape[1])
+            hits += ((alt[:, :n] == ids[:, :n]).all(dim=1) & (alt.shape[1] == ids.shape[1])).float()
+    return ids, hits / JITTER_TRIALS
+
+
+def g11_generate_bf16():
+    """Hooked generate ids in the reference's own bf16 regime (ref:inference.py:300-321, ref:config/inference.yaml:26-30):
+    Idefics with bf16 weights driven by the reference wrapper, 16 prompts per padding side, beam search (3 beams, 5 new tokens,
+    length_penalty 0) and greedy, with and without the intervention.  Per-row stabilities (see _gen_with_margins) tell the tests
+    which rows are decided by more than bf16 noise."""
+    from icv_src.icv_model.icv_intervention import LearnableICVInterventionLMM
+    arch = IDEFICS_TINY.with_(additional_vocab_size=0)
+    seed, B = 121, 16
+    out = {}
+    sd32 = synth_idefics_weights(arch, seed=seed, dtype=torch.float32)
+    out["weights_checksum"] = np.array(weights_checksum(sd32))
+    out["embed_scale"], out["head_scale"] = np.array(25.0), np.array(10.0)
+    sd32["model.embed_tokens.weight"] *= 25.0
+    sd32["lm_head.weight"] *= 10.0
+    g = torch.Generator().manual_seed(seed + 1)
+    icv = torch.randn(1, arch.num_layers, arch.hidden_size, generator=g) * 0.2
+    out["icv"] = np_(icv)
+    model = hf_model(arch, sd32, torch.bfloat16)
+    model.generation_config.pad_token_id = arch.pad_token_id
+    iface = Interface(model, arch.pad_token_id)
+    for pad_side in ("left", "right"):
+        mn = 9 if pad_side == "left" else 12                  # right padding: full rows (the prompt must end in real tokens)
+        batch = synth_vqa_batch(arch, B, 12, 1, seed=seed + (0 if pad_side == "left" else 7), min_len=mn, dtype=torch.float32,
+                                padding_side=pad_side)
+        for k, v in batch.items():
+            out[f"{pad_side}_in_{k}"] = np_(v)
+        kw = dict(batch)
+        kw["pixel_values"] = batch["pixel_values"].to(torch.bfloat16)
+        w = LearnableICVInterventionLMM(iface, True, -1, "model.model.layers.<LAYER_NUM>", arch.num_layers)
+        for tag, beams, on in (("beam", 3, True), ("greedy", 1, True), ("greedy_off", 1, False)):
+            w.toggle_intervention(on)
+            ids, mg = _gen_with_margins(w, icv, kw, beams, 12, B)
+            out[f"{pad_side}_bf16_{tag}_ids"] = ids.numpy()
+            out[f"{pad_side}_bf16_{tag}_stability"] = mg.numpy()
+    np.savez_compressed(OUT / "g11_generate_bf16.npz", **out)
+
+
+def g12_generate_idefics2_bf16():
+    """As g11 for Idefics2: bf16 weights under torch.autocast (the regime the reference needs for it), hook on
+    every text layer's `.mlp`, 16 prompts per padding side with two ragged images each."""
+    from icv_src.icv_model.icv_intervention import LearnableICVInterventionLMM
+    arch = IDEFICS2_TINY
+    seed, B = 181, 16
+    out = {}
+    sd32 = synth_idefics2_weights(arch, seed=seed, dtype=torch.float32)
+    out["weights_checksum"] = np.array(weights_checksum(sd32))
+    out["embed_scale"], out["head_scale"], out["down_scale"] = np.array(25.0), np.array(10.0), np.array(40.0)
+    sd32["model.text_model.embed_tokens.weight"] *= 25.0
+    sd32["lm_head.weight"] *= 10.0
+    for l in range(arch.num_layers):
+        sd32[f"model.text_model.layers.{l}.mlp.down_proj.weight"] *= 40.0
+    fmt = "model.model.text_model.layers.<LAYER_NUM>.mlp"
+    g = torch.Generator().manual_seed(seed + 1)
+    icv = torch.randn(1, arch.num_layers, arch.hidden_size, generator=g) * 0.2
+    out["icv"] = np_(icv)
+    model = hf_idefics2(arch, sd32, torch.bfloat16)
+    model.generation_config.pad_token_id = arch.pad_token_id
+    model.generation_config.eos_token_id = arch.eos_token_id
+    iface = Interface(model, arch.pad_token_id)
+    for pad_side in ("left", "right"):
+        mn = 15 if pad_side == "left" else 20
+        batch = synth_vqa_batch_idefics2(arch, B, 20, 2, 56, 42, seed=seed + (0 if pad_side == "left" else 7), min_len=mn,
+                                         dtype=torch.float32, padding_side=pad_side)
+        for k, v in batch.items():
+            out[f"{pad_side}_in_{k}"] = np_(v)
+        kw = dict(batch)
+        kw["pixel_values"] = batch["pixel_values"].to(torch.bfloat16)
+        w = LearnableICVInterventionLMM(iface, True, -1, fmt, arch.num_layers)
+        for tag, beams, on in (("beam", 3, True), ("greedy", 1, True), ("greedy_off", 1, False)):
+            w.toggle_intervention(on)
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                ids, mg = _gen_with_margins(w, icv, kw, beams, 20, B)
+            out[f"{pad_side}_bf16_{tag}_ids"] = ids.numpy()
+            out[f"{pad_side}_bf16_{tag}_stability"] = mg.numpy()
+    np.savez_compressed(OUT / "g12_generate_idefics2_bf16.npz", **out)
+
+
 def g6_loss():
     """The reference's VQAICVModule.forward (student hooked + teacher plain + KL) and its grads."""
     from icv_src.icv_encoder.global_icv_encoder import GlobalICVEncoder
@@ -652,8 +763,9 @@ def main():
     import icv_src.icv_model.icv_intervention as _ri
     assert _ri.__file__.startswith(str(REF)), _ri.__file__
     torch.set_num_threads(4)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
-    fns = dict(g1=g1_encoder, g2=g2_intervention, g3=g3_idefics, g4=g4_idefics2, g5=g5_generate, g6=g6_loss, g7=g7_optim, g8=g8_generate_idefics2, g9=g9_loss_idefics2, g10=g10_hard_loss)
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
+    fns = dict(g1=g1_encoder, g2=g2_intervention, g3=g3_idefics, g4=g4_idefics2, g5=g5_generate, g6=g6_loss, g7=g7_optim, g8=g8_generate_idefics2, g9=g9_loss_idefics2, g10=g10_hard_loss,
+               g11=g11_generate_bf16, g12=g12_generate_idefics2_bf16)
     for w in which:
         print("generating", w, flush=True)
         fns[w]()
