@@ -219,6 +219,22 @@ int licv_kl_rows_bwd(const void* stu_logits, const void* tea_logits, int dtype, 
                      int64_t n_rows, int64_t vocab, int64_t ld_stu, int64_t ld_tea, float temperature, float eps, float upstream,
                      const float* upstream_dev, void* grad_rows_bf16, int64_t ld_grad, void* stream);
 
+/* ---- device-side front-end: integer rules between the collator / processor and the first GEMM ---- */
+/* Idefics image_attention_mask (B, S, n_images) int32 one-hot rows from input_ids (B, S) int64 by the incremental rule of
+ * hf:idefics/processing_idefics.py:89-110 + :66-79 (ref:icv_src/icv_datamodule.py:80-124 gets it from processor.prepare_input). */
+int licv_idefics_image_attention_mask(const int64_t* input_ids, int32_t* mask_out, int64_t B, int64_t S, int64_t n_images,
+                                      int64_t image_token_id, int64_t eod_token_id, void* stream);
+/* Idefics2: per image real flag (some pixel != 0), patch validity (n, gh*gw) int32 and NaViT position ids (n, gh*gw) int64
+ * (hf:idefics2/modeling_idefics2.py:831-855, :136-170); boundaries = the module's fp32 arange(1/n_side, 1, 1/n_side);
+ * pixel_attention_mask (n, H, W) bytes, may be NULL (= everything attended). */
+int licv_idefics2_patch_front(const void* pixel_values_bf16, const void* pixel_attention_mask_u8, const float* boundaries,
+                              int32_t* real_out, int32_t* patch_valid_out, int64_t* position_ids_out,
+                              int64_t n_images, int64_t height, int64_t width, int64_t patch, int64_t n_side, void* stream);
+/* Idefics2 inputs_merger (hf:idefics2/modeling_idefics2.py:789-815): the k-th <image> token (row-major) of input_ids (M) takes row k
+ * of image_rows (n_image_rows, dim) in h (M, dim); rank_scratch: M int32; count_out (1 int32, optional) = number of <image> tokens. */
+int licv_merge_image_rows(void* h_bf16, const int64_t* input_ids, const void* image_rows_bf16, int32_t* rank_scratch,
+                          int32_t* count_out, int64_t M, int64_t dim, int64_t n_image_rows, int64_t image_token_id, void* stream);
+
 /* ---- loss + optimiser (ref:icv_src/icv_module.py:121-134, :171-209) ---- */
 /* per-row KL(teacher||student) with eps inside the log, rows gathered by index; out_rows fp32 (n_rows). */
 int licv_kl_rows_fwd(const void* stu_logits, const void* tea_logits, int dtype,

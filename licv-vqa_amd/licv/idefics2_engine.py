@@ -19,7 +19,7 @@ from typing import Dict, List, Optional, Sequence
 
 import torch
 
-from . import ops
+from . import frontend, ops
 from .config import Idefics2Arch
 from .idefics_engine import _bf, _pad_cols
 
@@ -130,27 +130,41 @@ class KVCache2:
             self.kv[i] = self.kv[i].index_select(0, idx)
 
 
-def navit_position_ids(patch_mask: torch.Tensor, n_side: int) -> torch.Tensor:
-    """hf:idefics2/modeling_idefics2.py:136-170 — fractional patch coordinates bucketised into the n_side x n_side
-    position table.  Tiny integer/host arithmetic on the (n, gh, gw) bool patch mask; runs on the CPU so that the
-    bucket boundaries are the same fp32 values the HF module builds."""
-    pm = patch_mask.cpu()
-    n, gh, gw = pm.shape
-    boundaries = torch.arange(1 / n_side, 1.0, 1 / n_side)
-    nb_h = pm[:, :, 0].sum(dim=1)
-    nb_w = pm[:, 0, :].sum(dim=1)
-    fh = torch.clamp(torch.arange(gh, dtype=torch.float32)[None, :] * (1.0 / nb_h)[:, None], max=1.0 - 1e-6)
-    fw = torch.clamp(torch.arange(gw, dtype=torch.float32)[None, :] * (1.0 / nb_w)[:, None], max=1.0 - 1e-6)
-    bh = torch.bucketize(fh.to(torch.bfloat16), boundaries, right=True)     # HF evaluates them in the pixel dtype (bf16)
-    bw = torch.bucketize(fw.to(torch.bfloat16), boundaries, right=True)
-    pos = (bh[:, :, None] * n_side + bw[:, None, :]).reshape(n, -1)
-    return torch.where(pm.view(n, -1), pos, torch.zeros_like(pos)).to(torch.int64)
+class _HostFlags:
+    """What the HOST must know about a batch before it can launch (how many images are real, whether any patch is masked, how
+    many <image> tokens there are) is computed on the device (licv.frontend) and read back ONCE per distinct input: later
+    forwards over the same tensor OBJECTS at the same version counter — the steady state of repeated evaluation, benchmarks
+    and the teacher / student pair of a step — make no host round trip at all.  Entries hold weak references and are matched by
+    object identity, so a new tensor that happens to reuse a freed address never hits a stale entry."""
+
+    def __init__(self, keep: int = 16):
+        self._entries, self._keep = [], keep
+
+    @staticmethod
+    def _sig(tensors):
+        return tuple(None if t is None else t._version for t in tensors)
+
+    def get(self, *tensors):
+        sig = self._sig(tensors)
+        for refs, vers, value in self._entries:
+            if vers == sig and len(refs) == len(tensors) and all((r is None and t is None) or (r is not None and r() is t)
+                                                                   for r, t in zip(refs, tensors)):
+                return value
+        return None
+
+    def put(self, value, *tensors):
+        import weakref
+        if len(self._entries) >= self._keep:
+            self._entries.pop(0)
+        self._entries.append((tuple(None if t is None else weakref.ref(t) for t in tensors), self._sig(tensors), value))
+        return value
 
 
 class Idefics2Engine:
     def __init__(self, weights: Idefics2Weights, fuse_hook_norm: bool = True):
         self.w, self.arch = weights, weights.arch
         self.fuse_hook_norm = fuse_hook_norm
+        self._flags = _HostFlags()
 
     # ----------------------------------------------------------------------------------- vision + connector
     def encode_images(self, pixel_values: torch.Tensor, pixel_attention_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -159,23 +173,24 @@ class Idefics2Engine:
         a, w = self.arch, self.w
         dev = w.device
         B, N = pixel_values.shape[:2]
-        pv = pixel_values.to(device=dev, dtype=torch.bfloat16).reshape(B * N, *pixel_values.shape[2:])
-        real = (pv == 0.0).sum(dim=(-1, -2, -3)) != pv.shape[1:].numel()
-        pv = pv[real].contiguous()
-        n = pv.shape[0]
-        Hh, Ww = pv.shape[-2:]
         P = a.v_patch
+        pv = pixel_values.to(device=dev, dtype=torch.bfloat16).reshape(B * N, *pixel_values.shape[2:]).contiguous()
+        Hh, Ww = pv.shape[-2:]
         gh, gw = Hh // P, Ww // P
         T = gh * gw
-        if pixel_attention_mask is None:
-            pmask = torch.ones((n, gh, gw), dtype=torch.bool, device=dev)
-        else:
-            pam = pixel_attention_mask.to(dev).reshape(B * N, Hh, Ww)[real]
-            sub = pam[:, :gh * P, :gw * P].reshape(n, gh, P, gw, P)
-            pmask = sub.sum(dim=(2, 4)) == P * P
-        valid = pmask.view(n, T).to(torch.int32).contiguous()
-        all_valid = bool(pmask.all())
-        pos_ids = navit_position_ids(pmask, a.v_image // P).to(dev).reshape(-1).contiguous()
+        pam = pixel_attention_mask.to(dev).reshape(B * N, Hh, Ww) if pixel_attention_mask is not None else None
+        # padding-image flags, patch validity and NaViT position ids: one integer kernel on the device (csrc/frontend.hip)
+        real, valid, pos_ids = frontend.idefics2_patch_front(pv, pam, P, a.v_image // P)
+        flags = self._flags.get(pixel_values, pixel_attention_mask)
+        if flags is None:                                  # first sight of these tensors: ONE 16-byte read-back
+            both = torch.stack([real.sum(), (valid * real[:, None]).sum()]).cpu()
+            flags = self._flags.put((int(both[0]), int(both[1])), pixel_values, pixel_attention_mask)
+        n, n_valid = flags
+        if n != B * N:                                     # all-zero padding images present: drop them (hf :831-836)
+            keep = real.bool()
+            pv, valid, pos_ids = pv[keep].contiguous(), valid[keep].contiguous(), pos_ids[keep].contiguous()
+        all_valid = n_valid == n * T
+        pos_ids = pos_ids.reshape(-1)
 
         E, nh, hd = a.v_hidden, a.v_heads, a.v_head_dim
         cols = ops.im2col_patches(pv, P, w.patch_ld)
@@ -255,11 +270,15 @@ class Idefics2Engine:
             image_hidden_states = self.encode_images(pixel_values, pixel_attention_mask)
         h = ops.embed_gather(ids, w.embed, None, w.embed.shape[0]).view(M, H)
         if image_hidden_states is not None:
-            slots = (ids.view(-1) == a.image_token_id).nonzero().view(-1).contiguous()
-            img = image_hidden_states.reshape(-1, H)
-            if slots.numel() != img.shape[0]:
-                raise ValueError(f"{slots.numel()} <image> tokens in input_ids but {img.shape[0]} image hidden states")
-            ops.scatter_rows_(h, slots, img.contiguous())
+            # inputs_merger on the device: rank of every <image> token + row copy (no nonzero(), no host round trip); the token
+            # count is validated against the rows at hand once per distinct input_ids tensor
+            img = image_hidden_states.reshape(-1, H).contiguous()
+            count = frontend.merge_image_rows_(h, ids, img, a.image_token_id)
+            n_tok = self._flags.get(input_ids)
+            if n_tok is None:
+                n_tok = self._flags.put(int(count), input_ids)
+            if n_tok != img.shape[0]:
+                raise ValueError(f"{n_tok} <image> tokens in input_ids but {img.shape[0]} image hidden states")
         key_valid = attention_mask.to(device=dev, dtype=torch.int32).contiguous()
         if position_ids is None:                        # plain forward: arange (MistralModel.forward); generate passes mask-derived ids
             pos = torch.arange(past, Sk, device=dev, dtype=torch.int64).repeat(B).contiguous()

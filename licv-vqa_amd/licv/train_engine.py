@@ -61,15 +61,18 @@ class StudentPass:
 
     # ------------------------------------------------------------------ forward
     def forward(self, input_ids, attention_mask, pixel_values, image_attention_mask, icv: torch.Tensor,
-                hook_layers: Sequence[int], alpha: Optional[torch.Tensor], logits_rows: torch.Tensor):
+                hook_layers: Sequence[int], alpha: Optional[torch.Tensor], logits_rows: torch.Tensor,
+                image_states: Optional[torch.Tensor] = None):
         """icv (1,n,H) fp32 and alpha (1,n) fp32 as in IdeficsEngine.forward; logits only for `logits_rows`
-        (flat b*S+t indices of the answer tokens).  Returns (logits_rows (R, V) bf16 view, saved state)."""
+        (flat b*S+t indices of the answer tokens).  image_states: precomputed perceiver outputs (licv.feature_cache) instead of
+        pixel_values.  Returns (logits_rows (R, V) bf16 view, saved state)."""
         e, a, w, tw = self.e, self.e.arch, self.e.w, self.tw
         dev = w.device
         B, S = input_ids.shape
         M, H, nh, hd = B * S, a.hidden_size, a.num_heads, a.head_dim
-        with torch.no_grad():
-            image_states = e.encode_images(pixel_values)
+        if image_states is None:
+            with torch.no_grad():
+                image_states = e.encode_images(pixel_values)
         Nk, E = image_states.shape[1], image_states.shape[2]
         img_len = a.image_seq_len
         img_mask = image_attention_mask.to(torch.int32).contiguous()
@@ -240,8 +243,8 @@ class StudentPass2:
             img = e.encode_images(pixel_values, pixel_attention_mask) if pixel_values is not None else None
         h = ops.embed_gather(ids, w.embed, None, w.embed.shape[0]).view(M, H)
         if img is not None:
-            slots = (ids.view(-1) == a.image_token_id).nonzero().view(-1).contiguous()
-            ops.scatter_rows_(h, slots, img.reshape(-1, H).contiguous())
+            from . import frontend
+            frontend.merge_image_rows_(h, ids, img.reshape(-1, H).contiguous(), a.image_token_id)
         key_valid = attention_mask.to(device=dev, dtype=torch.int32).contiguous()
         pos = torch.arange(S, device=dev, dtype=torch.int64).repeat(B).contiguous()
         idx_of = {int(l): i for i, l in enumerate(hook_layers)}

@@ -56,12 +56,62 @@ class ICVTrainer:
             module.global_step = 0
         self.layers = list(module.icv_model.intervention_layers)
         self._kl_sum = torch.zeros((), device=dev)
+        self.vision_cache = None          # licv.feature_cache.VisionFeatureCache (enable_caches)
+        self.teacher_cache = None         # licv.feature_cache.TeacherLogitCache
 
-    def micro_batch(self, query_inputs, inputs, query_x_length, in_context_length):
+    def enable_caches(self, vision_images: int = 0, teacher_rows: int = 0):
+        """Reuse of ICV-independent work across steps: perceiver outputs per image id and teacher answer-row
+        logits per (query, shots) key.  Callers then pass `image_ids` / `teacher_keys` (host-side ids the dataset already has) to
+        micro_batch / loss_and_backward; without them nothing is cached.  Idefics engine only (Idefics2 images are ragged)."""
+        from .feature_cache import TeacherLogitCache, VisionFeatureCache
+        eng = self.m.interface.engine
+        if vision_images:
+            assert type(eng).__name__ == "IdeficsEngine", "the vision-feature cache covers the Idefics engine"
+            self.vision_cache = VisionFeatureCache(eng, vision_images)
+        if teacher_rows:
+            self.teacher_cache = TeacherLogitCache(teacher_rows)
+        return self
+
+    def _teacher_answer_logits(self, t, in_context_length, image_ids, teacher_keys):
+        """Teacher logits of the answer rows, (n_rows, V) bf16 in batch order; through the caches when ids/keys are given."""
+        m, eng = self.m, self.m.interface.engine
+        dev = eng.w.device
+        B, S = t["input_ids"].shape
+        mask = m.get_mask(t, in_context_length.to(dev))
+
+        def run(sub, ids_sub):                                      # sub: question indices to compute, None = the whole batch
+            msk = mask if sub is None else mask[sub]
+            rows = msk.reshape(-1).nonzero().squeeze(1)
+            kw = dict(t) if sub is None else {k: v[sub] for k, v in t.items()}
+            if self.vision_cache is not None and ids_sub is not None:
+                kw["image_states"] = self.vision_cache.encode(kw.pop("pixel_values"), ids_sub)
+            with torch.no_grad():
+                return eng.forward(**kw, logits_rows=rows), msk.sum(1)
+
+        ids_t = image_ids.get("inputs") if image_ids else None
+        if self.teacher_cache is None or teacher_keys is None:
+            out, _ = run(None, ids_t)
+            return out
+        got, miss = self.teacher_cache.lookup(teacher_keys)
+        if miss:
+            sub = None if len(miss) == B else torch.tensor(miss, device=dev)
+            out, per_q = run(sub, [ids_t[i] for i in miss] if ids_t is not None else None)
+            ends = per_q.cumsum(0).tolist()                          # host read of B ints: only on a cache miss
+            start = 0
+            for j, i in enumerate(miss):
+                got[i] = out[start:ends[j]]
+                self.teacher_cache.insert(teacher_keys[i], got[i])
+                start = ends[j]
+        return torch.cat([g if g.stride(1) == 1 else g.contiguous() for g in got], 0)
+
+    def micro_batch(self, query_inputs, inputs, query_x_length, in_context_length, image_ids=None, teacher_keys=None):
         """One micro-batch of the accumulation window (= the reference's training_step, ref:icv_src/icv_module.py:160-169: the
-        temperature decay check runs first); returns the step's log dict when it closes the window."""
+        temperature decay check runs first); returns the step's log dict when it closes the window.
+        image_ids: {"query_inputs": B lists of image ids, "inputs": B lists of image ids}; teacher_keys: B hashable (query, shots)
+        keys — both optional, see enable_caches."""
         self.m.decay_temperature()
-        kl = self.loss_and_backward(query_inputs, inputs, query_x_length, in_context_length, upstream=1.0 / self.accum)
+        kl = self.loss_and_backward(query_inputs, inputs, query_x_length, in_context_length, upstream=1.0 / self.accum,
+                                    image_ids=image_ids, teacher_keys=teacher_keys)
         self._kl_sum += kl.detach() / self.accum
         self.micro += 1
         if self.micro % self.accum == 0:
@@ -69,20 +119,22 @@ class ICVTrainer:
         return None
 
     # ---- teacher rows, student rows, KL value, backward into the encoder's .grad (accumulating)
-    def loss_and_backward(self, query_inputs, inputs, query_x_length, in_context_length, upstream: float = 1.0):
+    def loss_and_backward(self, query_inputs, inputs, query_x_length, in_context_length, upstream: float = 1.0,
+                          image_ids=None, teacher_keys=None):
         m = self.m
         iface, eng = m.interface, m.interface.engine
         dev = eng.w.device
         q = {k: v.to(dev) for k, v in query_inputs.items() if k != "labels"}
         t = {k: v.to(dev) for k, v in inputs.items() if k != "labels"}
         s_rows = m.get_mask(q, query_x_length.to(dev)).reshape(-1).nonzero().squeeze(1)
-        t_rows = m.get_mask(t, in_context_length.to(dev)).reshape(-1).nonzero().squeeze(1)
-        assert s_rows.numel() == t_rows.numel(), "student and teacher must mask the same number of answer tokens"
+        stu_kw = dict(q)
+        if self.vision_cache is not None and image_ids and image_ids.get("query_inputs") is not None:
+            stu_kw["image_states"] = self.vision_cache.encode(q["pixel_values"], image_ids["query_inputs"])
         enc_out = m.icv_encoder()
         if self.only_hard:
             from lmm_icl_interface.interface import ce_rows_and_labels
             ce_rows, ce_tok = ce_rows_and_labels(q["input_ids"], q["attention_mask"][:, 1:] != 0)
-            stu, st = self.student.forward(**q, icv=enc_out.in_context_vector, hook_layers=self.layers, alpha=enc_out.alpha,
+            stu, st = self.student.forward(**stu_kw, icv=enc_out.in_context_vector, hook_layers=self.layers, alpha=enc_out.alpha,
                                            logits_rows=ce_rows)
             V = eng.w.lm_head.shape[0]
             stu2 = stu if stu.stride(1) == 1 else stu.contiguous()
@@ -93,8 +145,8 @@ class ICVTrainer:
             grad_v = self.student.backward(st, full)
             (enc_out.alpha.unsqueeze(dim=-1) * enc_out.in_context_vector).backward(grad_v)
             return ce
-        with torch.no_grad():
-            tea = eng.forward(**t, logits_rows=t_rows)          # Idefics: image_attention_mask; Idefics2: pixel_attention_mask
+        tea = self._teacher_answer_logits(t, in_context_length, image_ids, teacher_keys)    # (n_rows, V): no ICV dependence
+        assert s_rows.numel() == tea.shape[0], "student and teacher must mask the same number of answer tokens"
         n_kl = s_rows.numel()
         idx_t = torch.arange(n_kl, device=dev)
         if self.hard_w:
@@ -107,7 +159,7 @@ class ICVTrainer:
             idx_kl, idx_ce = torch.searchsorted(rows_all, s_rows), torch.searchsorted(rows_all, ce_rows)
         else:
             rows_all, idx_kl = s_rows, idx_t
-        stu, st = self.student.forward(**q, icv=enc_out.in_context_vector, hook_layers=self.layers, alpha=enc_out.alpha,
+        stu, st = self.student.forward(**stu_kw, icv=enc_out.in_context_vector, hook_layers=self.layers, alpha=enc_out.alpha,
                                        logits_rows=rows_all)
         V = eng.w.lm_head.shape[0]
         T, eps = float(m.temperature), float(m.module_cfg.kl_eps)

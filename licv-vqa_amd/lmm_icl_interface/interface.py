@@ -100,6 +100,19 @@ class IdeficsInterface(LMMInterface):
         self.tokenizer = tokenizer if tokenizer is not None else types.SimpleNamespace(
             pad_token_id=arch.pad_token_id, bos_token_id=arch.bos_token_id, eos_token_id=arch.eos_token_id, padding_side="right")
         self.processor = processor
+        # `<image>` id for the device-side image_attention_mask builder: from the tokenizer when it knows the token, else the second
+        # additional-vocabulary slot (where the released checkpoints put it)
+        conv = getattr(self.tokenizer, "convert_tokens_to_ids", None)
+        self.image_token_id = conv("<image>") if conv is not None else arch.vocab_size + (1 if arch.additional_vocab_size > 1 else 0)
+
+    def _image_mask(self, input_ids, pixel_values, image_attention_mask):
+        """image_attention_mask as processor.prepare_input builds it (hf:idefics/processing_idefics.py:89-133) when the caller
+        did not pass one: from input_ids, on the device (licv.frontend, csrc/frontend.hip)."""
+        if image_attention_mask is not None:
+            return image_attention_mask.to(self._device)
+        from licv import frontend
+        return frontend.idefics_image_attention_mask(input_ids.to(self._device), self.image_token_id,
+                                                     getattr(self.tokenizer, "eos_token_id", self.arch.eos_token_id), pixel_values.shape[1])
 
     @staticmethod
     def _load_checkpoint(path: Path, tokenizer, processor, arch_cls=IdeficsArch):
@@ -154,8 +167,8 @@ class IdeficsInterface(LMMInterface):
     def forward(self, input_ids=None, attention_mask=None, pixel_values=None, image_attention_mask=None, labels=None,
                 logits_rows=None, **_):
         dev = self._device
-        logits = self._run_lmm(dict(input_ids=input_ids.to(dev), attention_mask=attention_mask.to(dev),
-                                    pixel_values=pixel_values.to(dev), image_attention_mask=image_attention_mask.to(dev)), logits_rows)
+        logits = self._run_lmm(dict(input_ids=input_ids.to(dev), attention_mask=attention_mask.to(dev), pixel_values=pixel_values.to(dev),
+                                    image_attention_mask=self._image_mask(input_ids, pixel_values, image_attention_mask)), logits_rows)
         out = LMMOutput(logits=logits)
         if labels is not None:
             # shift-by-one CE with pads masked by attention_mask: transformers 4.38.2 Idefics behaviour
@@ -170,7 +183,7 @@ class IdeficsInterface(LMMInterface):
         if do_sample:
             raise NotImplementedError("sampling is not part of the reference's inference path")
         return native_generate(self.engine, input_ids.to(self._device), attention_mask.to(self._device),
-                               pixel_values.to(self._device), image_attention_mask.to(self._device),
+                               pixel_values.to(self._device), self._image_mask(input_ids, pixel_values, image_attention_mask),
                                max_new_tokens=max_new_tokens, num_beams=num_beams, length_penalty=length_penalty,
                                min_new_tokens=min_new_tokens, early_stopping=early_stopping,
                                eos_token_id=eos_token_id if eos_token_id is not None else getattr(self.tokenizer, "eos_token_id", None),

@@ -346,3 +346,30 @@ def test_oracle_bf16_decode_equals_reference_bf16_generate(golden, model):
                         greedy_off=gen(sd, arch, **cb, num_beams=1, **kw))
         for tag, got in outs.items():
             assert torch.equal(got, T(z[f"{side}_bf16_{tag}_ids"])), f"{model} {side} {tag}"
+
+
+def test_oracle_frontend_rules_match_hf_fixture(golden):
+    """g13: transformers' own image_attention_mask functions and the patch mask / NaViT position ids captured inside HF Idefics2."""
+    import torch
+    from oracle import frontend_ref as F
+    from oracle import idefics2_ref as R2
+    T = torch.from_numpy
+    z = golden("g13_frontend")
+    for tag in "abcd":
+        img, eod, n = (int(v) for v in z[f"m_{tag}_cfg"])
+        got = F.image_attention_mask(T(z[f"m_{tag}_ids"]), img, eod, n)
+        assert torch.equal(got, T(z[f"m_{tag}_mask"]).long()), tag
+    for tag, patch, n_side in (("tiny", 14, 4), ("mid", 14, 6)):
+        pv, pam = T(z[f"v_{tag}_pixel_values"]), T(z[f"v_{tag}_pixel_attention_mask"])
+        B, N = pv.shape[:2]
+        pvf = pv.reshape(B * N, *pv.shape[2:]).to(torch.bfloat16)
+        real = (pvf == 0.0).sum(dim=(-1, -2, -3)) != pvf.shape[1:].numel()
+        assert int(real.sum()) == int(z[f"v_{tag}_n_real"])
+        pm = R2.patch_mask_from_pixels(pam.reshape(B * N, *pam.shape[2:])[real], patch)
+        assert torch.equal(pm, T(z[f"v_{tag}_patch_mask"]))
+        fh, fw, bounds = R2.navit_position_ids(pm, n_side)
+        bh = torch.bucketize(fh.to(torch.bfloat16), bounds, right=True)
+        bw = torch.bucketize(fw.to(torch.bfloat16), bounds, right=True)
+        pos = (bh[:, :, None] * n_side + bw[:, None, :]).reshape(pm.shape[0], -1)
+        pos = torch.where(pm.view(pm.shape[0], -1), pos, torch.zeros_like(pos))
+        assert torch.equal(pos, T(z[f"v_{tag}_position_ids"]))

@@ -433,15 +433,15 @@ def g8_generate_idefics2():
     np.savez_compressed(OUT / "g8_generate_idefics2.npz", **out)
 
 
-JITTER_SIGMA, JITTER_TRIALS = 0.01, 12
+JITTER_SIGMA, JITTER_TRIALS = 0.02, 16
 
 
 def _gen_with_margins(w, icv, batch, num_beams, prompt_len, n_rows):
     """Reference generate (through the reference's wrapper, its own call shape: ref:inference.py:313,
     ref:config/inference.yaml:26-30) returning the ids plus, per row, how ROBUST that decode is to bf16-level noise:
     the same reference call is repeated JITTER_TRIALS times with N(0, JITTER_SIGMA) added to the next-token scores of every
-    step (a transformers LogitsProcessor; sigma = 0.01: the reference's own bf16-vs-fp32 logit difference on these
-    models is 0.0075 RMS / 0.027 max at |logit| <= 6.3, i.e. about one bf16 ulp) and the
+    step (a transformers LogitsProcessor; sigma = 0.02: the reference's own bf16-vs-fp32 logit difference on these
+    models is 0.0075 RMS / 0.027 max at |logit| <= 6.3 — one to two bf16 ulp — so 0.02 per score covers its tail) and the
     fraction of trials that reproduce the row's ids is stored.  A row with stability 1.0 is decided by more than bf16
     noise — every candidate comparison of the search, not only the final one — and an implementation computing in bf16
     must reproduce it exactly; rows below 1.0 are the reference's own near-ties."""
@@ -542,6 +542,75 @@ def g12_generate_idefics2_bf16():
             out[f"{pad_side}_bf16_{tag}_ids"] = ids.numpy()
             out[f"{pad_side}_bf16_{tag}_stability"] = mg.numpy()
     np.savez_compressed(OUT / "g12_generate_idefics2_bf16.npz", **out)
+
+
+def g13_frontend():
+    """Processor-side integer rules, produced by the HF code itself:
+    (a) Idefics image_attention_mask: transformers' image_attention_mask_for_packed_input_ids_pt + incremental_to_binary_attention_mask
+        on random id rows with <image> / end-of-document tokens (incl. more images than mask columns, leading text, EOD runs);
+    (b) Idefics2: the patch_attention_mask Idefics2Model.forward derives, which images it drops as padding, and the NaViT
+        position ids Idefics2VisionEmbeddings feeds its position table — captured with forward hooks on a tiny HF model (bf16), and
+        on a stand-alone embeddings module at the full 980 x 980 / 70 x 70 grid."""
+    import types as _t
+    from transformers.models.idefics.processing_idefics import (image_attention_mask_for_packed_input_ids_pt,
+                                                                incremental_to_binary_attention_mask)
+    out = {}
+    g = torch.Generator().manual_seed(1301)
+    IMG, EOD = 11, 2
+    tok = _t.SimpleNamespace(convert_tokens_to_ids=lambda t: IMG, eos_token_id=EOD)
+    for tag, (B, S, hi, n_cls) in dict(a=(6, 150, 14, 5), b=(3, 64, 40, 3), c=(2, 1, 12, 2), d=(4, 333, 13, 33)).items():
+        ids = torch.randint(0, hi, (B, S), generator=g)
+        ids[0, : min(S, 9)] = 5                                  # a row that starts with text only
+        if S > 40:
+            ids[1, 20:30] = EOD                                   # a run of end-of-document tokens
+        inc, _ = image_attention_mask_for_packed_input_ids_pt(ids.clone(), tok)
+        mask = incremental_to_binary_attention_mask(inc, "pt", num_classes=n_cls)
+        out[f"m_{tag}_ids"], out[f"m_{tag}_mask"], out[f"m_{tag}_cfg"] = ids.numpy(), mask.numpy().astype(np.int8), np.array([IMG, EOD, n_cls])
+    # (b) tiny HF Idefics2 with ragged images and one all-zero padding image
+    for tag, arch, hw in (("tiny", IDEFICS2_TINY, (56, 42)), ("mid", IDEFICS2_MID, (84, 70))):
+        sd = synth_idefics2_weights(arch, seed=1302, dtype=torch.float32)
+        model = hf_idefics2(arch, sd, torch.bfloat16)
+        batch = synth_vqa_batch_idefics2(arch, 3, 40 if tag == "tiny" else 60, 2, hw[0], hw[1], seed=1303, min_len=30 if tag == "tiny" else 50,
+                                         dtype=torch.float32, drop_last_image_of_row0=True)
+        cap = {}
+        emb = model.model.vision_model.embeddings
+        def grab_pos(m, a):
+            cap["pos"] = a[0].clone()
+
+        def grab_mask(m, a, kw):
+            cap["pam"], cap["n"] = kw["patch_attention_mask"].clone(), kw["pixel_values"].shape[0]
+        h1 = emb.position_embedding.register_forward_pre_hook(grab_pos)
+        h2 = model.model.vision_model.register_forward_pre_hook(grab_mask, with_kwargs=True)
+        with torch.inference_mode(), torch.autocast("cpu", dtype=torch.bfloat16):
+            model(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], pixel_values=batch["pixel_values"].to(torch.bfloat16),
+                  pixel_attention_mask=batch["pixel_attention_mask"])
+        h1.remove(); h2.remove()
+        out[f"v_{tag}_pixel_values"] = np_(batch["pixel_values"])
+        out[f"v_{tag}_pixel_attention_mask"] = batch["pixel_attention_mask"].numpy()
+        out[f"v_{tag}_patch_mask"] = cap["pam"].numpy()
+        out[f"v_{tag}_position_ids"] = cap["pos"].numpy()
+        out[f"v_{tag}_n_real"] = np.array(cap["n"])
+    # full-size grid: the embeddings module alone (hidden 16), 980 x 980 canvas, three ragged images
+    from transformers.models.idefics2.configuration_idefics2 import Idefics2VisionConfig
+    from transformers.models.idefics2.modeling_idefics2 import Idefics2VisionEmbeddings
+    vc = Idefics2VisionConfig(hidden_size=16, image_size=980, patch_size=14, num_hidden_layers=1, num_attention_heads=1, intermediate_size=16)
+    emb = Idefics2VisionEmbeddings(vc).to(torch.bfloat16).eval()
+    sizes = [(980, 980), (378, 504), (14, 966), (700, 28)]
+    pam = torch.zeros(len(sizes), 980, 980, dtype=torch.bool)
+    for i, (hh, ww) in enumerate(sizes):
+        pam[i, :hh, :ww] = True
+    sub = pam.unfold(1, 14, 14).unfold(2, 14, 14)
+    patch_mask = (sub.sum(dim=(-1, -2)) == 14 * 14).bool()
+    cap = {}
+    def grab_full(m, a):
+        cap["pos"] = a[0].clone()
+    h1 = emb.position_embedding.register_forward_pre_hook(grab_full)
+    with torch.inference_mode():
+        emb(torch.zeros(len(sizes), 3, 980, 980, dtype=torch.bfloat16), patch_mask)
+    h1.remove()
+    out["v_full_sizes"] = np.array(sizes)
+    out["v_full_position_ids"] = cap["pos"].numpy().astype(np.int16)
+    np.savez_compressed(OUT / "g13_frontend.npz", **out)
 
 
 def g6_loss():
@@ -763,9 +832,9 @@ def main():
     import icv_src.icv_model.icv_intervention as _ri
     assert _ri.__file__.startswith(str(REF)), _ri.__file__
     torch.set_num_threads(4)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
     fns = dict(g1=g1_encoder, g2=g2_intervention, g3=g3_idefics, g4=g4_idefics2, g5=g5_generate, g6=g6_loss, g7=g7_optim, g8=g8_generate_idefics2, g9=g9_loss_idefics2, g10=g10_hard_loss,
-               g11=g11_generate_bf16, g12=g12_generate_idefics2_bf16)
+               g11=g11_generate_bf16, g12=g12_generate_idefics2_bf16, g13=g13_frontend)
     for w in which:
         print("generating", w, flush=True)
         fns[w]()
