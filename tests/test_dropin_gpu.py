@@ -159,3 +159,27 @@ def test_module_forward_kl_matches_reference_forward(golden, temp):
     assert abs(got - kl32) <= 1.5 * abs(kl16 - kl32) + 0.05 * kl32, (got, kl16, kl32)
     assert set(loss_dict) == {"kl_loss", "loss"} and float(loss_dict["loss"]) == got
     assert enc.in_context_vector is mod.icv_encoder.icv
+
+
+def test_interface_from_checkpoint_directory_and_real_checkpoint_script(tmp_path, capsys):
+    """``IdeficsInterface(model_name_or_path=<dir>)`` (ref:utils.py:41-50) on a tiny save_pretrained directory: the engine built
+    from the directory gives the same logits, bit for bit, as the one built from the state dict; tools/check_checkpoint.py (the
+    real-checkpoint parity run) passes on it."""
+    pytest.importorskip("transformers")
+    import sys
+    from pathlib import Path
+    from lmm_icl_interface import IdeficsInterface
+    from licv.synthetic import synth_vqa_batch
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    from test_checkpoint_load import _save_idefics
+    arch = IDEFICS_TINY
+    sd = synth_idefics_weights(arch, seed=9, dtype=torch.float32)
+    _save_idefics(tmp_path, arch, sd)
+    a = IdeficsInterface(str(tmp_path), "bf16", DEV)
+    b = IdeficsInterface(state_dict=sd, arch=arch, device=DEV)
+    batch = {k: v.to(DEV) for k, v in synth_vqa_batch(arch, 2, 20, 2, seed=10, min_len=16, dtype=torch.bfloat16).items()}
+    assert torch.equal(a(**batch)["logits"], b(**batch)["logits"])
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "tools"))
+    import check_checkpoint
+    assert check_checkpoint.main([str(tmp_path), "--fp32", "--batch", "2"]) == 0
+    assert "PARITY OK" in capsys.readouterr().out

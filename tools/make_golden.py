@@ -613,6 +613,59 @@ def g13_frontend():
     np.savez_compressed(OUT / "g13_frontend.npz", **out)
 
 
+def g14_vqa_metric():
+    """VQA accuracy scoring: the reference's own evaluator (icv_src/metrics/vqa_metric.py imports with the
+    standard library alone) on a corpus of answer strings — every key of its contraction / number-word tables, punctuation and
+    digit cases — and on synthetic annotation / question / result files."""
+    import contextlib as _c
+    import importlib.util
+    import io
+    import json as _json
+    import tempfile
+    spec = importlib.util.spec_from_file_location("ref_vqa_metric", REF / "icv_src" / "metrics" / "vqa_metric.py")
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    ev = ref.VQAEval(None, None)
+    corpus = sorted(ev.contractions) + sorted(set(ev.contractions.values())) + list(ev.manualMap) + list(ev.articles)
+    corpus += ["Yes.", "no!", "a red bus", "The  Two dogs", "1,000", "3.5", "it's 2,5 meters, ok", "U.S.A.", "dont know; maybe", "left/right",
+               "x - y", "hello , world", "tennis racket?", "An apple (green)", "e.g. this", "....", "a.b.c.d.e.f.g.h.i.j.k.l.m.n.o.p.q.r.s.t.u.v.w.x.y.z.a.b.c.d.e.f.g.h.i",
+               "couldntve done it", "Shes here", "lets go", "somebody'd know", "10", "ten", "None", "\tspaced\n out ", "a", "", "#1 player @home", "50% off"]
+    g = torch.Generator().manual_seed(1401)
+    vocab = ["yes", "no", "2", "two", "red", "a red", "the bus", "bus.", "dont", "don't", "tennis", "Tennis racket", "racket,", "1,000", "left", "right"]
+    corpus += [" ".join(vocab[int(i)] for i in torch.randint(0, len(vocab), (int(torch.randint(1, 4, (1,), generator=g)),), generator=g)) for _ in range(60)]
+    out = {"corpus": np.array(corpus)}
+    out["punct"] = np.array([ev.processPunctuation(t.replace("\n", " ").replace("\t", " ").strip()) for t in corpus])
+    out["full"] = np.array([ev.processDigitArticle(ev.processPunctuation(t.replace("\n", " ").replace("\t", " ").strip())) for t in corpus])
+    gens = ["cat Question: what", "two, maybe three Answer: x", "Short answer: blue", " red\nQuestion", "a dog", "yes, it is", ""]
+    out["gen_in"] = np.array(gens)
+    out["gen_out"] = np.array([ref.postprocess_vqa_generation(t) for t in gens])
+    # synthetic files: 40 questions, 10 human answers each, 3 question types, answer types incl. a missing one
+    anns, ques, res = [], [], []
+    for q in range(40):
+        humans = [vocab[int(i)] for i in torch.randint(0, len(vocab), (10,), generator=g)]
+        a = dict(question_id=1000 + q, image_id=q // 3, question_type=["what", "is the", "how many"][q % 3],
+                 multiple_choice_answer=humans[0],
+                 answers=[dict(answer=h, answer_confidence="yes", answer_id=i + 1) for i, h in enumerate(humans)])
+        if q % 5:
+            a["answer_type"] = ["yes/no", "number", "other"][q % 3]
+        anns.append(a)
+        ques.append(dict(question_id=1000 + q, image_id=q // 3, question="synthetic?"))
+        res.append(dict(question_id=1000 + q, answer=vocab[int(torch.randint(0, len(vocab), (1,), generator=g))] if q % 7 else humans[2] + "!"))
+    meta = dict(info={}, task_type="Open-Ended", data_type="mscoco", data_subtype="val", license={})
+    files = dict(ann=dict(meta, annotations=anns), que=dict(meta, questions=ques), res=res)
+    with tempfile.TemporaryDirectory() as d:
+        paths = {}
+        for k, v in files.items():
+            paths[k] = str(Path(d) / f"{k}.json")
+            _json.dump(v, open(paths[k], "w"))
+        with _c.redirect_stdout(io.StringIO()):
+            acc = ref.compute_vqa_accuracy(paths["res"], paths["que"], paths["ann"])
+    for k, v in files.items():
+        out[f"file_{k}"] = np.array(_json.dumps(v))
+    out["accuracy"] = np.array(_json.dumps(acc))
+    np.savez_compressed(OUT / "g14_vqa_metric.npz", **out)
+
+
 def g6_loss():
     """The reference's VQAICVModule.forward (student hooked + teacher plain + KL) and its grads."""
     from icv_src.icv_encoder.global_icv_encoder import GlobalICVEncoder
@@ -832,9 +885,9 @@ def main():
     import icv_src.icv_model.icv_intervention as _ri
     assert _ri.__file__.startswith(str(REF)), _ri.__file__
     torch.set_num_threads(4)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
     fns = dict(g1=g1_encoder, g2=g2_intervention, g3=g3_idefics, g4=g4_idefics2, g5=g5_generate, g6=g6_loss, g7=g7_optim, g8=g8_generate_idefics2, g9=g9_loss_idefics2, g10=g10_hard_loss,
-               g11=g11_generate_bf16, g12=g12_generate_idefics2_bf16, g13=g13_frontend)
+               g11=g11_generate_bf16, g12=g12_generate_idefics2_bf16, g13=g13_frontend, g14=g14_vqa_metric)
     for w in which:
         print("generating", w, flush=True)
         fns[w]()
