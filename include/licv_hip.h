@@ -108,6 +108,9 @@ int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void*
  * to its own slice of a caller-provided workspace (no atomics: bit-reproducible), a second kernel sums the slices in order and
  * applies the epilogue.  licv_gemm_splitk_plan returns splits <= 1 when the plain kernel should be used. */
 int licv_gemm_splitk_plan(int64_t M, int64_t N, int64_t K, int* splits, int64_t* workspace_bytes);
+/* workspace bytes licv_gemm_bf16_splitk wants for (M, N, K); 0 = the one-pass kernels serve the shape; < 0 = bad arguments.
+ * (SURVEY.md §8b "licv_workspace_size": the library allocates no device memory — every buffer, this one included, is the caller's.) */
+int64_t licv_workspace_size(int64_t M, int64_t N, int64_t K);
 int licv_gemm_bf16_splitk(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
                           int64_t M, int64_t N, int64_t K, const licv_gemm_epilogue* e, int splits,
                           void* workspace, int64_t workspace_bytes, void* stream);

@@ -390,7 +390,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmEpi& ep, void* __restric
 // SwiGLU pairing / row gate / tanh-gate scale / residual on the bf16 values (exactly where the unfused torch
 // ops would round) and stores bf16 or fp32.
 // ------------------------------------------------------------------------------------------------
-// timing-only instrumentation (scratch/gemm_phases.py): when set, wave 0 of every pingpong workgroup records
+// timing-only instrumentation (tools/gemm_phases.py): when set, wave 0 of every pingpong workgroup records
 // wall_clock64() at [0] start, [1] stage 0 published, [2] main loop done, [3] output image in LDS, [4] end
 __device__ long long* g_dbg_ts = nullptr;
 extern "C" int licv_gemm_debug_timestamps(void* dev_buffer) {
@@ -1572,7 +1572,7 @@ extern "C" int licv_gemm_splitk_plan(int64_t M, int64_t N, int64_t K, int* split
         }
         return LICV_OK;
     }
-    // measured (scratch/gemm_skinny.py): worth it from K ~ 8192 up (K = 11008: 132 -> 69 us at M = 256); at K = 4096 the extra
+    // measured (round 1): worth it from K ~ 8192 up (K = 11008: 132 -> 69 us at M = 256); at K = 4096 the extra
     // fp32 round trip through the workspace and the second launch cancel the gain
     if (M <= 0 || M > 256 || K < 8192 || K % 8 != 0 || N < 128) return LICV_OK;
     const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
@@ -1584,6 +1584,14 @@ extern "C" int licv_gemm_splitk_plan(int64_t M, int64_t N, int64_t K, int* split
     *splits = (int)sp;
     *workspace_bytes = sp * ((M + 127) / 128 * 128) * ((N + 127) / 128 * 128) * 4;
     return LICV_OK;
+}
+
+// bytes of caller-provided scratch licv_gemm_bf16_splitk needs for (M, N, K): 0 when the one-pass kernels are used.  The library
+// itself never allocates device memory; this is the only operator that wants a workspace, and the caller owns it.
+extern "C" int64_t licv_workspace_size(int64_t M, int64_t N, int64_t K) {
+    int sp = 1; int64_t nb = 0;
+    if (licv_gemm_splitk_plan(M, N, K, &sp, &nb) != LICV_OK) return -1;
+    return sp > 1 ? nb : 0;
 }
 
 extern "C" int licv_gemm_bf16_splitk(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,

@@ -57,6 +57,8 @@ def lib() -> C.CDLL:
         _lib.licv_last_error.restype = C.c_char_p
         _lib.licv_version.restype = C.c_int
         _lib.licv_inject_bwd_partials.restype = C.c_int64
+        _lib.licv_workspace_size.restype = C.c_int64
+        _lib.licv_workspace_size.argtypes = [C.c_int64, C.c_int64, C.c_int64]
         _lib.licv_inject_bwd_partials.argtypes = [C.c_int64]
         P, I64, F, I = C.c_void_p, C.c_int64, C.c_float, C.c_int
         sig = {

@@ -117,8 +117,8 @@ def test_fullsize_idefics2_properties():
     assert float((off.float() - lg.float()).abs().max()) > 1e-3 * scale                              # P6
     # P2.  A single question has 172 text rows and 128 latent rows, so its K >= 8192 GEMMs (perceiver and text down-projections)
     # take the split-K path, whose fp32 partial sums are added in a different order than the one-pass kernel the batch of 8 uses.
-    # Kernel level that is 6e-5 relative (a few outputs flip one bf16 ulp: scratch/splitk_check.py); this random-weight model
-    # amplifies it to 0.9 % after the connector + first layer and 3.7 % at the logits (scratch/splitk_div.py).  So: bit-exact
+    # Kernel level that is 6e-5 relative (a few outputs flip one bf16 ulp, measured in round 1); this random-weight model
+    # amplifies it to 0.9 % after the connector + first layer and 3.7 % at the logits.  So: bit-exact
     # with the split-K path off, within the model's own bf16 noise floor with it on.
     from licv import ops
     for b in (0, 3):
