@@ -433,18 +433,17 @@ def g8_generate_idefics2():
     np.savez_compressed(OUT / "g8_generate_idefics2.npz", **out)
 
 
-JITTER_SIGMA, JITTER_TRIALS = 0.02, 16
+JITTER_TRIALS = 24
 
 
 def _gen_with_margins(w, icv, batch, num_beams, prompt_len, n_rows):
     """Reference generate (through the reference's wrapper, its own call shape: ref:inference.py:313,
     ref:config/inference.yaml:26-30) returning the ids plus, per row, how ROBUST that decode is to bf16-level noise:
-    the same reference call is repeated JITTER_TRIALS times with N(0, JITTER_SIGMA) added to the next-token scores of every
-    step (a transformers LogitsProcessor; sigma = 0.02: the reference's own bf16-vs-fp32 logit difference on these
-    models is 0.0075 RMS / 0.027 max at |logit| <= 6.3 — one to two bf16 ulp — so 0.02 per score covers its tail) and the
-    fraction of trials that reproduce the row's ids is stored.  A row with stability 1.0 is decided by more than bf16
-    noise — every candidate comparison of the search, not only the final one — and an implementation computing in bf16
-    must reproduce it exactly; rows below 1.0 are the reference's own near-ties."""
+    the same reference call is repeated JITTER_TRIALS times with every next-token score moved by -1, 0 or +1 bf16 ulp of its own
+    magnitude at random (a transformers LogitsProcessor) and the fraction of trials that reproduce the row's ids is stored.
+    Two bf16 implementations of the same model differ by one ulp on a few logits per step (measured: the native engine vs this
+    reference, max 1 ulp), so a row with stability 1.0 — no candidate comparison of the search sits within two ulp — must be
+    reproduced exactly; rows below 1.0 are the reference's own near-ties (bf16 logits tie EXACTLY on several rows)."""
     from transformers import LogitsProcessor, LogitsProcessorList
 
     class Jitter(LogitsProcessor):
@@ -452,7 +451,10 @@ def _gen_with_margins(w, icv, batch, num_beams, prompt_len, n_rows):
             self.g = torch.Generator().manual_seed(seed)
 
         def __call__(self, input_ids, scores):
-            return scores + JITTER_SIGMA * torch.randn(scores.shape, generator=self.g).to(scores.dtype)
+            x = scores.float()
+            ulp = torch.exp2(torch.floor(torch.log2(x.abs().clamp_min(1e-20))) - 7)
+            step = torch.randint(-1, 2, x.shape, generator=self.g).float()
+            return (x + step * ulp).to(scores.dtype)
 
     plain = dict(max_new_tokens=5, do_sample=False)
     if num_beams > 1:
