@@ -222,6 +222,44 @@ int licv_kl_rows_bwd(const void* stu_logits, const void* tea_logits, int dtype, 
                      int64_t n_rows, int64_t vocab, int64_t ld_stu, int64_t ld_tea, float temperature, float eps, float upstream,
                      const float* upstream_dev, void* grad_rows_bf16, int64_t ld_grad, void* stream);
 
+/* ---- native layer runner: the Idefics language stack (32 decoder + 8 gated cross-attention layers, hooks, final norm, LM head;
+ * hf:idefics/modeling_idefics.py:1052-1074,1179-1182) given the image states, in ONE call: the same kernels, order and dispatch as
+ * the Python engine loop (bit-identical), issued from C++ so that launch-bound shapes (decode steps of hooked generate,
+ * ref:inference.py:300-321; the 32-token student / prefill) are not paced by the interpreter.  All pointers are device pointers
+ * unless marked HOST; the caller owns every buffer. ---- */
+typedef struct { const void *in_ln, *qkv_w, *o_w, *post_ln, *gu_w, *down_w; } licv_idefics_dec_w;
+typedef struct { const void *in_ln, *q_w, *kv_w, *o_w, *qn_w, *kn_w, *post_ln, *gu_w, *down_w; float gate_attn, gate_dense; } licv_idefics_xattn_w;
+typedef struct {
+    int64_t hidden, inter, n_heads, head_dim, n_layers, cross_interval;
+    int64_t vocab, n_extra_vocab, vocab_total;         /* base vocabulary, additional embeddings, rows of the fused LM head */
+    int64_t img_dim, img_len, rope_len;                /* width of the image states, latents per image, rows of cos/sin */
+    float rms_eps;
+    const void *embed, *embed_extra, *final_ln, *lm_head, *cos, *sin;
+    const licv_idefics_dec_w* dec;                     /* HOST array [n_layers] */
+    const licv_idefics_xattn_w* xat;                   /* HOST array [n_layers / cross_interval] */
+} licv_idefics_text_weights;
+typedef struct {
+    const int64_t* input_ids;                          /* (B, S) */
+    const int32_t* key_valid;                          /* (B, Sk) attention mask over past + new tokens */
+    const int64_t* position_ids;                       /* (B*S) */
+    const void* image_states;                          /* (B, Nk, img_dim) bf16 */
+    const int32_t* img_mask;                           /* (B, S, n_img) */
+    const float* gate;                                 /* (B*S) cross_attention_gate */
+    int64_t B, S, Sk, Nk, n_img;
+    const float* icv;                                  /* (n_hooked, hidden) fp32, or NULL: no intervention */
+    const float* alpha;                                /* (n_hooked) fp32 folded into the hook, or NULL: icv is already scaled */
+    const int32_t* hook_slot;                          /* HOST array [n_layers]: row of icv for that layer's output, -1 = not hooked */
+    void* const* kv_cache;                             /* HOST array [n_layers] of (B, cache_max_len, 2*hidden) bf16, or NULL */
+    int64_t cache_max_len, past;
+    const void* const* xkv_cached;                     /* HOST array [n_x] of projected+normed cross-attention K|V (B, Nk, 2*hidden), or NULL */
+    void* const* xkv_out;                              /* HOST array [n_x]: project INTO these (they become next step's xkv_cached), or NULL */
+    const int64_t* logits_rows; int64_t n_rows;        /* logits only for these flat rows (n_rows = 0: all B*S rows) */
+    void *h16, *h32, *x, *xn, *q, *qkv, *o, *act, *xkv, *xsel;   /* scratch: (M,H) bf16, (M,H) fp32, 3 x (M,H) bf16, (M,3H), (M,H), (M,I), (B*Nk,2H), (n_rows,H) */
+    void* workspace; int64_t workspace_bytes;          /* split-K scratch (licv_workspace_size) */
+    void* logits; int64_t ld_logits;                   /* (rows, ld_logits >= vocab_total) bf16 */
+} licv_idefics_text_call;
+int licv_idefics_text_forward(const licv_idefics_text_weights* w, const licv_idefics_text_call* c, void* stream);
+
 /* ---- device-side front-end: integer rules between the collator / processor and the first GEMM ---- */
 /* Idefics image_attention_mask (B, S, n_images) int32 one-hot rows from input_ids (B, S) int64 by the incremental rule of
  * hf:idefics/processing_idefics.py:89-110 + :66-79 (ref:icv_src/icv_datamodule.py:80-124 gets it from processor.prepare_input). */

@@ -1,0 +1,139 @@
+// Native layer runner for the Idefics language stack (hooked forward given the image states): the same kernels, in the same
+// order and with the same dispatch decisions as licv/idefics_engine.py's Python loop, issued from ONE C-ABI call.
+//
+// Why: a decode step of hooked generate (ref:inference.py:300-321: 3 beams x B rows, one token each) is ~400 kernel launches
+// that stream 18 GB of weights (a ~4 ms floor at HBM rate) but cost ~25 us of interpreter + ctypes + allocator work EACH from
+// Python: 12 ms per step, launch-bound.  From C++ a launch costs ~3-4 us, so the step becomes GPU-bound.  The same holds for
+// the 32-token student / prefill shapes.  Results are bit-identical to the Python loop by construction (tests/test_runner_gpu.py).
+//
+// The caller owns every buffer (weights, inputs, scratch, KV caches, output); nothing is allocated or synchronised here.
+#include "common.h"
+
+#define RUN(call) do { int rc__ = (call); if (rc__ != LICV_OK) return rc__; } while (0)
+
+// cache[b, past + s, :] = qkv[b, s, H : 3H]   (the K|V columns of the fused projection)
+__global__ __launch_bounds__(256)
+void kv_append_k(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ cache, int64_t S, int64_t H, int64_t max_len, int64_t past) {
+    const int64_t row = blockIdx.x;                       // b * S + s
+    const int64_t b = row / S, s = row - b * S;
+    const uint4* src = reinterpret_cast<const uint4*>(qkv + row * 3 * H + H);
+    uint4* dst = reinterpret_cast<uint4*>(cache + (b * max_len + past + s) * 2 * H);
+    for (int64_t i = threadIdx.x; i < 2 * H / 8; i += blockDim.x) dst[i] = src[i];
+}
+
+namespace {
+struct Ctx {
+    const licv_idefics_text_weights* w;
+    const licv_idefics_text_call* c;
+    void* stream;
+    int64_t M, H;
+    void* h; int h_dt;                                    // residual stream: h16 (bf16) until the first hook, h32 (fp32) after
+};
+
+int linear(const Ctx& x, const void* A, int64_t M, const void* W, int64_t N, int64_t K, void* C, int64_t ldc, int out_dt,
+           const void* residual = nullptr, int res_dt = 0, const float* row_gate = nullptr, const float* scale = nullptr, int swiglu = 0) {
+    licv_gemm_epilogue ep;
+    ep.bias_bf16 = nullptr; ep.row_gate = row_gate; ep.residual = residual; ep.residual_dtype = res_dt;
+    ep.ld_res = swiglu ? N / 2 : N; ep.act = 0; ep.swiglu = swiglu; ep.use_scale = scale ? 1 : 0; ep.scale = scale ? *scale : 0.f;
+    ep.out_dtype = out_dt;
+    int splits = 1; int64_t ws = 0;
+    RUN(licv_gemm_splitk_plan(M, N, K, &splits, &ws));    // the same decision licv.ops.linear takes
+    if (splits > 1) {
+        if (ws > x.c->workspace_bytes) return licv_set_error(LICV_E_BADARG, "idefics_text_forward: workspace %lld B < %lld B needed by a %lld x %lld x %lld split-K GEMM",
+                                                             (long long)x.c->workspace_bytes, (long long)ws, (long long)M, (long long)N, (long long)K);
+        return licv_gemm_bf16_splitk(A, K, W, K, C, ldc, M, N, K, &ep, splits, x.c->workspace, x.c->workspace_bytes, x.stream);
+    }
+    return licv_gemm_bf16(A, K, W, K, C, ldc, M, N, K, &ep, x.stream);
+}
+}  // namespace
+
+extern "C" int licv_idefics_text_forward(const licv_idefics_text_weights* w, const licv_idefics_text_call* c, void* stream) {
+    LICV_CHECK_ARG(w && c, "idefics_text_forward: null argument");
+    LICV_CHECK_ARG(w->dec && w->embed && w->final_ln && w->lm_head && w->cos && w->sin, "idefics_text_forward: missing weights");
+    LICV_CHECK_ARG(c->input_ids && c->key_valid && c->position_ids && c->image_states && c->img_mask && c->gate, "idefics_text_forward: missing inputs");
+    LICV_CHECK_ARG(c->h16 && c->h32 && c->x && c->xn && c->q && c->qkv && c->o && c->act && c->logits, "idefics_text_forward: missing scratch / output buffers");
+    LICV_CHECK_ARG(c->B > 0 && c->S > 0 && c->Sk >= c->S && c->Nk > 0 && c->n_img > 0, "idefics_text_forward: bad shape");
+    LICV_CHECK_ARG(!c->kv_cache || (c->past + c->S == c->Sk && c->Sk <= c->cache_max_len), "idefics_text_forward: KV cache / mask lengths inconsistent");
+    LICV_CHECK_ARG(c->kv_cache || c->Sk == c->S, "idefics_text_forward: without a KV cache the mask must span exactly the new tokens");
+    LICV_CHECK_ARG(c->xkv_cached || c->xkv, "idefics_text_forward: no cross-attention K/V cache and no scratch to project into");
+    const int64_t H = w->hidden, I = w->inter, nh = w->n_heads, hd = w->head_dim, E = w->img_dim;
+    const int64_t B = c->B, S = c->S, M = B * S, Nk = c->Nk;
+    const float att_scale = 1.0f / sqrtf((float)hd);
+    hipStream_t st = (hipStream_t)stream;
+    Ctx x{w, c, stream, M, H, c->h16, LICV_BF16};
+
+    RUN(licv_embed_gather(c->input_ids, w->embed, w->embed_extra, c->h16, M, H, w->vocab, w->n_extra_vocab, stream));
+    bool xn_valid = false;                                 // c->xn holds RMSNorm(h) for the next block (made by the fused hook kernel)
+    auto next_norm = [&](int64_t l) -> const void* {
+        if (l + 1 >= w->n_layers) return w->final_ln;
+        if ((l + 1) % w->cross_interval == 0) return w->xat[(l + 1) / w->cross_interval].in_ln;
+        return w->dec[l + 1].in_ln;
+    };
+    for (int64_t l = 0; l < w->n_layers; ++l) {
+        if (l % w->cross_interval == 0) {                  // gated cross-attention layer (hf:idefics/modeling_idefics.py:746-802)
+            const int64_t j = l / w->cross_interval;
+            const licv_idefics_xattn_w& X = w->xat[j];
+            const void* xin = c->xn;
+            if (!xn_valid) { RUN(licv_rmsnorm_fwd(x.h, x.h_dt, X.in_ln, c->x, M, H, 1, H, H, w->rms_eps, 0, stream)); xin = c->x; }
+            xn_valid = false;
+            RUN(linear(x, xin, M, X.q_w, H, H, c->q, H, LICV_BF16));
+            const void* kv = c->xkv_cached ? c->xkv_cached[j] : nullptr;
+            if (!kv) {
+                void* dst = c->xkv_out ? c->xkv_out[j] : c->xkv;
+                RUN(linear(x, c->image_states, B * Nk, X.kv_w, 2 * H, E, dst, 2 * H, LICV_BF16));
+                if (X.kn_w) RUN(licv_rmsnorm_fwd(dst, LICV_BF16, X.kn_w, dst, B * Nk * nh, hd, nh, 2 * H, 2 * H, w->rms_eps, 0, stream));
+                kv = dst;
+            }
+            if (X.qn_w) RUN(licv_rmsnorm_fwd(c->q, LICV_BF16, X.qn_w, c->q, M * nh, hd, nh, H, H, w->rms_eps, 0, stream));
+            licv_attn_args a;
+            a.q = c->q; a.q_bs = S * H; a.q_rs = H;
+            a.k = kv; a.v = (const char*)kv + H * 2; a.kv_bs = Nk * 2 * H; a.kv_rs = 2 * H;
+            a.o = c->o; a.B = B; a.Sq = S; a.Sk = Nk; a.n_heads = nh; a.n_kv_heads = nh; a.head_dim = hd;
+            a.scale = att_scale; a.mask_mode = 3; a.key_valid = nullptr; a.img_mask = c->img_mask; a.n_img = c->n_img; a.img_len = w->img_len;
+            RUN(licv_attn_fwd(&a, stream));
+            RUN(linear(x, c->o, M, X.o_w, H, H, x.h, H, x.h_dt, x.h, x.h_dt, c->gate, &X.gate_attn));
+            RUN(licv_rmsnorm_fwd(x.h, x.h_dt, X.post_ln, c->x, M, H, 1, H, H, w->rms_eps, 0, stream));
+            RUN(linear(x, c->x, M, X.gu_w, 2 * I, H, c->act, I, LICV_BF16, nullptr, 0, nullptr, nullptr, 1));
+            RUN(linear(x, c->act, M, X.down_w, H, I, x.h, H, x.h_dt, x.h, x.h_dt, nullptr, &X.gate_dense));
+        }
+        const licv_idefics_dec_w& D = w->dec[l];           // decoder layer (hf:idefics/modeling_idefics.py:645-675), hooked on its output
+        const void* xin = c->xn;
+        if (!xn_valid) { RUN(licv_rmsnorm_fwd(x.h, x.h_dt, D.in_ln, c->x, M, H, 1, H, H, w->rms_eps, 0, stream)); xin = c->x; }
+        xn_valid = false;
+        RUN(linear(x, xin, M, D.qkv_w, 3 * H, H, c->qkv, 3 * H, LICV_BF16));
+        RUN(licv_rotary_fwd(c->qkv, w->cos, w->sin, c->position_ids, M, nh, hd, 3 * H, H, 2, w->rope_len, stream));
+        licv_attn_args a;
+        a.q = c->qkv; a.q_bs = S * 3 * H; a.q_rs = 3 * H;
+        a.o = c->o; a.B = B; a.Sq = S; a.n_heads = nh; a.n_kv_heads = nh; a.head_dim = hd; a.scale = att_scale; a.mask_mode = 1;
+        a.key_valid = c->key_valid; a.img_mask = nullptr; a.n_img = 0; a.img_len = 0;
+        if (!c->kv_cache) {
+            a.k = (const char*)c->qkv + H * 2; a.v = (const char*)c->qkv + 2 * H * 2; a.kv_bs = S * 3 * H; a.kv_rs = 3 * H; a.Sk = S;
+        } else {
+            void* cache = c->kv_cache[l];
+            kv_append_k<<<(unsigned)M, 256, 0, st>>>((const bf16_t*)c->qkv, (bf16_t*)cache, S, H, c->cache_max_len, c->past);
+            LICV_LAUNCH_CHECK();
+            a.k = cache; a.v = (const char*)cache + H * 2; a.kv_bs = c->cache_max_len * 2 * H; a.kv_rs = 2 * H; a.Sk = c->Sk;
+        }
+        RUN(licv_attn_fwd(&a, stream));
+        RUN(linear(x, c->o, M, D.o_w, H, H, x.h, H, x.h_dt, x.h, x.h_dt));
+        RUN(licv_rmsnorm_fwd(x.h, x.h_dt, D.post_ln, c->x, M, H, 1, H, H, w->rms_eps, 0, stream));
+        RUN(linear(x, c->x, M, D.gu_w, 2 * I, H, c->act, I, LICV_BF16, nullptr, 0, nullptr, nullptr, 1));
+        RUN(linear(x, c->act, M, D.down_w, H, I, x.h, H, x.h_dt, x.h, x.h_dt));
+        const int slot = (c->hook_slot && c->icv) ? c->hook_slot[l] : -1;
+        if (slot >= 0) {                                   // the hook (ref:icv_src/icv_model/icv_intervention.py:61-86) fused with the next RMSNorm
+            RUN(licv_inject_renorm_fwd(x.h, x.h_dt, c->icv + (int64_t)slot * H, c->alpha ? c->alpha + slot : nullptr, (float*)c->h32, M, H,
+                                       next_norm(l), c->xn, w->rms_eps, stream));
+            x.h = c->h32; x.h_dt = LICV_F32;               // the fp32 ICV promotes the stream
+            xn_valid = true;
+        }
+    }
+    const void* xf = c->xn;
+    if (!xn_valid) { RUN(licv_rmsnorm_fwd(x.h, x.h_dt, w->final_ln, c->x, M, H, 1, H, H, w->rms_eps, 0, stream)); xf = c->x; }
+    int64_t rows = M;
+    if (c->logits_rows && c->n_rows > 0) {
+        LICV_CHECK_ARG(c->xsel, "idefics_text_forward: logits_rows given without the xsel scratch");
+        RUN(licv_embed_gather(c->logits_rows, xf, nullptr, c->xsel, c->n_rows, H, M, 0, stream));
+        xf = c->xsel; rows = c->n_rows;
+    }
+    return linear(x, xf, rows, w->lm_head, w->vocab_total, H, c->logits, c->ld_logits, LICV_BF16);
+}

@@ -44,6 +44,8 @@ class _IdeficsDecoder:
 
     def replicate(self, nb):                       # HF prefills B*nb identical rows; replicate the prompt state instead
         self.cache.kv = [t.repeat_interleave(nb, 0) for t in self.cache.kv]
+        if self.cache.xkv is not None:             # beams of one question share the image side: replicated once, never reordered
+            self.cache.xkv = [t.repeat_interleave(nb, 0) for t in self.cache.xkv]
         self.image_states = self.image_states.repeat_interleave(nb, 0)
         self.iam = self.iam.repeat_interleave(nb, 0)
 

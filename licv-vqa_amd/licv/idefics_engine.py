@@ -145,6 +145,7 @@ class KVCache:
         H = arch.hidden_size
         self.max_len, self.len = max_len, 0
         self.kv = [torch.empty((batch, max_len, 2 * H), dtype=torch.bfloat16, device=device) for _ in range(arch.num_layers)]
+        self.xkv = None        # cross-attention K|V per gated layer, projected once at the prefill by the native runner (step-invariant)
 
     def reorder(self, idx: torch.Tensor):
         for i in range(len(self.kv)):
@@ -152,9 +153,13 @@ class KVCache:
 
 
 class IdeficsEngine:
-    def __init__(self, weights: IdeficsWeights, fuse_hook_norm: bool = True):
+    def __init__(self, weights: IdeficsWeights, fuse_hook_norm: bool = True, use_runner: bool = True):
         self.w, self.arch = weights, weights.arch
         self.fuse_hook_norm = fuse_hook_norm
+        # the language stack through ONE C call (csrc/runner.hip) whenever nothing is captured: same kernels, same results, no
+        # per-launch interpreter cost (decode steps and 32-token passes are launch-bound from Python)
+        self.use_runner = use_runner
+        self._runner = None
 
     # ----------------------------------------------------------------------------------- vision side
     def encode_images(self, pixel_values: torch.Tensor) -> torch.Tensor:
@@ -251,11 +256,20 @@ class IdeficsEngine:
             if alpha is not None:
                 alpha = alpha.to(device=dev, dtype=torch.float32).contiguous()
 
+        past = kv_cache.len if kv_cache is not None else 0
+        assert past + S == Sk, "attention_mask must span past + new tokens"
+        if self.use_runner and self.fuse_hook_norm and capture is None and save_hook_inputs is None and not ops.profiling():
+            if self._runner is None:
+                from .runner import TextRunner
+                self._runner = TextRunner(w)
+            return self._runner.forward(input_ids.contiguous(), key_valid, pos, image_states.contiguous(), img_mask, gate,
+                                        icv=icv, alpha=alpha.reshape(-1).contiguous() if alpha is not None else None,
+                                        hook_layers=hook_layers if idx_of else None, kv_cache=kv_cache, logits_rows=logits_rows)
+        if kv_cache is not None and kv_cache.xkv is not None:
+            kv_cache.xkv = None                      # the Python loop re-projects the cross-attention K|V at every step
         h = ops.embed_gather(input_ids.contiguous(), w.embed, w.embed_extra, a.vocab_size).view(M, H)
         xn = None                                    # RMSNorm of h for the next block, when the hook kernel made it
         img2d = image_states.reshape(B * Nk, E)
-        past = kv_cache.len if kv_cache is not None else 0
-        assert past + S == Sk, "attention_mask must span past + new tokens"
 
         def next_norm_weight(l: int):
             if l + 1 >= a.num_layers:

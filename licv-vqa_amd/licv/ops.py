@@ -20,6 +20,11 @@ def set_profiler(store):
     _prof = store
 
 
+def profiling() -> bool:
+    """True while a launch profiler is installed (the per-launch event pairs need the Python-level launches)."""
+    return _prof is not None
+
+
 def _timed(kind, work, fn, label=None):
     if _prof is None:
         return fn()
