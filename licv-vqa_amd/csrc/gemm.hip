@@ -1370,24 +1370,168 @@ void gemm_bf16_splitk_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t*
             *reinterpret_cast<floatx4*>(slice + (int64_t)(rl + i * 16) * np + c0 + j * 16) = acc[i][j];
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight-streaming GEMM for M <= 32 (decode steps of hooked generate: beams x questions rows, one token each).  Such a GEMM
+// is a read of the weight matrix: 15.6 GB per decode step at Idefics-9B, a 3.5 ms floor at HBM rate; through the 128 x 128
+// tile kernels (32-172 workgroups, three quarters of every A tile padding) it took ~10 ms.  Here:
+//   * grid = ceil(N / 64) column blocks x `splits` K ranges (>= 512 workgroups); a wave owns 16 output columns;
+//   * W goes global -> VGPR directly (read once, by one wave: no LDS round trip), 16 bytes per lane = one MFMA A-fragment,
+//     eight loads in flight per wave before the first is consumed;
+//   * the few activation rows of the K range are staged once per workgroup in LDS (row stride + 16 B: conflict-free
+//     ds_read_b128 fragments), zero-padded to 16 / 32 rows;
+//   * fp32 partials go to the caller's workspace as [split][32 rows][N padded to 128] and gemm_splitk_finalize_k adds them
+//     in order and runs the usual epilogue (deterministic, no atomics).
+// ------------------------------------------------------------------------------------------------
+#define SKINNY_KR_MAX 1024          // K elements per split: 32 rows x 1024 x 2 B + padding = 66 KB of LDS
+
+template <int MB>                   // 16-row blocks of A: 1 (M <= 16) or 2 (M <= 32)
+__global__ __launch_bounds__(256)
+void gemm_bf16_skinny_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw, float* __restrict__ ws,
+                        int M, int N, int K, int steps_per_split, int64_t np) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int nsteps = (K + 31) / 32;
+    const int s0 = blockIdx.y * steps_per_split, s1 = min(nsteps, s0 + steps_per_split);
+    const int ns = s1 - s0;
+    const int kbase = s0 * 32, kr = ns * 32;
+    const int xstr = kr * 2 + 16;                                    // LDS row stride in bytes
+    // ---- activations of this K range -> LDS (zero rows past M, zero columns past K)
+    const int chunks = kr / 8;
+    for (int c = tid; c < MB * 16 * chunks; c += 256) {
+        const int row = c / chunks, ch = c - row * chunks;
+        const int k = kbase + ch * 8;
+        u32x4 v = u32x4{0u, 0u, 0u, 0u};
+        if (row < M && k < K) v = *reinterpret_cast<const u32x4*>(A + (int64_t)row * lda + k);
+        *reinterpret_cast<u32x4*>(smem + row * xstr + ch * 16) = v;
+    }
+    __syncthreads();
+    const int n = blockIdx.x * 64 + wave * 16 + fr;
+    const bf16_t* wp = W + (int64_t)min(n, N - 1) * ldw + kbase + fq * 8;
+    const char* xp = smem + fr * xstr + fq * 16;
+    floatx4 acc[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) acc[mb] = floatx4{0.f, 0.f, 0.f, 0.f};
+    constexpr int UN = 8;
+    int s = 0;
+    for (; s + UN <= ns; s += UN) {
+        u32x4 wf[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int k = kbase + (s + u) * 32 + fq * 8;
+            wf[u] = k < K ? *reinterpret_cast<const u32x4*>(wp + (s + u) * 32) : u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xp + mb * 16 * xstr + (s + u) * 64);
+                acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&wf[u]), xf, acc[mb], 0, 0, 0);
+            }
+        }
+    }
+    for (; s < ns; ++s) {
+        const int k = kbase + s * 32 + fq * 8;
+        const u32x4 w1 = k < K ? *reinterpret_cast<const u32x4*>(wp + s * 32) : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xp + mb * 16 * xstr + s * 64);
+            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&w1), xf, acc[mb], 0, 0, 0);
+        }
+    }
+    // lane holds rows m = mb*16 + fr, columns n0 + fq*4 .. +3  (W was the A operand)
+    float* slice = ws + (int64_t)blockIdx.y * 32 * np;
+    const int64_t c0 = (int64_t)blockIdx.x * 64 + wave * 16 + fq * 4;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+        *reinterpret_cast<floatx4*>(slice + (int64_t)(mb * 16 + fr) * np + c0) = acc[mb];
+    if (MB == 1) *reinterpret_cast<floatx4*>(slice + (int64_t)(16 + fr) * np + c0) = floatx4{0.f, 0.f, 0.f, 0.f};
+}
+
+// Finalize of the skinny path: sum the fp32 slices in order and run the epilogue for <= 32 rows, four consecutive output
+// columns per thread.  Same rounding points, in the same order, as epilogue_staged + epilogue_rows_generic (y = bf16(acc + bias);
+// activation; SwiGLU pairing; row gate; gate scale; residual in the stream dtype) — the general finalize kernel walks
+// 128 x 128 tiles through an LDS image, 17 us per call for 24 rows; this one is a few microseconds.
+__global__ __launch_bounds__(256)
+void skinny_finalize_k(const float* __restrict__ ws, void* __restrict__ C, int64_t ldc, int M, int N, int64_t np, int splits, GemmEpi ep) {
+    const int n_out = ep.swiglu ? N >> 1 : N;
+    const int groups = (n_out + 3) >> 2;
+    const int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (item >= (int64_t)M * groups) return;
+    const int m = (int)(item / groups), c = (int)(item - (int64_t)m * groups) * 4;
+    const int nv = min(4, n_out - c);
+    const int64_t slice = 32 * np;
+    auto sum4 = [&](int col) -> floatx4 {
+        const float* p = ws + (int64_t)m * np + col;
+        floatx4 v = *reinterpret_cast<const floatx4*>(p);
+        for (int sp = 1; sp < splits; ++sp) v += *reinterpret_cast<const floatx4*>(p + sp * slice);         // fixed order
+        return v;
+    };
+    float y[4];
+    if (!ep.swiglu) {
+        const floatx4 a = sum4(c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float b = (ep.bias && e < nv) ? bf2f(ep.bias[c + e]) : 0.f;
+            y[e] = rbf(a[e] + b);
+            if (ep.act) y[e] = rbf(act_apply(y[e], ep.act));
+        }
+    } else {
+        const int pc = (c >> 4) * 32 + (c & 15);                    // packed gate columns; the matching up columns sit 16 further
+        const floatx4 gsum = sum4(pc), usum = sum4(pc + 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = rbf(rbf(silu_fast(rbf(gsum[e]))) * rbf(usum[e]));
+    }
+    if (ep.row_gate && ep.row_gate[m] == 0.0f) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = 0.f;
+    }
+    if (ep.use_scale) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = rbf(ep.scale * y[e]);
+    }
+    if (ep.residual) {
+        if (ep.residual_dtype == LICV_F32) {
+            const float* rp = reinterpret_cast<const float*>(ep.residual) + (int64_t)m * ep.ld_res + c;
+            for (int e = 0; e < nv; ++e) y[e] = rp[e] + y[e];
+        } else {
+            const bf16_t* rp = reinterpret_cast<const bf16_t*>(ep.residual) + (int64_t)m * ep.ld_res + c;
+            for (int e = 0; e < nv; ++e) y[e] = rbf(bf2f(rp[e]) + y[e]);
+        }
+    }
+    if (ep.out_dtype == LICV_F32) {
+        float* cp = reinterpret_cast<float*>(C) + (int64_t)m * ldc + c;
+        if (nv == 4) *reinterpret_cast<floatx4*>(cp) = floatx4{y[0], y[1], y[2], y[3]};
+        else for (int e = 0; e < nv; ++e) cp[e] = y[e];
+    } else {
+        bf16_t* cp = reinterpret_cast<bf16_t*>(C) + (int64_t)m * ldc + c;
+        if (nv == 4) *reinterpret_cast<uint2*>(cp) = uint2{pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3])};
+        else for (int e = 0; e < nv; ++e) cp[e] = f2bf(y[e]);
+    }
+}
+
 __global__ __launch_bounds__(256, 2)
 void gemm_splitk_finalize_k(const float* __restrict__ ws, void* __restrict__ C, int64_t ldc, int M, int N, int tiles_m, int tiles_n,
-                            int splits, GemmEpi ep) {
+                            int splits, GemmEpi ep, int slice_rows) {      // slice_rows: rows a slice holds (0: tiles_m * 128)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
     const int m0 = tm * 128, n0 = tn * 128;
-    const int64_t np = (int64_t)tiles_n * 128, slice = ((int64_t)tiles_m * 128) * np;
+    const int rows = slice_rows > 0 ? slice_rows : tiles_m * 128;
+    const int64_t np = (int64_t)tiles_n * 128, slice = (int64_t)rows * np;
     const int rl = m0 + wm * 64 + (lane & 15), c0 = n0 + wn * 64 + (lane >> 4) * 4;
     floatx4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float* p = ws + (int64_t)(rl + i * 16) * np + c0 + j * 16;
-            floatx4 v = *reinterpret_cast<const floatx4*>(p);
-            for (int sp = 1; sp < splits; ++sp) v += *reinterpret_cast<const floatx4*>(p + sp * slice);      // fixed order
+            floatx4 v = floatx4{0.f, 0.f, 0.f, 0.f};
+            if (rl + i * 16 < rows) {                              // rows past the slice height were never produced (skinny slices: 32 rows)
+                const float* p = ws + (int64_t)(rl + i * 16) * np + c0 + j * 16;
+                v = *reinterpret_cast<const floatx4*>(p);
+                for (int sp = 1; sp < splits; ++sp) v += *reinterpret_cast<const floatx4*>(p + sp * slice);  // fixed order
+            }
             acc[i][j] = v;
         }
     epilogue_staged<128, 128, 4, 4, 4>(acc, ep, C, ldc, M, N, m0, n0, wm * 64, wn * 64, wave, lane, smem);
@@ -1572,6 +1716,20 @@ extern "C" int licv_gemm_splitk_plan(int64_t M, int64_t N, int64_t K, int* split
         }
         return LICV_OK;
     }
+    if (M > 0 && M <= 32 && N >= 256 && K >= 256 && K % 8 == 0) {    // weight-streaming kernel (gemm_bf16_skinny_k)
+        const int64_t nblocks = (N + 63) / 64, nsteps = (K + 31) / 32;
+        int64_t sp = (nsteps + SKINNY_KR_MAX / 32 - 1) / (SKINNY_KR_MAX / 32);
+        const int64_t want = (512 + nblocks - 1) / nblocks;       // aim at >= 512 workgroups
+        if (want > sp) sp = want;
+        if (sp > nsteps / 4) sp = nsteps / 4 > 0 ? nsteps / 4 : 1;     // at least 4 K-steps per split
+        const int64_t per = (nsteps + sp - 1) / sp;
+        sp = (nsteps + per - 1) / per;
+        if (sp >= 1 && per * 32 <= SKINNY_KR_MAX) {
+            *splits = (int)(sp < 2 ? 2 : sp);                     // the split-K entry point wants >= 2; an empty extra range adds zeros
+            *workspace_bytes = (int64_t)(*splits) * 32 * ((N + 127) / 128 * 128) * 4;
+            return LICV_OK;
+        }
+    }
     // measured (round 1): worth it from K ~ 8192 up (K = 11008: 132 -> 69 us at M = 256); at K = 4096 the extra
     // fp32 round trip through the workspace and the second launch cancel the gain
     if (M <= 0 || M > 256 || K < 8192 || K % 8 != 0 || N < 128) return LICV_OK;
@@ -1607,6 +1765,35 @@ extern "C" int licv_gemm_bf16_splitk(const void* A, int64_t lda, const void* W, 
     LICV_CHECK_ARG(e->act >= 0 && e->act <= 3, "gemm_bf16_splitk: bad activation %d", e->act);
     LICV_CHECK_ARG(!e->swiglu || (N % 32 == 0 && !e->bias_bf16 && !e->act), "gemm_bf16_splitk: swiglu needs N %% 32 == 0, no bias/act");
     LICV_CHECK_ARG(!e->residual || (e->ld_res % 4 == 0 && ((uintptr_t)e->residual & 15) == 0), "gemm_bf16_splitk: residual misaligned");
+    if (M <= 32 && N >= 256 && K >= 256) {                     // weight-streaming kernel, slices of 32 rows
+        const int64_t np = (N + 127) / 128 * 128;
+        LICV_CHECK_ARG(workspace_bytes >= (int64_t)splits * 32 * np * 4, "gemm_bf16_splitk: workspace too small for the skinny path");
+        const int nsteps = (int)((K + 31) / 32);
+        const int per = (nsteps + splits - 1) / splits;
+        LICV_CHECK_ARG(per * 32 <= SKINNY_KR_MAX, "gemm_bf16_splitk: %d splits leave more than %d K elements per split", splits, SKINNY_KR_MAX);
+        GemmEpi eps;
+        eps.bias = (const bf16_t*)e->bias_bf16; eps.row_gate = e->row_gate; eps.residual = e->residual;
+        eps.residual_dtype = e->residual_dtype; eps.ld_res = e->ld_res; eps.act = e->act; eps.swiglu = e->swiglu;
+        eps.use_scale = e->use_scale; eps.scale = e->scale; eps.out_dtype = e->out_dtype; eps.a_scale = nullptr; eps.w_scale = nullptr;
+        static bool sattr = false;
+        if (!sattr) {
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_skinny_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 32 * (SKINNY_KR_MAX * 2 + 16));
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_skinny_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 32 * (SKINNY_KR_MAX * 2 + 16));
+            (void)hipFuncSetAttribute((const void*)gemm_splitk_finalize_k, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+            sattr = true;
+        }
+        hipStream_t sst = (hipStream_t)stream;
+        const dim3 grid((unsigned)((N + 63) / 64), (unsigned)splits);
+        const int mb = M <= 16 ? 1 : 2;
+        const size_t lds = (size_t)mb * 16 * (per * 32 * 2 + 16);
+        if (mb == 1) gemm_bf16_skinny_k<1><<<grid, 256, lds, sst>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, (float*)workspace, (int)M, (int)N, (int)K, per, np);
+        else         gemm_bf16_skinny_k<2><<<grid, 256, lds, sst>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, (float*)workspace, (int)M, (int)N, (int)K, per, np);
+        const int n_out = e->swiglu ? (int)(N / 2) : (int)N;
+        const int64_t items = (int64_t)M * ((n_out + 3) / 4);
+        skinny_finalize_k<<<dim3((unsigned)((items + 255) / 256)), dim3(256), 0, sst>>>((const float*)workspace, C, ldc, (int)M, (int)N, np, splits, eps);
+        LICV_LAUNCH_CHECK();
+        return LICV_OK;
+    }
     const bool big = M > 256;                                  // partials from the 256 x 256 ping-pong kernel
     const int pad = big ? 256 : 128;
     const int tiles_m = (int)((M + 127) / 128), tiles_n = (int)((N + 127) / 128);
@@ -1637,12 +1824,12 @@ extern "C" int licv_gemm_bf16_splitk(const void* A, int64_t lda, const void* W, 
             (const bf16_t*)A, lda, (const bf16_t*)W, ldw, workspace, 0, (int)M, (int)N, (int)K, t256m, t256n, ep, 0, per32);
         // the finalize kernel walks 128 x 128 tiles of the same [split][M_pad][N_pad] workspace
         gemm_splitk_finalize_k<<<dim3((int)(mp / 128) * (int)(npad / 128)), dim3(256), 65536, st>>>((const float*)workspace, C, ldc, (int)M, (int)N,
-            (int)(mp / 128), (int)(npad / 128), splits, ep);
+            (int)(mp / 128), (int)(npad / 128), splits, ep, 0);
     } else {
         gemm_bf16_splitk_k<<<dim3(tiles_m * tiles_n, splits), dim3(256), 65536, st>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw,
             (float*)workspace, (int)M, (int)N, (int)K, tiles_m, tiles_n, per);
         gemm_splitk_finalize_k<<<dim3(tiles_m * tiles_n), dim3(256), 65536, st>>>((const float*)workspace, C, ldc, (int)M, (int)N,
-            tiles_m, tiles_n, splits, ep);
+            tiles_m, tiles_n, splits, ep, 0);
     }
     LICV_LAUNCH_CHECK();
     return LICV_OK;

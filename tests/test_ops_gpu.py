@@ -565,3 +565,40 @@ def test_gemm_splitk_matches_plain_kernel_and_is_reproducible(M, N, K, epi):
     finally:
         O_.SPLITK = True
     assert (y1.float() - ref.float()).abs().max() <= 2.0 ** -7 * ref.float().abs().max()
+
+
+@pytest.mark.parametrize("epi", ["plain", "bias", "swiglu", "res32", "res16"])
+@pytest.mark.parametrize("M,N,K", [(1, 256, 256), (16, 4096, 4096), (17, 1000, 1000), (24, 12288, 4096), (24, 4096, 11008), (32, 22016, 4096)])
+def test_gemm_skinny_weight_streaming_kernel(M, N, K, epi):
+    """M <= 32 (decode steps: beams x questions rows): gemm_bf16_skinny_k + ordered split-K finalize against the one-pass kernel and
+    an fp64 product — ragged N (not a multiple of 64), K not a multiple of 32, one row, both 16- and 32-row forms, every epilogue
+    family; bit-reproducible run to run."""
+    from licv import ops as O_
+    if epi == "swiglu" and N % 32:
+        pytest.skip("swiglu needs N % 32 == 0")
+    gen = g(M + N + K)
+    a = torch.randn(M, K, generator=gen).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(N, K, generator=gen) * 0.03).to(torch.bfloat16).to(DEV)
+    kw = {}
+    if epi == "bias":
+        kw = dict(bias=(torch.randn(N, generator=gen) * 0.1).to(torch.bfloat16).to(DEV))
+    elif epi == "swiglu":
+        kw = dict(swiglu=True)
+    elif epi == "res32":
+        kw = dict(residual=torch.randn(M, N, generator=gen).to(DEV))
+    elif epi == "res16":
+        kw = dict(residual=torch.randn(M, N, generator=gen).to(torch.bfloat16).to(DEV))
+    splits, ws = O_._splitk_plan(M, N, K)
+    assert splits >= 2 and ws == splits * 32 * ((N + 127) // 128 * 128) * 4
+    y1 = O_.linear(a, w, **kw).clone()
+    assert torch.equal(y1, O_.linear(a, w, **kw))
+    try:
+        O_.SPLITK = False
+        ref = O_.linear(a, w, **kw).clone()
+    finally:
+        O_.SPLITK = True
+    assert y1.shape == ref.shape
+    assert (y1.float() - ref.float()).abs().max() <= 2.0 ** -7 * ref.float().abs().max()
+    if epi == "plain":
+        exact = (a.double().cpu() @ w.double().cpu().T)
+        assert (y1.double().cpu() - exact).abs().max() <= 2.0 ** -8 * exact.abs().max() * 1.01
