@@ -646,7 +646,7 @@ void gemm_bf16_pingpong_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;                         // group = wm: waves 0-3 lead, 4-7 trail
-    long long* ts = (g_dbg_ts && tid == 0) ? g_dbg_ts + (int64_t)blockIdx.x * 8 : nullptr;
+    long long* ts = (ABL != 6 && g_dbg_ts && tid == 0) ? g_dbg_ts + (int64_t)blockIdx.x * 8 : nullptr;
     if (ts) ts[0] = wall_clock64();
     int tm, tn;
     tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn, ABL == 5 ? 8 : group);
@@ -701,23 +701,35 @@ void gemm_bf16_pingpong_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_
     if (ts) ts[1] = wall_clock64();
     if (wm == 1) __builtin_amdgcn_s_barrier();               // trailing group starts half a stage later
 
+    // ABL 6 (diagnostic build, results unaffected): every wave stamps s_memtime around the segments of ONE mid-loop stage into
+    // g_dbg_ts[(block * 8 + wave) * 8 + i]: 0 load-phase start, 1 fragment reads issued, 2 DMA pieces issued, 3 counted vmcnt
+    // passed, 4 lgkmcnt(0) passed, 5 barrier passed (compute starts), 6 MFMAs issued, 7 second barrier passed
+    unsigned long long stamp[8];
+    const int probe = (ABL == 6 && g_dbg_ts) ? ns / 2 : -1;
+#define STAMP(i) do { if (ABL == 6 && s == probe) { __builtin_amdgcn_sched_barrier(0); stamp[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
     for (int s = 0; s < ns; ++s) {
         // ---- LOAD phase (partner computes)
         {
             const char* sa = smem + (s % RING_STAGES) * RING_STAGE_BYTES + (wm * 128) * 64 + fo;
             const char* sw = smem + (s % RING_STAGES) * RING_STAGE_BYTES + 16384 + (wn * 64) * 64 + fo;
+            STAMP(0);
             if (ABL != 3 || s == 0) {                            // ABL 3 (timing only): fragments read once, never again
 #pragma unroll
                 for (int j = 0; j < 4; ++j) fw[j] = *reinterpret_cast<const bf16x8*>(sw + j * 16 * 64);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 64);
             }
+            STAMP(1);
             if (s + 4 < ns) issue(s + 4);
+            STAMP(2);
             wait_vmcnt(4 * max(0, min(3, ns - 2 - s)));      // retire my pieces of stage s+1; later stages stay in flight
+            STAMP(3);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
+            STAMP(4);
         }
         __builtin_amdgcn_s_barrier();
+        STAMP(5);
         // ---- COMPUTE phase (partner loads)
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
@@ -735,8 +747,16 @@ void gemm_bf16_pingpong_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_
         }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
+        STAMP(6);
         __builtin_amdgcn_s_barrier();
+        STAMP(7);
+        if (ABL == 6 && s == probe && lane == 0) {
+            long long* o = g_dbg_ts + ((int64_t)blockIdx.x * 8 + wave) * 8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = (long long)stamp[i];
+        }
     }
+#undef STAMP
     if (wm == 0) __builtin_amdgcn_s_barrier();               // leading group: match the barrier count
     if (ts) ts[2] = wall_clock64();
     if (ABL == 1) {
@@ -759,6 +779,113 @@ void gemm_bf16_pingpong_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_
     }
     epilogue_staged<256, 256, 8, 8, 4>(acc, ep, C, ldc, M, N, m0, n0, wm * 128, wn * 64, wave, lane, smem, ts);
     if (ts) ts[4] = wall_clock64();
+}
+
+// ------------------------------------------------------------------------------------------------
+// "pair" kernel: the ping-pong schedule with TWO 32-deep K stages per phase.
+//
+// Measured on the ping-pong kernel (tools/gemm_segments.py, s_memtime stamps, cycles per wave and stage): LOAD phase 600
+// (12 fragment reads 236 — the LDS port, 4 waves x 12 KiB; 4 DMA pieces 152; counted vmcnt 108; lgkmcnt 68; barrier 36),
+// COMPUTE phase 600 (32 MFMAs), second barrier 320: 1536 per stage against 1024 if the matrix pipe never waited.  Each
+// phase is about as long as the partner's, so every barrier costs its skew, and there are two per 32 K.  With two stages
+// per phase the load phase (~950) fits under the partner's 64 MFMAs (~1200) and the barrier count per K halves — the
+// 256 x 256 x 64 geometry of the vendor library's kernels, on the same five 32 KiB ring slots:
+//   * interval H(2P): leaders read pair P (stages 2P, 2P+1) while trailers run the MFMAs of pair P-1; H(2P+1): the reverse;
+//   * BOTH groups issue the DMA of stages 2P+3 and 2P+4 during H(2P) — the leaders at the head of their load phase, the
+//     trailers at the head of their compute phase — into the slots of pair P-1, which nobody reads any more; both retire
+//     pair P+1 (counted vmcnt(4): stage 2P+4 stays in flight) before the barrier that ends H(2P+1), two intervals after the
+//     issue, and the leaders first read pair P+1 after that barrier.
+// Same tile, same K order, same epilogue: bit-identical to the ping-pong kernel.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2)
+void gemm_bf16_pair_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw,
+                      void* __restrict__ C, int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n, GemmEpi ep, int group) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // [5 stages][A 16 KiB | W 16 KiB]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;                         // waves 0-3 lead, 4-7 trail by one interval
+    int tm, tn;
+    tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn, group);
+    const int m0 = tm * 256, n0 = tn * 256;
+    const bf16_t* srcA[2];
+    const bf16_t* srcW[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = wave * 32 + i * 16 + (lane >> 2);
+        const int chunk = (lane & 3) ^ (((row >> 2) & 1) << 1);
+        srcA[i] = A + (int64_t)min(m0 + row, M - 1) * lda + chunk * 8;
+        srcW[i] = W + (int64_t)min(n0 + row, N - 1) * ldw + chunk * 8;
+    }
+    const int ns = K / 32, npair = ns >> 1;                  // K % 64 == 0 and K >= 128: npair >= 2
+    auto issue = [&](int s) {
+        char* sa = smem + (s % RING_STAGES) * RING_STAGE_BYTES + wave * 32 * 64;
+        char* sw = sa + 16384;
+        const int64_t koff = (int64_t)s * 32;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + koff),
+                                             (__attribute__((address_space(3))) void*)(sa + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[i] + koff),
+                                             (__attribute__((address_space(3))) void*)(sw + i * 1024), 16, 0, 0);
+        }
+    };
+    floatx4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    const int fo = ring_off(lane & 15, lane >> 4);
+    bf16x8 fa0[8], fw0[4], fa1[8], fw1[4];
+    auto read_stage = [&](int s, bf16x8 (&fa)[8], bf16x8 (&fw)[4]) {
+        const char* sa = smem + (s % RING_STAGES) * RING_STAGE_BYTES + (wm * 128) * 64 + fo;
+        const char* sw = smem + (s % RING_STAGES) * RING_STAGE_BYTES + 16384 + (wn * 64) * 64 + fo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fw[j] = *reinterpret_cast<const bf16x8*>(sw + j * 16 * 64);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 64);
+    };
+    auto mma = [&](bf16x8 (&fa)[8], bf16x8 (&fw)[4]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
+    };
+    // DMA of the two stages that become free when pair P is the one being read: 2P+3 and 2P+4 (P = 0: stage 3 went out in the prologue)
+    auto issue_for = [&](int P) {
+        if (P > 0 && 2 * P + 3 < ns) issue(2 * P + 3);
+        if (2 * P + 4 < ns) issue(2 * P + 4);
+    };
+    // all but stage 2P+4 (if it exists) retired: pair P+1 has landed
+    auto retire_next = [&](int P) { wait_vmcnt(2 * P + 4 < ns ? 4 : 0); };
+
+    issue(0); issue(1); issue(2); issue(3);
+    wait_vmcnt(8);                                           // my pieces of pair 0 have landed
+    __builtin_amdgcn_s_barrier();                            // pair 0 published
+    if (wm == 1) { issue_for(0); __builtin_amdgcn_s_barrier(); }     // trailers: the H(0) issue, then start one interval later
+
+    for (int P = 0; P < npair; ++P) {
+        // ---- LOAD phase (partner computes)
+        read_stage(2 * P, fa0, fw0);
+        read_stage(2 * P + 1, fa1, fw1);
+        if (wm == 0) issue_for(P);                           // leaders: H(2P)
+        else if (P + 1 < npair) retire_next(P);              // trailers: pair P+1 must be in before the barrier that ends H(2P+1)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- COMPUTE phase (partner loads)
+        __builtin_amdgcn_sched_barrier(0);
+        if (wm == 1) issue_for(P + 1);                       // trailers: H(2P+2) = the leaders' load phase of pair P+1
+        __builtin_amdgcn_s_setprio(1);
+        mma(fa0, fw0);
+        mma(fa1, fw1);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (wm == 0 && P + 1 < npair) retire_next(P);        // leaders: the same deadline, the end of H(2P+1)
+        __builtin_amdgcn_s_barrier();
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();               // leading group: match the barrier count
+    epilogue_staged<256, 256, 8, 8, 4>(acc, ep, C, ldc, M, N, m0, n0, wm * 128, wn * 64, wave, lane, smem);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1675,6 +1802,18 @@ extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
                 (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, pp_ticks, pp_group)
             if (g_force_kernel == 10) PP_ABL(2); else if (g_force_kernel == 11) PP_ABL(3); else PP_ABL(4);
 #undef PP_ABL
+        }
+        else if (g_force_kernel == 13 && K >= 128) {             // diagnostic build with per-segment s_memtime stamps
+            static bool a6 = false;
+            if (!a6) { (void)hipFuncSetAttribute((const void*)gemm_bf16_pingpong_k<6>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES); a6 = true; }
+            gemm_bf16_pingpong_k<6><<<grid, block, RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>(
+                (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, pp_ticks, pp_group);
+        }
+        else if (g_force_kernel == 21 && K >= 128) {
+            static bool a21 = false;
+            if (!a21) { (void)hipFuncSetAttribute((const void*)gemm_bf16_pair_k, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES); a21 = true; }
+            gemm_bf16_pair_k<<<grid, block, RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>(
+                (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, pp_group);
         }
         else if (g_force_kernel == 6 && K >= 128)
             gemm_bf16_pingpong_k<0><<<grid, block, RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>(

@@ -243,12 +243,12 @@ def test_gemm_large_tile_kernels_match_general_kernel(variant, M, N, K):
         kw = dict(out_dtype=torch.float32)
     outs = {}
     try:
-        for sel in (1, 2, 6, 8):
+        for sel in (1, 2, 6, 8, 21):                              # 21: the pair kernel (two K stages per ping-pong phase)
             _lib.lib().licv_gemm_select(sel)
             outs[sel] = o.linear(a, w, **kw).clone()
     finally:
         _lib.lib().licv_gemm_select(0)
-    assert torch.equal(outs[1], outs[2]) and torch.equal(outs[1], outs[6]) and torch.equal(outs[1], outs[8])
+    assert torch.equal(outs[1], outs[2]) and torch.equal(outs[1], outs[6]) and torch.equal(outs[1], outs[8]) and torch.equal(outs[1], outs[21])
     ref = (a[:32].float() @ w.float().t())
     if variant == "plain":
         assert (outs[6][:32].float() - ref).abs().max() <= 2 ** -7 * ref.abs().max()
