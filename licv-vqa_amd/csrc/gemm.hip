@@ -393,6 +393,10 @@ __device__ __forceinline__ void epilogue_rows(const GemmEpi& ep, void* __restric
 // timing-only instrumentation (tools/gemm_phases.py): when set, wave 0 of every pingpong workgroup records
 // wall_clock64() at [0] start, [1] stage 0 published, [2] main loop done, [3] output image in LDS, [4] end
 __device__ long long* g_dbg_ts = nullptr;
+// experiment knob (licv_gemm_experiment knob 3): wave-priority scheme of the ping-pong main loop
+//   0 = priority 1 around each MFMA cluster (the round-1 scheme)   1 = no priority changes
+//   2 = priority 1 during the LOAD phase instead                   3 = static: the trailing waves 4-7 run at priority 1 throughout
+__device__ int g_prio_mode = 0;
 extern "C" int licv_gemm_debug_timestamps(void* dev_buffer) {
     long long* p = (long long*)dev_buffer;
     return hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_ts), &p, sizeof(p)) == hipSuccess ? LICV_OK : LICV_E_HIP;
@@ -707,11 +711,14 @@ void gemm_bf16_pingpong_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_
     unsigned long long stamp[8];
     const int probe = (ABL == 6 && g_dbg_ts) ? ns / 2 : -1;
 #define STAMP(i) do { if (ABL == 6 && s == probe) { __builtin_amdgcn_sched_barrier(0); stamp[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+    const int prio_mode = __builtin_amdgcn_readfirstlane(g_prio_mode);
+    if (prio_mode == 3 && wm == 1) __builtin_amdgcn_s_setprio(1);
     for (int s = 0; s < ns; ++s) {
         // ---- LOAD phase (partner computes)
         {
             const char* sa = smem + (s % RING_STAGES) * RING_STAGE_BYTES + (wm * 128) * 64 + fo;
             const char* sw = smem + (s % RING_STAGES) * RING_STAGE_BYTES + 16384 + (wn * 64) * 64 + fo;
+            if (prio_mode == 2) __builtin_amdgcn_s_setprio(1);
             STAMP(0);
             if (ABL != 3 || s == 0) {                            // ABL 3 (timing only): fragments read once, never again
 #pragma unroll
@@ -728,11 +735,12 @@ void gemm_bf16_pingpong_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_
             __builtin_amdgcn_sched_barrier(0);
             STAMP(4);
         }
+        if (prio_mode == 2) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_s_barrier();
         STAMP(5);
         // ---- COMPUTE phase (partner loads)
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
+        if (prio_mode == 0) __builtin_amdgcn_s_setprio(1);
         if (ABL != 4) {                                          // ABL 4 (timing only): no MFMAs
 #pragma unroll
             for (int i = 0; i < 8; ++i)
@@ -745,7 +753,7 @@ void gemm_bf16_pingpong_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_
 #pragma unroll
             for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(fw[j]));
         }
-        __builtin_amdgcn_s_setprio(0);
+        if (prio_mode == 0) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         STAMP(6);
         __builtin_amdgcn_s_barrier();
@@ -1688,6 +1696,7 @@ extern "C" int licv_gemm_stagger(int on) { g_stagger = on; return LICV_OK; }
 //   knob 1: tile-rows per XCD patch group (0 = the default 8)
 extern "C" int licv_gemm_experiment(int knob, int value) {
     if (knob == 0) g_pp_stagger = value; else if (knob == 1) g_pp_group = value; else if (knob == 2) g_flow_default = value;
+    else if (knob == 3) return hipMemcpyToSymbol(HIP_SYMBOL(g_prio_mode), &value, sizeof(int)) == hipSuccess ? LICV_OK : LICV_E_HIP;
     else return licv_set_error(LICV_E_BADARG, "gemm_experiment: unknown knob %d", knob);
     return LICV_OK;
 }

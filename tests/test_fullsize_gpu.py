@@ -15,17 +15,27 @@ import pytest
 import torch
 
 from licv.config import IDEFICS_9B
-from licv.synthetic import synth_icv, synth_idefics_weights, synth_vqa_batch
+from licv.synthetic import synth_icv, synth_idefics_weights, synth_vqa_batch, trained_like_
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
+# P2 with the split-K path on: a single question's K >= 8192 projections add their fp32 partial sums in another order than the
+# one-pass kernel of the batch of 8 (one-ulp differences in 32 down-projections).  With trained-like weight scales that stays a
+# bf16-noise-level difference at the logits: measured relative L2 3.3e-2 (9B, 32+8 layers) / 1.7e-2 (8B), max 3.5e-2 / 2.3e-2 of
+# the logit scale at full depth (random-init weights gave 0.1+, hence the trained-like scales); bounds = ~1.5x measured.
+P2_REL, P2_MAX = 5e-2, 5.5e-2
+# fp8 (e4m3, 3 mantissa bits) against bf16 through 32 layers: quantisation noise.  Measured relative L2 0.171, per-row cosine
+# min 0.92 / mean 0.986; bounds = ~1.5x measured (the test prints the values)
+F3_REL, F3_COS = 0.27, 0.86
 
 
 @pytest.fixture(scope="module")
 def full():
     from licv.idefics_engine import IdeficsEngine, IdeficsWeights
     arch = IDEFICS_9B
-    sd = synth_idefics_weights(arch, seed=426, dtype=torch.bfloat16, device=DEV)
+    # trained-like scales (residual-branch outputs x 1/sqrt(2L)): with every linear ~N(0, 0.02) a 32-layer random model turns a
+    # one-ulp kernel difference into a percent-level logit difference, and no bound on P2 could mean anything
+    sd = trained_like_(synth_idefics_weights(arch, seed=426, dtype=torch.bfloat16, device=DEV), arch.num_layers)
     w = IdeficsWeights(sd, arch, DEV)
     del sd
     torch.cuda.empty_cache()
@@ -79,7 +89,8 @@ def test_fullsize_hook_properties(full):
         one = {k: v[b:b + 1].contiguous() for k, v in batch.items()}
         alone = eng.forward(**one, icv=scaled, hook_layers=layers)
         d = alone[0].float() - lg[b].float()
-        assert float(d.norm() / lg[b].float().norm()) <= 6e-2 and float(d.abs().max()) <= 0.15 * scale
+        print(f"\n  P2 idefics-9b row {b}: alone vs in-batch (split-K on): relative L2 {float(d.norm() / lg[b].float().norm()):.2e}, max {float(d.abs().max()) / scale:.2e} of scale")
+        assert float(d.norm() / lg[b].float().norm()) <= P2_REL and float(d.abs().max()) <= P2_MAX * scale
         try:
             ops.SPLITK = False
             alone = eng.forward(**one, icv=scaled, hook_layers=layers)
@@ -95,7 +106,7 @@ def test_fullsize_idefics2_properties():
     from licv.idefics2_engine import Idefics2Engine, Idefics2Weights
     from licv.synthetic import synth_idefics2_weights, synth_vqa_batch_idefics2
     arch = IDEFICS2_8B
-    sd = synth_idefics2_weights(arch, seed=426, dtype=torch.bfloat16, device=DEV)
+    sd = trained_like_(synth_idefics2_weights(arch, seed=426, dtype=torch.bfloat16, device=DEV), arch.num_layers)
     w = Idefics2Weights(sd, arch, DEV)
     del sd
     torch.cuda.empty_cache()
@@ -124,8 +135,9 @@ def test_fullsize_idefics2_properties():
     for b in (0, 3):
         one = {k: v[b:b + 1].contiguous() for k, v in batch.items()}
         alone = eng.forward(**one, icv=scaled, hook_layers=layers)
-        d = alone[0].float() - lg[b].float()              # one-ulp differences in 32 down-projections, amplified by 32 random layers
-        assert float(d.norm() / lg[b].float().norm()) <= 6e-2 and float(d.abs().max()) <= 0.15 * scale
+        d = alone[0].float() - lg[b].float()              # one-ulp differences in 32 down-projections
+        print(f"\n  P2 idefics2-8b row {b}: alone vs in-batch (split-K on): relative L2 {float(d.norm() / lg[b].float().norm()):.2e}, max {float(d.abs().max()) / scale:.2e} of scale")
+        assert float(d.norm() / lg[b].float().norm()) <= P2_REL and float(d.abs().max()) <= P2_MAX * scale
         try:
             ops.SPLITK = False
             alone = eng.forward(**one, icv=scaled, hook_layers=layers)
@@ -181,3 +193,40 @@ def test_fullsize_training_micro_batch_properties(full):
         assert d_icv <= spec["icv_lr"] * lam * 1.01 + 1e-12 and d_alpha <= spec["alpha_lr"] * lam * 1.05 + 1e-12
         assert (lam == 0.0 and d_icv == 0.0) if step == 0 else (lam > 0.0 and d_icv > 0.0 and d_alpha > 0.0)
         assert log["grad_norm"] > 0 and log["kl_loss"] == log["loss"]
+
+
+def test_fullsize_idefics2_fp8_32shot_properties():
+    """BASELINE configs[4] shape: Idefics2-8B at FULL depth, 32 shots (33 images of 378 x 504 per question, S = 2900), text stack on
+    fp8 operands; two questions (the bench runs eight).  No reference has an fp8 mode, so at this size: F1 two runs are
+    bit-identical; F2 every logit is finite and the hook still preserves the norm of every token's MLP branch and promotes the
+    stream; F3 the fp8 logits stay within the quantisation-noise bar of the bf16 engine on the same weights (per-position cosine,
+    printed with the relative L2); F4 all four projections of every text layer carry fp8 weights."""
+    from licv.config import IDEFICS2_8B
+    from licv.idefics2_engine import Idefics2Engine, Idefics2Weights
+    from licv.synthetic import synth_idefics2_weights, synth_vqa_batch_idefics2
+    arch = IDEFICS2_8B
+    sd = trained_like_(synth_idefics2_weights(arch, seed=426, dtype=torch.bfloat16, device=DEV), arch.num_layers)
+    e8 = Idefics2Engine(Idefics2Weights(sd, arch, DEV, fp8_text=True))
+    e16 = Idefics2Engine(Idefics2Weights(sd, arch, DEV))
+    del sd
+    torch.cuda.empty_cache()
+    assert all(set(L.q8) == {"qkv_w", "o_w", "gu_w", "down_w"} for L in e8.w.text)                     # F4
+    batch = synth_vqa_batch_idefics2(arch, 2, 2900, 33, 378, 504, seed=426, min_len=2800, dtype=torch.bfloat16, device=DEV, ragged=False)
+    icv, alpha = synth_icv(arch.num_layers, arch.hidden_size, seed=426, alpha=0.1, device=DEV)
+    layers = list(range(arch.num_layers))
+    scaled = alpha.unsqueeze(-1) * icv
+    img = e8.encode_images(batch["pixel_values"], batch["pixel_attention_mask"])                        # the vision side is bf16 in both
+    ins = dict(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], image_hidden_states=img)
+    cap = {}
+    lg8 = e8.forward(**ins, icv=scaled, hook_layers=layers, capture=cap).clone()
+    assert torch.isfinite(lg8.float()).all()                                                              # F2
+    assert all(t.dtype == torch.float32 for t in cap["layer_out"]) and cap["mlp_raw"][0].dtype == torch.bfloat16
+    del cap
+    assert torch.equal(lg8, e8.forward(**ins, icv=scaled, hook_layers=layers))                           # F1
+    lg16 = e16.forward(**ins, icv=scaled, hook_layers=layers)
+    valid = batch["attention_mask"].bool()
+    a, b = lg16.float()[valid], lg8.float()[valid]
+    rel = float((a - b).norm() / a.norm())
+    cos = torch.nn.functional.cosine_similarity(a, b, dim=-1)
+    print(f"\n  F3 idefics2-8b 32-shot, fp8 text stack vs bf16 engine at full depth: relative L2 {rel:.3f}, cosine min {float(cos.min()):.4f} mean {float(cos.mean()):.4f}")
+    assert rel <= F3_REL and float(cos.min()) >= F3_COS                                                  # F3

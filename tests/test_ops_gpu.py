@@ -314,6 +314,18 @@ def _ref_attn(q, k, v, mask, scale):
     return (p @ v.float())
 
 
+def _attn_close(out, ref):
+    """bf16 output, bf16 probabilities into the PV MFMA, fp32 accumulators: measured on MI355X (hd 16..128, S 150/800, all mask
+    modes) max error 1.4e-3 .. 3.4e-3 of max|ref| and <= 1.28 of the element-wise unit |ref| 2^-8 + max|ref| 2^-10.
+    Bars = ~2x measured."""
+    out, ref = out.float().cpu(), ref.float()
+    e = (out - ref).abs()
+    top = ref.abs().max()
+    assert float(e.max()) <= 6e-3 * float(top), float(e.max() / top)
+    unit = ref.abs() * 2.0 ** -8 + top * 2.0 ** -10
+    assert float((e / unit).max()) <= 2.5, float((e / unit).max())
+
+
 @pytest.mark.parametrize("hd", [8, 16, 64, 80, 96, 128])
 @pytest.mark.parametrize("mode", ["none", "causal", "keypad"])
 def test_attention_self(hd, mode):
@@ -334,8 +346,7 @@ def test_attention_self(hd, mode):
     d = qkv.to(DEV)
     out = ops().attention(d, d.view(-1)[H:], d.view(-1)[2 * H:], B, S, S, nh, nh, hd, S * 3 * H, 3 * H, S * 3 * H, 3 * H,
                           hd ** -0.5, {"none": 0, "causal": 1, "keypad": 2}[mode], key_valid=valid.to(DEV))
-    err = (out.float().cpu() - ref).abs().max()
-    assert err <= 2e-2 * ref.abs().max(), err
+    _attn_close(out, ref)
 
 
 @pytest.mark.parametrize("hd,S,Sq", [(80, 257, 257), (96, 321, 64), (64, 200, 130)])
@@ -358,7 +369,7 @@ def test_attention_resident_kv_variant_matches_tiled_and_reference(hd, S, Sq):
     finally:
         _lib.lib().licv_attn_select(0)
     for o in outs:
-        assert (o.float().cpu() - ref).abs().max() <= 2e-2 * ref.abs().max()
+        _attn_close(o, ref)
     assert (outs[0].float() - outs[1].float()).abs().max() <= 2 ** -7 * ref.abs().max()
 
 
@@ -378,7 +389,7 @@ def test_attention_cross_image_mask_and_gqa_decode():
     dq, dkv = q.to(DEV), kv.to(DEV)
     out = ops().attention(dq, dkv, dkv.view(-1)[nh * hd:], B, Sq, Sk, nh, nh, hd, Sq * nh * hd, nh * hd, Sk * 2 * nh * hd,
                           2 * nh * hd, hd ** -0.5, 3, img_mask=im.to(DEV), img_len=img_len)
-    assert (out.float().cpu() - ref).abs().max() <= 2e-2 * ref.abs().max()
+    _attn_close(out, ref)
     assert out[:, :5].abs().max() == 0
     # tile-uniform image mask path (img_len % 64 == 0) + GQA + causal decode offset (Sq < Sk)
     B, Sq, Sk, nh, nkv, hd = 2, 3, 200, 8, 2, 64
@@ -392,7 +403,7 @@ def test_attention_cross_image_mask_and_gqa_decode():
     ref = _ref_attn(qh, kh, vh, mask, 0.125).transpose(1, 2).reshape(B, Sq, nh * hd)
     out = ops().attention(q.to(DEV), k.to(DEV), v.to(DEV), B, Sq, Sk, nh, nkv, hd, Sq * nh * hd, nh * hd, Sk * nkv * hd,
                           nkv * hd, 0.125, 1)
-    assert (out.float().cpu() - ref).abs().max() <= 2e-2 * ref.abs().max()
+    _attn_close(out, ref)
     B, Sq, n_img, img_len, nh, hd = 1, 9, 2, 64, 2, 128
     Sk = n_img * img_len
     q = torch.randn(B, Sq, nh * hd, generator=g(47)).to(torch.bfloat16)
@@ -404,7 +415,7 @@ def test_attention_cross_image_mask_and_gqa_decode():
     dkv = kv.to(DEV)
     out = ops().attention(q.to(DEV), dkv, dkv.view(-1)[nh * hd:], B, Sq, Sk, nh, nh, hd, Sq * nh * hd, nh * hd,
                           Sk * 2 * nh * hd, 2 * nh * hd, hd ** -0.5, 3, img_mask=im.to(DEV), img_len=img_len)
-    assert (out.float().cpu() - ref).abs().max() <= 2e-2 * ref.abs().max()
+    _attn_close(out, ref)
 
 
 def test_attention_softmax_rescale_branch_forced():
@@ -416,7 +427,7 @@ def test_attention_softmax_rescale_branch_forced():
     k[0, 250] = (q[0, 10].float() * 3).to(torch.bfloat16)
     ref = _ref_attn(q[:, None], k[:, None], v[:, None], None, hd ** -0.5)[:, 0]
     out = ops().attention(q.to(DEV), k.to(DEV), v.to(DEV), B, S, S, 1, 1, hd, S * hd, hd, S * hd, hd, hd ** -0.5, 0)
-    assert (out.float().cpu() - ref).abs().max() <= 2e-2 * ref.abs().max()
+    _attn_close(out, ref)
 
 
 # ------------------------------------------------------------------------------------------- gathers
