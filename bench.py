@@ -224,6 +224,7 @@ def main():
     ap.add_argument("--no-gpu-baseline", action="store_true", help="skip the unfused PyTorch-ROCm run of the oracle on the GPU (row G0)")
     ap.add_argument("--no-hooks", action="store_true", help="teacher shape: same forward with the intervention off")
     ap.add_argument("--no-profiler", action="store_true", help="no per-launch event pairs: the language stack then runs through the native layer runner")
+    ap.add_argument("--gemm-select", type=int, default=0, help="diagnostic A/B only: force a GEMM kernel variant (licv_gemm_select); 0 = the library's own choice")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; default).  'gloo' only to rehearse the multi-rank code path "
                     "on a box with fewer GPUs than ranks (ranks then share devices: timings are meaningless)")
     args = ap.parse_args()
@@ -257,6 +258,9 @@ def main():
             dist.init_process_group(args.dist_backend)
 
     from licv import ops
+    if args.gemm_select:
+        from licv import _lib
+        _lib.lib().licv_gemm_select(args.gemm_select)
     from licv.config import idefics_arch
     from licv.idefics_engine import IdeficsEngine, IdeficsWeights
     from licv.roofline import PEAK_BF16_TFLOPS, PEAK_HBM_GBS, flops_per_question, inject_bytes_per_question

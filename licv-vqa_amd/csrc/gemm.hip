@@ -393,10 +393,6 @@ __device__ __forceinline__ void epilogue_rows(const GemmEpi& ep, void* __restric
 // timing-only instrumentation (tools/gemm_phases.py): when set, wave 0 of every pingpong workgroup records
 // wall_clock64() at [0] start, [1] stage 0 published, [2] main loop done, [3] output image in LDS, [4] end
 __device__ long long* g_dbg_ts = nullptr;
-// experiment knob (licv_gemm_experiment knob 3): wave-priority scheme of the ping-pong main loop
-//   0 = priority 1 around each MFMA cluster (the round-1 scheme)   1 = no priority changes
-//   2 = priority 1 during the LOAD phase instead                   3 = static: the trailing waves 4-7 run at priority 1 throughout
-__device__ int g_prio_mode = 0;
 extern "C" int licv_gemm_debug_timestamps(void* dev_buffer) {
     long long* p = (long long*)dev_buffer;
     return hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_ts), &p, sizeof(p)) == hipSuccess ? LICV_OK : LICV_E_HIP;
@@ -711,14 +707,11 @@ void gemm_bf16_pingpong_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_
     unsigned long long stamp[8];
     const int probe = (ABL == 6 && g_dbg_ts) ? ns / 2 : -1;
 #define STAMP(i) do { if (ABL == 6 && s == probe) { __builtin_amdgcn_sched_barrier(0); stamp[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
-    const int prio_mode = __builtin_amdgcn_readfirstlane(g_prio_mode);
-    if (prio_mode == 3 && wm == 1) __builtin_amdgcn_s_setprio(1);
     for (int s = 0; s < ns; ++s) {
         // ---- LOAD phase (partner computes)
         {
             const char* sa = smem + (s % RING_STAGES) * RING_STAGE_BYTES + (wm * 128) * 64 + fo;
             const char* sw = smem + (s % RING_STAGES) * RING_STAGE_BYTES + 16384 + (wn * 64) * 64 + fo;
-            if (prio_mode == 2) __builtin_amdgcn_s_setprio(1);
             STAMP(0);
             if (ABL != 3 || s == 0) {                            // ABL 3 (timing only): fragments read once, never again
 #pragma unroll
@@ -735,12 +728,11 @@ void gemm_bf16_pingpong_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_
             __builtin_amdgcn_sched_barrier(0);
             STAMP(4);
         }
-        if (prio_mode == 2) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_s_barrier();
         STAMP(5);
         // ---- COMPUTE phase (partner loads)
         __builtin_amdgcn_sched_barrier(0);
-        if (prio_mode == 0) __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_s_setprio(1);
         if (ABL != 4) {                                          // ABL 4 (timing only): no MFMAs
 #pragma unroll
             for (int i = 0; i < 8; ++i)
@@ -753,18 +745,18 @@ void gemm_bf16_pingpong_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_
 #pragma unroll
             for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(fw[j]));
         }
-        if (prio_mode == 0) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         STAMP(6);
         __builtin_amdgcn_s_barrier();
         STAMP(7);
-        if (ABL == 6 && s == probe && lane == 0) {
-            long long* o = g_dbg_ts + ((int64_t)blockIdx.x * 8 + wave) * 8;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) o[i] = (long long)stamp[i];
-        }
     }
 #undef STAMP
+    if (ABL == 6 && probe >= 0 && lane == 0) {                    // after the loop: a store inside it would sit on the counted vmcnt
+        long long* o = g_dbg_ts + ((int64_t)blockIdx.x * 8 + wave) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (long long)stamp[i];
+    }
     if (wm == 0) __builtin_amdgcn_s_barrier();               // leading group: match the barrier count
     if (ts) ts[2] = wall_clock64();
     if (ABL == 1) {
@@ -775,6 +767,178 @@ void gemm_bf16_pingpong_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_
         return;
     }
     if (ABL == 5) {                                          // fp32 partial tile -> this split's workspace slice
+        const int64_t np = (int64_t)tiles_n * 256;
+        float* slice = reinterpret_cast<float*>(C) + (int64_t)blockIdx.y * ((int64_t)tiles_m * 256) * np;
+        const int rl = m0 + wm * 128 + (lane & 15), c0 = n0 + wn * 64 + (lane >> 4) * 4;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<floatx4*>(slice + (int64_t)(rl + i * 16) * np + c0 + j * 16) = acc[i][j];
+        return;
+    }
+    epilogue_staged<256, 256, 8, 8, 4>(acc, ep, C, ldc, M, N, m0, n0, wm * 128, wn * 64, wave, lane, smem, ts);
+    if (ts) ts[4] = wall_clock64();
+}
+
+// ------------------------------------------------------------------------------------------------
+// "lean" ping-pong kernel: the ping-pong schedule, ring and K order unchanged (bit-identical results), with the per-stage
+// overhead of the LOAD phase taken out.  The stamped timeline of the kernel above (tools/gemm_segments.py) shows where a stage
+// goes: the interval in which the trailing group loads is 870 cycles against 700 for the other one — a wave that begins its
+// load phase just as its SIMD partner begins an MFMA burst loses ~140 cycles before its first LDS read issues, and that head
+// was vector-ALU address arithmetic (two 32-bit adds per fragment base, a 64-bit add per DMA piece) plus a chain of scalar
+// branches for the counted wait.  Here
+//   * a DMA piece is `global_load_lds  v_offset, s[base:base+1]`: the lane part (row * ld + chunk, loop-invariant, 32-bit) stays
+//     in a VGPR and the K advance is scalar — no vector ALU per piece;
+//   * the fragment-read base of stage s+1 is formed at the END of stage s's compute phase (inside the wave's own priority
+//     window), so a load phase starts with its ds_reads;
+//   * the steady-state loop (s + 4 < ns) has no data-dependent branch: issue 4 pieces, `s_waitcnt vmcnt(12)`; only the last
+//     four stages run the variable wait.
+// SPLITK = 1 is the split-K producer (blockIdx.y selects `group` stages; C is the fp32 workspace, [split][M_pad][N_pad]).
+// ------------------------------------------------------------------------------------------------
+template <int SPLITK, int VAR = 0>     // VAR: load-phase order experiments (1: counted wait before the DMA issue, 2: DMA before the reads)
+__global__ __launch_bounds__(512, 2)
+void gemm_bf16_lean_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw,
+                      void* __restrict__ C, int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n, GemmEpi ep, int group) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // [5 stages][A 16 KiB | W 16 KiB]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;                         // waves 0-3 lead, 4-7 trail by half a stage
+    // VAR 8 (diagnostic build): lane 0 of wave 0 records the 100 MHz wall clock at the tile's phase boundaries (slots 0-4, as the
+    // ping-pong kernel does) and the shader clock around the main loop (slots 5, 6) into g_dbg_ts[block * 8 ...]
+    long long* ts = (VAR == 8 && g_dbg_ts && tid == 0) ? g_dbg_ts + (int64_t)blockIdx.x * 8 : nullptr;
+    if (ts) ts[0] = wall_clock64();
+    int tm, tn;
+    tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn, SPLITK ? 8 : group);
+    const int m0 = tm * 256, n0 = tn * 256;
+    const int kbase = SPLITK ? (int)blockIdx.y * group : 0;
+    const int ns = SPLITK ? min(group, K / 32 - kbase) : K / 32;     // >= 4, host-guaranteed
+
+    // DMA sources: wave-uniform corner of the tile (scalar registers) + a per-lane byte offset that never changes
+    uint32_t offA[2], offW[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = wave * 32 + i * 16 + (lane >> 2);
+        const int chunk = (lane & 3) ^ (((row >> 2) & 1) << 1);
+        offA[i] = (uint32_t)(min(row, M - 1 - m0) * (int)lda * 2 + chunk * 16);      // rows past M / N re-read the last valid row
+        offW[i] = (uint32_t)(min(row, N - 1 - n0) * (int)ldw * 2 + chunk * 16);
+    }
+    const char* gA = reinterpret_cast<const char*>(A + (int64_t)m0 * lda + (int64_t)kbase * 32);
+    const char* gW = reinterpret_cast<const char*>(W + (int64_t)n0 * ldw + (int64_t)kbase * 32);
+    auto issue = [&](int s, int slot_bytes) {
+        char* sa = smem + slot_bytes + wave * 2048;
+        const char* a = gA + (int64_t)s * 64;
+        const char* w = gW + (int64_t)s * 64;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a + offA[i]),
+                                             (__attribute__((address_space(3))) void*)(sa + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w + offW[i]),
+                                             (__attribute__((address_space(3))) void*)(sa + 16384 + i * 1024), 16, 0, 0);
+        }
+    };
+
+    floatx4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    const int fo = ring_off(lane & 15, lane >> 4);
+    const int constA = wm * 8192 + fo, constW = 16384 + wn * 4096 + fo;
+    bf16x8 fa[8], fw[4];
+
+    issue(0, 0); issue(1, RING_STAGE_BYTES); issue(2, 2 * RING_STAGE_BYTES); issue(3, 3 * RING_STAGE_BYTES);
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");        // my pieces of stage 0 have landed
+    __builtin_amdgcn_s_barrier();                            // stage 0 published
+    if (ts) { ts[1] = wall_clock64(); ts[5] = (long long)__builtin_amdgcn_s_memtime(); }
+    if (wm == 1) __builtin_amdgcn_s_barrier();               // trailing group starts half a stage later
+
+    int slot_rd = 0, slot_wr = 4 * RING_STAGE_BYTES;         // ring slots (byte offsets) of stage s and of stage s + 4
+    typedef const __attribute__((address_space(3))) char* lds_cptr;
+    typedef const __attribute__((address_space(3))) bf16x8* lds_fptr;
+    const lds_cptr ring = (lds_cptr)smem;
+    lds_cptr rdA = ring + constA, rdW = ring + constW;       // fragment-read bases of the stage about to be read
+    // VAR 9 (diagnostic build, results unaffected): s_memtime stamps around the segments of ONE mid-loop stage, as in the kernel above
+    unsigned long long stamp[8];
+    const int probe = (VAR == 9 && g_dbg_ts) ? ns / 2 : -1;
+#define STAMP(i) do { if (VAR == 9 && s == probe) { __builtin_amdgcn_sched_barrier(0); stamp[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+    // VAR 7 (diagnostic build): a time series — lane l of every wave keeps the shader clock at the start of stage l * series_stride
+    // (one v_cndmask per stamp, no memory traffic inside the loop); written to g_dbg_ts[(block * 8 + wave) * 64 + l] after the loop
+    uint32_t series = 0;
+    const int series_stride = (VAR == 7 && g_dbg_ts) ? (ns + 63) / 64 : 0;
+    int series_next = 0, series_lane = 0;
+    auto stage = [&](int s, auto steady_c) {
+        constexpr bool STEADY = decltype(steady_c)::value;
+        if (VAR == 7 && series_stride && s == series_next) {
+            { const uint32_t now = (uint32_t)__builtin_amdgcn_s_memtime(); series = lane == series_lane ? now : series; }
+            series_next += series_stride; ++series_lane;
+        }
+        STAMP(0);
+        // ---- LOAD phase (partner computes)
+        {
+            if (VAR == 2 && STEADY) { issue(s + 4, slot_wr); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fw[j] = *(lds_fptr)(rdW + j * 16 * 64);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) fa[i] = *(lds_fptr)(rdA + i * 16 * 64);
+            __builtin_amdgcn_sched_barrier(0);
+            STAMP(1);
+            if (VAR == 9 && STEADY) {
+                issue(s + 4, slot_wr);
+                STAMP(2);
+                asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                STAMP(3);
+            } else if (STEADY && VAR == 1) {
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                issue(s + 4, slot_wr);
+            } else if (STEADY) {
+                if (VAR != 2) issue(s + 4, slot_wr);
+                asm volatile("s_waitcnt vmcnt(12)" ::: "memory");    // retires my pieces of stage s+1; s+2 .. s+4 stay in flight
+            } else {
+                wait_vmcnt(4 * max(0, min(3, ns - 2 - s)));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            STAMP(4);
+        }
+        __builtin_amdgcn_s_barrier();
+        STAMP(5);
+        // ---- COMPUTE phase (partner loads)
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        slot_wr = slot_rd;                                           // the slot just consumed is the next one refilled
+        slot_rd = slot_rd == 4 * RING_STAGE_BYTES ? 0 : slot_rd + RING_STAGE_BYTES;
+        rdA = ring + (constA + slot_rd);
+        rdW = ring + (constW + slot_rd);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(0);
+        STAMP(6);
+        __builtin_amdgcn_s_barrier();
+        STAMP(7);
+    };
+    int s = 0;
+    for (; s + 4 < ns; ++s) stage(s, std::true_type{});
+    for (; s < ns; ++s) stage(s, std::false_type{});
+#undef STAMP
+    if (VAR == 7 && series_stride) {
+        { const uint32_t now = (uint32_t)__builtin_amdgcn_s_memtime(); series = lane == series_lane ? now : series; }     // end of the loop
+        g_dbg_ts[((int64_t)blockIdx.x * 8 + wave) * 64 + lane] = lane <= series_lane ? (long long)series : -1;
+    }
+    if (VAR == 9 && probe >= 0 && lane == 0) {
+        long long* o = g_dbg_ts + ((int64_t)blockIdx.x * 8 + wave) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (long long)stamp[i];
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();               // leading group: match the barrier count
+    if (ts) { ts[2] = wall_clock64(); ts[6] = (long long)__builtin_amdgcn_s_memtime(); }
+    if (SPLITK) {                                            // fp32 partial tile -> this split's workspace slice
         const int64_t np = (int64_t)tiles_n * 256;
         float* slice = reinterpret_cast<float*>(C) + (int64_t)blockIdx.y * ((int64_t)tiles_m * 256) * np;
         const int rl = m0 + wm * 128 + (lane & 15), c0 = n0 + wn * 64 + (lane >> 4) * 4;
@@ -1178,7 +1342,13 @@ void gemm_bf16_flow_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* _
     const int fo = ring_off(lane & 15, lane >> 4);
     constexpr int NST = (EPI == 4) ? 8 : 16;                 // epilogue store instructions per wave and tile
     const auto crs = __builtin_amdgcn_make_buffer_rsrc((void*)C, 0, (int)((int64_t)M * ldc * 2), 0x00020000);
+    typedef const __attribute__((address_space(3))) char* lds_cptr;
+    typedef const __attribute__((address_space(3))) bf16x8* lds_fptr;
+    const lds_cptr ring = (lds_cptr)smem;
+    const int constA = wm * 8192 + fo, constW = 16384 + wn * 4096 + fo;
 
+    // DMA sources (lean form, see gemm_bf16_lean_k): the K position advances with the pointers, which are stepped inside the
+    // compute phase; a load phase carries no vector-ALU address arithmetic
     const bf16_t* srcA[2];
     const bf16_t* srcW[2];
     int m0 = 0, n0 = 0;
@@ -1194,23 +1364,28 @@ void gemm_bf16_flow_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* _
             srcW[i] = W + (int64_t)min(n0 + row, N - 1) * ldw + chunk * 8;
         }
     };
-    auto issue = [&](int s) {
-        char* sa = smem + (s % RING_STAGES) * RING_STAGE_BYTES + wave * 32 * 64;
-        char* sw = sa + 16384;
-        const int64_t koff = (int64_t)s * 32;
+    auto issue = [&](int slot_bytes) {                       // the next K stage of the current source pointers -> ring slot
+        char* sa = smem + slot_bytes + wave * 2048;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + koff),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcA[i],
                                              (__attribute__((address_space(3))) void*)(sa + i * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[i] + koff),
-                                             (__attribute__((address_space(3))) void*)(sw + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcW[i],
+                                             (__attribute__((address_space(3))) void*)(sa + 16384 + i * 1024), 16, 0, 0);
         }
+    };
+    auto advance = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { srcA[i] += 32; srcW[i] += 32; }
+    };
+    auto fill4 = [&]() {
+        issue(0); advance(); issue(RING_STAGE_BYTES); advance(); issue(2 * RING_STAGE_BYTES); advance(); issue(3 * RING_STAGE_BYTES); advance();
     };
 
     int tile = blockIdx.x;
     if (tile >= ntiles) return;
     set_tile(tile);
-    issue(0); issue(1); issue(2); issue(3);
+    fill4();
     int extra4 = 0;                                          // (stores of the previous tile still queued behind stages 0-3) / 4
     for (;;) {
         const int cm0 = m0, cn0 = n0;                        // coordinates of the tile being computed
@@ -1223,17 +1398,23 @@ void gemm_bf16_flow_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* _
         wait_vmcnt4(3 + extra4);                             // my pieces of stage 0 have landed
         __builtin_amdgcn_s_barrier();                        // stage 0 published
         if (wm == 1) __builtin_amdgcn_s_barrier();           // trailing group starts half a stage later
-        for (int s = 0; s < ns; ++s) {
+        int slot_rd = 0, slot_wr = 4 * RING_STAGE_BYTES;
+        lds_cptr rdA = ring + constA, rdW = ring + constW;
+        // KIND 0: first three stages of a tile (the previous tile's stores are still queued behind stages 0-3: vmcnt(12 + NST));
+        // KIND 1: steady state (issue + vmcnt(12), no data-dependent branch); KIND 2: last four stages (nothing left to issue)
+        auto stage = [&](int s, auto kind_c) {
+            constexpr int KIND = decltype(kind_c)::value;
             {
-                const char* sa = smem + (s % RING_STAGES) * RING_STAGE_BYTES + (wm * 128) * 64 + fo;
-                const char* sw = smem + (s % RING_STAGES) * RING_STAGE_BYTES + 16384 + (wn * 64) * 64 + fo;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) fw[j] = *reinterpret_cast<const bf16x8*>(sw + j * 16 * 64);
+                for (int j = 0; j < 4; ++j) fw[j] = *(lds_fptr)(rdW + j * 16 * 64);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 64);
-                if (s + 4 < ns) issue(s + 4);
+                for (int i = 0; i < 8; ++i) fa[i] = *(lds_fptr)(rdA + i * 16 * 64);
+                __builtin_amdgcn_sched_barrier(0);
+                if (KIND != 2) issue(slot_wr);
                 // retire my pieces of stage s+1; stages 0-3 were issued BEFORE the previous tile's stores, stage 4 onwards behind them
-                wait_vmcnt4(max(0, min(3, ns - 2 - s)) + (s <= 2 ? extra4 : 0));
+                if (KIND == 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                else if (KIND == 0) wait_vmcnt4(3 + extra4);
+                else wait_vmcnt4(max(0, min(3, ns - 2 - s)) + (s <= 2 ? extra4 : 0));
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1245,16 +1426,26 @@ void gemm_bf16_flow_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* _
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
+            slot_wr = slot_rd;
+            slot_rd = slot_rd == 4 * RING_STAGE_BYTES ? 0 : slot_rd + RING_STAGE_BYTES;
+            rdA = ring + (constA + slot_rd);
+            rdW = ring + (constW + slot_rd);
+            if (KIND != 2) advance();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_s_barrier();
-        }
+        };
+        int s = 0;
+        for (; s < 3 && s + 4 < ns; ++s) stage(s, std::integral_constant<int, 0>{});
+        for (; s + 4 < ns; ++s) stage(s, std::integral_constant<int, 1>{});
+        for (; s < ns; ++s) stage(s, std::integral_constant<int, 2>{});
         if (wm == 0) __builtin_amdgcn_s_barrier();           // leading group: match the barrier count
         // every wave retired its last fragment reads (lgkmcnt(0)) before that barrier: the whole ring is free
 
         const int next = tile + gridDim.x;
         const bool more = next < ntiles;
-        if (more) { set_tile(next); issue(0); issue(1); issue(2); issue(3); }
+        if (more) { set_tile(next); fill4(); }
         __builtin_amdgcn_sched_barrier(0);
 
         // ---- register-direct epilogue of tile (cm0, cn0)
@@ -1689,14 +1880,17 @@ static int g_stagger = 0;        // per-XCD start stagger of the persistent kern
 // (A rotated K traversal per tile was also tried: -3 ... -25 %, lockstep K sweeps are what makes L2 sharing work.)
 static int g_pp_stagger = 0;
 static int g_pp_group = 0;      // experiment knob: tile-rows per XCD patch group (0 = heuristic)
+static int g_splitk_enabled = 1;
 static int g_flow_default = 1;  // auto mode takes the flow kernel where it is eligible and measured faster (knob 2 of licv_gemm_experiment)
 extern "C" int licv_gemm_stagger(int on) { g_stagger = on; return LICV_OK; }
 // A/B timing knobs of the default (ping-pong) kernel, all measured neutral-to-negative and off by default:
 //   knob 0: per-XCD first-round start stagger, percent of an eighth of the estimated tile time (0 = off)
 //   knob 1: tile-rows per XCD patch group (0 = the default 8)
+//   knob 2: 0 = never take the flow kernel by default;  knob 4: 0 = licv_gemm_splitk_plan always answers "one pass" (the
+//   batch-independence tests switch split-K off for every caller, the native layer runner included)
 extern "C" int licv_gemm_experiment(int knob, int value) {
     if (knob == 0) g_pp_stagger = value; else if (knob == 1) g_pp_group = value; else if (knob == 2) g_flow_default = value;
-    else if (knob == 3) return hipMemcpyToSymbol(HIP_SYMBOL(g_prio_mode), &value, sizeof(int)) == hipSuccess ? LICV_OK : LICV_E_HIP;
+    else if (knob == 4) g_splitk_enabled = value;
     else return licv_set_error(LICV_E_BADARG, "gemm_experiment: unknown knob %d", knob);
     return LICV_OK;
 }
@@ -1770,7 +1964,7 @@ extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
     const bool use256 = g_force_kernel >= 2 ? can256 : (g_force_kernel == 1 ? false : big);
     // auto mode takes it where it measured faster than the staged epilogue: short K (the epilogue is a large share of the tile:
     // ViT QKV / fc1, cross-attention K|V; +3-5 %), not the K = 4096 shapes (-4 ... 0 %)
-    const bool flow_auto = g_flow_default && K <= 2048 && !e->swiglu;
+    const bool flow_auto = g_flow_default != 0;
     if (use256 && flow_ok && flow_scratch_free() && (g_force_kernel == 20 || (g_force_kernel == 0 && flow_auto))) {
         const int tiles_m = (int)((M + 255) / 256), tiles_n = (int)((N + 255) / 256);
         const int pp_group = g_pp_group > 0 ? g_pp_group : (tiles_n <= 6 ? 2 : 8);
@@ -1795,6 +1989,7 @@ extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
         // tile-rows per XCD patch: 8 (a 32-CU XCD then works on an 8 x 4 patch); with <= 6 tile-columns an 8-row group is 40-48
         // tiles and the patch straddles two groups -> 2-row groups keep it compact (measured +6 % at N = 1280, K = 5120)
         const int pp_group = g_pp_group > 0 ? g_pp_group : (tiles_n <= 6 ? 2 : 8);
+        const bool lean_ok = lda * 510 < (1ll << 31) && ldw * 510 < (1ll << 31);     // 32-bit lane offsets of the DMA sources
         const int pp_ticks = (g_pp_stagger > 0 && tiles_m * tiles_n >= 2 * g_num_cus)
                                  ? (int)(((K / 32) * 85 + 1500) / 8 * g_pp_stagger / 100) : 0;
 #define LAUNCH256(ABL) gemm_bf16_tile256_k<ABL><<<grid, block, T256_LDS, (hipStream_t)stream>>>( \
@@ -1824,6 +2019,22 @@ extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
             gemm_bf16_pair_k<<<grid, block, RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>(
                 (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, pp_group);
         }
+        else if (g_force_kernel >= 22 && g_force_kernel <= 27 && K >= 128 && lean_ok) {
+            static bool a22 = false;
+            if (!a22) {
+                (void)hipFuncSetAttribute((const void*)gemm_bf16_lean_k<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
+                (void)hipFuncSetAttribute((const void*)gemm_bf16_lean_k<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
+                (void)hipFuncSetAttribute((const void*)gemm_bf16_lean_k<0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
+                (void)hipFuncSetAttribute((const void*)gemm_bf16_lean_k<0, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
+                (void)hipFuncSetAttribute((const void*)gemm_bf16_lean_k<0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
+                (void)hipFuncSetAttribute((const void*)gemm_bf16_lean_k<0, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
+                a22 = true;
+            }
+#define LEAN(V) gemm_bf16_lean_k<0, V><<<grid, block, RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>( \
+                (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, pp_group)
+            if (g_force_kernel == 22) LEAN(0); else if (g_force_kernel == 23) LEAN(1); else if (g_force_kernel == 24) LEAN(2); else if (g_force_kernel == 25) LEAN(9); else if (g_force_kernel == 26) LEAN(8); else LEAN(7);
+#undef LEAN
+        }
         else if (g_force_kernel == 6 && K >= 128)
             gemm_bf16_pingpong_k<0><<<grid, block, RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>(
                 (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, pp_ticks, pp_group);
@@ -1832,7 +2043,13 @@ extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
                 (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep,
                 // one tile ~ K/32 stages x ~1300 cycles; s_sleep 64 = 4096 cycles; an eighth of a tile per XCD group
                 (tiles_m * tiles_n > g_num_cus && g_stagger) ? (int)((K / 32) * 1300 / 8 / 4096 + 1) : 0);
-        else if ((g_force_kernel == 0 || g_force_kernel == 9 || g_force_kernel == 20) && K >= 128)
+        else if ((g_force_kernel == 0 || g_force_kernel == 20) && K >= 128 && lean_ok) {
+            static bool a0 = false;
+            if (!a0) { (void)hipFuncSetAttribute((const void*)gemm_bf16_lean_k<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES); a0 = true; }
+            gemm_bf16_lean_k<0, 0><<<grid, block, RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>(
+                (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, pp_group);
+        }
+        else if ((g_force_kernel == 0 || g_force_kernel == 9 || g_force_kernel == 20 || (g_force_kernel >= 22 && g_force_kernel <= 27)) && K >= 128)
             gemm_bf16_pingpong_k<0><<<grid, block, RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>(
                 (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, pp_ticks, pp_group);
         else LAUNCH256(0);
@@ -1850,6 +2067,7 @@ extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
 extern "C" int licv_gemm_splitk_plan(int64_t M, int64_t N, int64_t K, int* splits, int64_t* workspace_bytes) {
     LICV_CHECK_ARG(splits && workspace_bytes, "gemm_splitk_plan: null pointer");
     *splits = 1; *workspace_bytes = 0;
+    if (!g_splitk_enabled) return LICV_OK;
     if (M > 256) {
         // few 256 x 256 tiles and a long K (Idefics2 1-shot down-projection: 1376 x 4096 x 14336 = 96 tiles on 256 CUs, 257 us):
         // the ping-pong kernel itself produces the partials (workspace padded to 256)
@@ -1965,11 +2183,19 @@ extern "C" int licv_gemm_bf16_splitk(const void* A, int64_t lda, const void* W, 
     hipStream_t st = (hipStream_t)stream;
     if (big) {
         static bool attr5 = false;
-        if (!attr5) { (void)hipFuncSetAttribute((const void*)gemm_bf16_pingpong_k<5>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES); attr5 = true; }
+        if (!attr5) {
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_pingpong_k<5>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_lean_k<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
+            attr5 = true;
+        }
         const int t256m = (int)(mp / 256), t256n = (int)(npad / 256);
         const int stages = (int)(K / 32), per32 = (stages + splits - 1) / splits;
-        gemm_bf16_pingpong_k<5><<<dim3(t256m * t256n, splits), dim3(512), RING_STAGES * RING_STAGE_BYTES, st>>>(
-            (const bf16_t*)A, lda, (const bf16_t*)W, ldw, workspace, 0, (int)M, (int)N, (int)K, t256m, t256n, ep, 0, per32);
+        if (lda * 510 < (1ll << 31) && ldw * 510 < (1ll << 31) && g_force_kernel != 6)
+            gemm_bf16_lean_k<1, 0><<<dim3(t256m * t256n, splits), dim3(512), RING_STAGES * RING_STAGE_BYTES, st>>>(
+                (const bf16_t*)A, lda, (const bf16_t*)W, ldw, workspace, 0, (int)M, (int)N, (int)K, t256m, t256n, ep, per32);
+        else
+            gemm_bf16_pingpong_k<5><<<dim3(t256m * t256n, splits), dim3(512), RING_STAGES * RING_STAGE_BYTES, st>>>(
+                (const bf16_t*)A, lda, (const bf16_t*)W, ldw, workspace, 0, (int)M, (int)N, (int)K, t256m, t256n, ep, 0, per32);
         // the finalize kernel walks 128 x 128 tiles of the same [split][M_pad][N_pad] workspace
         gemm_splitk_finalize_k<<<dim3((int)(mp / 128) * (int)(npad / 128)), dim3(256), 65536, st>>>((const float*)workspace, C, ldc, (int)M, (int)N,
             (int)(mp / 128), (int)(npad / 128), splits, ep, 0);

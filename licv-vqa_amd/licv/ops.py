@@ -157,7 +157,16 @@ def rotary_(buf: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, position_id
 
 
 # ------------------------------------------------------------------------------------------ GEMM
-SPLITK = True               # False: never take the split-K path (A/B timing, kernel-agreement tests)
+SPLITK = True               # False: never take the split-K path (A/B timing, kernel-agreement tests); set through set_splitk()
+
+
+def set_splitk(on: bool) -> None:
+    """Split-K on/off for every caller: this module's linear() and the library's own plan (the native layer runner asks it)."""
+    global SPLITK
+    SPLITK = bool(on)
+    check(_lib.lib().licv_gemm_experiment(4, 1 if on else 0))
+
+
 _plans: dict = {}
 _ws: dict = {}
 

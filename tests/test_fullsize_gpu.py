@@ -92,11 +92,11 @@ def test_fullsize_hook_properties(full):
         print(f"\n  P2 idefics-9b row {b}: alone vs in-batch (split-K on): relative L2 {float(d.norm() / lg[b].float().norm()):.2e}, max {float(d.abs().max()) / scale:.2e} of scale")
         assert float(d.norm() / lg[b].float().norm()) <= P2_REL and float(d.abs().max()) <= P2_MAX * scale
         try:
-            ops.SPLITK = False
+            ops.set_splitk(False)
             alone = eng.forward(**one, icv=scaled, hook_layers=layers)
             whole = eng.forward(**ins, icv=scaled, hook_layers=layers) if b == 0 else whole
         finally:
-            ops.SPLITK = True
+            ops.set_splitk(True)
         assert torch.equal(alone[0], whole[b]), f"row {b} depends on its batch neighbours"
 
 
@@ -139,11 +139,11 @@ def test_fullsize_idefics2_properties():
         print(f"\n  P2 idefics2-8b row {b}: alone vs in-batch (split-K on): relative L2 {float(d.norm() / lg[b].float().norm()):.2e}, max {float(d.abs().max()) / scale:.2e} of scale")
         assert float(d.norm() / lg[b].float().norm()) <= P2_REL and float(d.abs().max()) <= P2_MAX * scale
         try:
-            ops.SPLITK = False
+            ops.set_splitk(False)
             alone = eng.forward(**one, icv=scaled, hook_layers=layers)
             whole = eng.forward(**batch, icv=scaled, hook_layers=layers) if b == 0 else whole
         finally:
-            ops.SPLITK = True
+            ops.set_splitk(True)
         assert torch.equal(alone[0], whole[b]), f"row {b} depends on its batch neighbours"
 
 

@@ -42,7 +42,6 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--iters", type=int, default=8)
     ap.add_argument("--shapes", default="")
-    ap.add_argument("--prio", default="", help="comma list of priority modes (licv_gemm_experiment knob 3) to A/B on the first select value")
     args = ap.parse_args()
     lib = _lib.lib()
     shapes = SHAPES
@@ -57,14 +56,10 @@ def main():
         res16 = torch.randn(M, n_out, device="cuda", generator=g).to(torch.bfloat16) if "res" in epi and "32" not in epi else None
         res32 = torch.randn(M, n_out, device="cuda", generator=g) if "res32" in epi else None
         best, outs = {}, {}
-        variants = args.select if not args.prio else [f"p{m}" for m in args.prio.split(",")]
+        variants = args.select
         for _ in range(args.rounds):
             for sel in variants:
-                if args.prio:
-                    lib.licv_gemm_select(args.select[0])
-                    lib.licv_gemm_experiment(3, int(sel[1:]))
-                else:
-                    lib.licv_gemm_select(sel)
+                lib.licv_gemm_select(sel)
                 for _ in range(2):
                     o = run(M, N, K, epi, a, w, bias, res16, res32)
                 torch.cuda.synchronize()
@@ -87,7 +82,6 @@ def main():
                 best[sel] = max(best.get(sel, 0.0), 2.0 * M * N * K / t / 1e12)
                 outs[sel] = o
         lib.licv_gemm_select(0)
-        lib.licv_gemm_experiment(3, 0)
         first = variants[0]
         same = {s: bool(torch.equal(outs[s], outs[first])) for s in variants}
         print(f"{M:6d} {N:6d} {K:6d} {epi:10s} " + "  ".join(f"{s}: {best[s]:7.1f} TF" for s in variants)
