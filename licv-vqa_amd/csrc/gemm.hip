@@ -954,6 +954,311 @@ void gemm_bf16_lean_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* _
 }
 
 // ------------------------------------------------------------------------------------------------
+// "quad" kernel: 256 x 256 tile on FOUR waves, one per SIMD, each owning a 128 x 128 block of the tile in 256 accumulator
+// registers (the whole 512-entry register file is one wave's).  Same ring (5 x [A 256 x 32 | W 256 x 32]), same K order and
+// rounding as the kernels above — bit-identical results — but
+//   * a wave reads 16 KiB of fragments per 64 MFMAs where a 128 x 64 wave reads 12 KiB per 32: a third less LDS traffic per
+//     flop (energy: the chip holds its clock by power, MI355X_MICROARCH.md 'DVFS give-back'), half the waves, half the
+//     barrier arrivals;
+//   * there is no partner wave to hide behind, so everything that is not an MFMA is slotted between the wave's own MFMAs:
+//     the 8 LDS-DMA pieces of stage s+4 (`buffer_load_dwordx4 ... offen lds`: one VGPR offset per piece that never changes,
+//     the K advance in the scalar offset — no vector ALU) between the first 32 MFMAs of stage s, the 16 fragment reads of
+//     stage s+1 (into the other register set) between the last 32;
+//   * one barrier per stage, in the MIDDLE of the MFMA stream (the pipe still holds queued work when the wave parks):
+//     before it the wave's own pieces of stage s+1 are retired by a counted vmcnt(24); after it stage s+1 is readable and —
+//     because every wave passed its lgkmcnt(0) for stage s at the top of this body — the slot of stage s is free for the
+//     DMA of stage s+5, issued in the first half of the next body.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wait_vmcnt8(int n) {                // waits vmcnt(8 * n); n is wave-uniform, 0..3
+    if (n >= 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else if (n == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (n == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// The accumulators are pinned to the AGPR half of the register file through the instruction's operand constraint: left to
+// itself the allocator spreads 256 accumulators over both halves and shuffles them with v_accvgpr moves inside the loop.
+#define QUAD_MFMA(c, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b))
+
+template <int VAR>      // 0 production; timing-only builds: 1 no DMA inside the loop; 2 no fragment reads inside the loop; 3 DMA pieces of 8 whole lines
+__global__ __launch_bounds__(256)
+void gemm_bf16_quad_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw,
+                      void* __restrict__ C, int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n, GemmEpi ep, int group) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // [5 stages][A 16 KiB | W 16 KiB]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int tm, tn;
+    tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn, group);
+    const int m0 = tm * 256, n0 = tn * 256;
+    const int ns = K / 32;                                           // >= 4, host-guaranteed
+
+    // DMA: wave w stages rows [64w, 64w + 64) of both operands, 16 rows x 64 B per piece.  Buffer resources start at the tile's
+    // corner; rows past M / N re-read the last valid row (clamped offsets: always in bounds, the records field is not relied on)
+    const auto rA = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (int64_t)m0 * lda), 0, 0xFFFFFFFF, 0x00020000);
+    const auto rW = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (int64_t)n0 * ldw), 0, 0xFFFFFFFF, 0x00020000);
+    int offA[4], offW[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = VAR == 3 ? wave * 64 + i * 8 + (lane >> 3) : wave * 64 + i * 16 + (lane >> 2);
+        const int chunk = VAR == 3 ? (lane & 7) : (lane & 3) ^ (((row >> 2) & 1) << 1);     // VAR 3 (timing only, wrong results): whole 128-B lines per row
+        offA[i] = min(row, M - 1 - m0) * (int)lda * 2 + chunk * 16;
+        offW[i] = min(row, N - 1 - n0) * (int)ldw * 2 + chunk * 16;
+    }
+    typedef __attribute__((address_space(3))) char* lds_ptr;
+    typedef const __attribute__((address_space(3))) char* lds_cptr;
+    typedef const __attribute__((address_space(3))) bf16x8* lds_fptr;
+    const lds_ptr ring_w = (lds_ptr)smem;
+    const lds_cptr ring = (lds_cptr)smem;
+    const int lds_base = __builtin_amdgcn_readfirstlane((int)(uintptr_t)ring_w);     // LDS byte address of the ring (M0 arithmetic of VAR 6)
+    auto piece = [&](int q, int kbytes, int slot_bytes) {           // q 0-3: A rows, 4-7: W rows; q is a compile-time constant at every call
+        if (q < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, ring_w + slot_bytes + wave * 4096 + q * 1024, 16, offA[q & 3], kbytes, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, ring_w + slot_bytes + 16384 + wave * 4096 + (q & 3) * 1024, 16, offW[q & 3], kbytes, 0, 0);
+    };
+    auto issue_all = [&](int s, int slot_bytes) {
+        static_for<0, 8>([&](auto qc) { piece(decltype(qc)::value, s * 64, slot_bytes); });
+    };
+
+    floatx4 acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    const int fo = ring_off(lane & 15, lane >> 4);
+    const int constA = wm * 8192 + fo, constW = 16384 + wn * 8192 + fo;
+    bf16x8 fa0[8], fw0[8], fa1[8], fw1[8];
+
+    issue_all(0, 0); issue_all(1, RING_STAGE_BYTES); issue_all(2, 2 * RING_STAGE_BYTES); issue_all(3, 3 * RING_STAGE_BYTES);
+    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");        // my pieces of stage 0 have landed
+    __builtin_amdgcn_s_barrier();                            // stage 0 published
+#pragma unroll
+    for (int j = 0; j < 8; ++j) fw0[j] = *(lds_fptr)(ring + constW + j * 1024);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fa0[i] = *(lds_fptr)(ring + constA + i * 1024);
+
+    int slot_nx = RING_STAGE_BYTES, slot_wr = 4 * RING_STAGE_BYTES;  // ring slots (byte offsets) of stage s + 1 and of stage s + 4
+    // One K stage: MFMAs on (fac, fwc) = stage s; fragments of stage s + 1 into (fan, fwn)
+    auto body = [&](int s, bf16x8 (&fac)[8], bf16x8 (&fwc)[8], bf16x8 (&fan)[8], bf16x8 (&fwn)[8], auto steady_c) {
+        constexpr bool STEADY = decltype(steady_c)::value;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // this stage's fragments are in registers
+        __builtin_amdgcn_sched_barrier(0);
+        const bool dma = STEADY || s + 4 < ns;
+        const int kb = VAR == 3 ? ((s + 4) * 128) % (K * 2) : (s + 4) * 64;
+        const bool rd = STEADY || s + 1 < ns;
+        // 64 MFMAs, m = 8 i + j.  m 0-23: one DMA piece of stage s + 4 before every third MFMA.  After m = 23: my pieces of stage
+        // s + 1 are retired (counted vmcnt) and the workgroup meets — stage s + 1 is published, the slot of stage s - 1 was freed one
+        // barrier ago.  m 24-39: one fragment read of stage s + 1 before each MFMA.  m 40-63: MFMAs only (they cover the reads' latency,
+        // so the lgkmcnt(0) at the top of the next body does not wait).
+        static_for<0, 64>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            constexpr int i = m >> 3, j = m & 7;
+            constexpr bool SPREAD = STEADY && (VAR == 4 || VAR == 5 || VAR == 6);
+            // VAR 6: as VAR 4 with the piece written out by hand — M0 (the LDS destination) stepped in the gap BEFORE the one that
+            // carries the load, so no wait state is needed between them, and nothing but those two instructions per piece
+            if constexpr (SPREAD && VAR == 6 && m % 8 == 0) {
+                constexpr int q = m / 8;
+                if constexpr (q == 0) asm volatile("s_mov_b32 m0, %0" :: "s"(lds_base + slot_wr + wave * 4096) : "memory");
+                else if constexpr (q == 4) asm volatile("s_add_u32 m0, m0, 0x3400" ::: "memory");
+                else asm volatile("s_add_u32 m0, m0, 0x400" ::: "memory");
+            }
+            if constexpr (SPREAD && VAR == 6 && m % 8 == 1) {
+                constexpr int q = m / 8;
+                if constexpr (q < 4) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" :: "v"(offA[q & 3]), "s"(rA), "s"(kb) : "memory");
+                else asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" :: "v"(offW[q & 3]), "s"(rW), "s"(kb) : "memory");
+            }
+            if constexpr (!SPREAD && m < 24 && m % 3 == 0) {
+                if (VAR != 1 && dma) piece(m / 3, kb, slot_wr);
+            }
+            // VAR 4: the pieces spread over the whole stage, one before every eighth MFMA; VAR 5: the same, and wave w two MFMAs
+            // (32 cycles, two pieces' worth of texture-path time) behind wave w - 1, so that the four waves' pieces never queue
+            if constexpr (SPREAD && VAR == 4 && m % 8 == 0) piece(m / 8, kb, slot_wr);
+            if constexpr (SPREAD && VAR == 5 && m % 2 == 0 && (m & 7) < 8) {
+                if (wave == ((m & 7) >> 1)) piece(m / 8, kb, slot_wr);
+            }
+            if constexpr (m >= 24 && m < 40) {
+                constexpr int q = m - 24;
+                if (VAR != 2 && rd) {
+                    if constexpr (q < 8) fwn[q] = *(lds_fptr)(ring + slot_nx + constW + q * 1024);
+                    else fan[q - 8] = *(lds_fptr)(ring + slot_nx + constA + (q - 8) * 1024);
+                }
+            }
+            QUAD_MFMA(acc[i][j], fwc[j], fac[i]);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (m == 23) {
+                if (SPREAD) asm volatile("s_waitcnt vmcnt(19)" ::: "memory");       // stages s+2, s+3 and the three pieces of s+4 issued so far
+                else if (STEADY) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+                else wait_vmcnt8(max(0, min(3, ns - 2 - s)));
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        });
+        slot_wr = slot_wr == 4 * RING_STAGE_BYTES ? 0 : slot_wr + RING_STAGE_BYTES;
+        slot_nx = slot_nx == 4 * RING_STAGE_BYTES ? 0 : slot_nx + RING_STAGE_BYTES;
+    };
+    int s = 0;
+    for (; s + 5 < ns; s += 2) {
+        body(s, fa0, fw0, fa1, fw1, std::true_type{});
+        body(s + 1, fa1, fw1, fa0, fw0, std::true_type{});
+    }
+    for (; s < ns; s += 2) {
+        body(s, fa0, fw0, fa1, fw1, std::false_type{});
+        if (s + 1 < ns) body(s + 1, fa1, fw1, fa0, fw0, std::false_type{});
+    }
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");    // the last MFMAs' results (inline asm: no hazard tracking by the compiler)
+    __syncthreads();                           // every wave is done with the ring before it becomes the output image
+    epilogue_staged<256, 256, 4, 8, 8>(acc, ep, C, ldc, M, N, m0, n0, wm * 128, wn * 128, wave, lane, smem);
+}
+
+// ------------------------------------------------------------------------------------------------
+// "quad64" kernel: the quad kernel on 64-deep K tiles, so that an LDS-DMA piece is 8 rows x 128 B — whole cache lines — instead
+// of 16 rows x 64 B (measured on the quad kernel with a timing-only build: whole-line pieces are worth +10-14 %; the texture
+// path handles a 64-lane request line by line).
+//   * LDS = a ring of ten 16 KiB UNITS, a unit = 128 rows x 64 K of one operand (W rows 0-127, W rows 128-255, A rows 0-127,
+//     A rows 128-255 of a K tile, in that order): unit h = 4 t + c lives in slot h mod 10.  Wave (wm, wn) reads exactly two
+//     units per tile: A half wm and W half wn.  128-byte rows, 16-byte chunk c of row r at position c ^ (r & 7) (the swizzle is
+//     applied to the DMA's per-lane SOURCE chunk; the destination is lane-linear).
+//   * a K tile is two 32-deep steps of 64 MFMAs (same K order as every other kernel: bit-identical results).  Step (t, 0):
+//     16 fragment reads of (t, second half) and the 8 pieces of W units of tile t + 2.  Step (t, 1): after 8 MFMAs the wave
+//     retires its pieces of tile t + 1 (counted vmcnt(8): the W units of t + 2 stay in flight) and the workgroup meets — the ONE
+//     barrier per 128 MFMAs: tile t + 1 is published and, since every wave passed its lgkmcnt(0) for the last reads of tile t,
+//     tile t's four slots are free; then 16 fragment reads of (t + 1, first half), then the 8 pieces of the A units of tile
+//     t + 2 into two of the freed slots (the other two take the W units of tile t + 3 one step later).
+//   * a piece is issued at least two steps (~2 x 1024 MFMA cycles) before the barrier that needs it.
+// ------------------------------------------------------------------------------------------------
+#define Q64_UNIT 16384
+template <int VAR>      // 0 production; timing-only builds: 1 no DMA inside the loop, 2 no fragment reads inside the loop
+__global__ __launch_bounds__(256)
+void gemm_bf16_quad64_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw,
+                        void* __restrict__ C, int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n, GemmEpi ep, int group) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // 10 units x 16 KiB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int tm, tn;
+    tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn, group);
+    const int m0 = tm * 256, n0 = tn * 256;
+    const int nt = K / 64;                                           // >= 2, host-guaranteed
+
+    const auto rA = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (int64_t)m0 * lda), 0, 0xFFFFFFFF, 0x00020000);
+    const auto rW = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (int64_t)n0 * ldw), 0, 0xFFFFFFFF, 0x00020000);
+    // piece (half, q): rows half * 128 + 32 * wave + 8 q + lane / 8 of the tile; LDS position lane % 8 holds source chunk (lane % 8) ^ (row % 8)
+    int offA[2][4], offW[2][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = h * 128 + wave * 32 + q * 8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ (row & 7);
+            offA[h][q] = min(row, M - 1 - m0) * (int)lda * 2 + chunk * 16;
+            offW[h][q] = min(row, N - 1 - n0) * (int)ldw * 2 + chunk * 16;
+        }
+    typedef __attribute__((address_space(3))) char* lds_ptr;
+    typedef const __attribute__((address_space(3))) char* lds_cptr;
+    typedef const __attribute__((address_space(3))) bf16x8* lds_fptr;
+    const lds_ptr ring_w = (lds_ptr)smem;
+    const lds_cptr ring = (lds_cptr)smem;
+    // the 8 pieces of this wave for the two W units (IS_A = false) or the two A units (true) of K tile t; u0 = slot of the first of the two units
+    auto piece = [&](auto isa_c, auto p_c, int t, int u0) {
+        constexpr bool IS_A = decltype(isa_c)::value;
+        constexpr int p = decltype(p_c)::value, h = p >> 2, q = p & 3;
+        int slot = u0 + h;
+        slot = slot >= 10 ? slot - 10 : slot;
+        const lds_ptr dst = ring_w + slot * Q64_UNIT + wave * 4096 + q * 1024;
+        if (IS_A) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, dst, 16, offA[h][q], t * 128, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, dst, 16, offW[h][q], t * 128, 0, 0);
+    };
+    auto wrap = [](int u) { return u >= 10 ? u - 10 : u; };
+
+    floatx4 acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment (row i * 16 + lane % 16 of the unit, K chunk kk * 4 + lane / 16): the swizzle term is (lane % 16) % 8 = lane % 8 for every i
+    const int fo0 = (lane & 15) * 128 + ((((lane >> 4)) ^ (lane & 7)) << 4);
+    const int fo1 = (lane & 15) * 128 + ((((lane >> 4) + 4) ^ (lane & 7)) << 4);
+    bf16x8 fa0[8], fw0[8], fa1[8], fw1[8];
+
+    // prologue: K tiles 0 and 1 (units 0-7)
+    static_for<0, 8>([&](auto pc) { piece(std::false_type{}, pc, 0, 0); });
+    static_for<0, 8>([&](auto pc) { piece(std::true_type{}, pc, 0, 2); });
+    static_for<0, 8>([&](auto pc) { piece(std::false_type{}, pc, 1, 4); });
+    static_for<0, 8>([&](auto pc) { piece(std::true_type{}, pc, 1, 6); });
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");        // my pieces of tile 0 have landed
+    __builtin_amdgcn_s_barrier();                            // tile 0 published
+#pragma unroll
+    for (int j = 0; j < 8; ++j) fw0[j] = *(lds_fptr)(ring + wn * Q64_UNIT + fo0 + j * 2048);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fa0[i] = *(lds_fptr)(ring + (2 + wm) * Q64_UNIT + fo0 + i * 2048);
+
+    int ub = 0;                                              // slot of unit 4 t (W rows 0-127 of the current tile)
+    for (int t = 0; t < nt; ++t) {
+        const bool more1 = t + 1 < nt, more2 = t + 2 < nt;
+        const int ubn = wrap(ub + 4);                        // slot of unit 4 (t + 1)
+        const int u8 = wrap(ub + 8);                         // slot of unit 4 (t + 2): W units of tile t + 2 (free since the barrier of tile t - 1)
+        // ---- step (t, 0): MFMAs on set 0; reads of (t, second half) into set 1; pieces of the W units of tile t + 2
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const lds_cptr pw = ring + wrap(ub + wn) * Q64_UNIT + fo1;
+            const lds_cptr pa = ring + wrap(ub + 2 + wm) * Q64_UNIT + fo1;
+            static_for<0, 64>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                constexpr int i = m >> 3, j = m & 7;
+                if constexpr (m < 16) {
+                    if (VAR != 2) {
+                        if constexpr (m < 8) fw1[m] = *(lds_fptr)(pw + m * 2048);
+                        else fa1[m - 8] = *(lds_fptr)(pa + (m - 8) * 2048);
+                    }
+                }
+                if constexpr (m >= 16 && m < 40 && (m - 16) % 3 == 0) {
+                    if (VAR != 1 && more2) piece(std::false_type{}, std::integral_constant<int, (m - 16) / 3>{}, t + 2, u8);
+                }
+                QUAD_MFMA(acc[i][j], fw0[j], fa0[i]);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+        // ---- step (t, 1): MFMAs on set 1; rendezvous; reads of (t + 1, first half) into set 0; pieces of the A units of tile t + 2
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const lds_cptr pw = ring + wrap(ubn + wn) * Q64_UNIT + fo0;
+            const lds_cptr pa = ring + wrap(ubn + 2 + wm) * Q64_UNIT + fo0;
+            const int u10 = ub;                              // slots of units 4 t, 4 t + 1 = units 4 (t + 2) + 2, + 3: freed by this step's barrier
+            static_for<0, 64>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                constexpr int i = m >> 3, j = m & 7;
+                if constexpr (m >= 8 && m < 24) {
+                    constexpr int r = m - 8;
+                    if (VAR != 2 && more1) {
+                        if constexpr (r < 8) fw0[r] = *(lds_fptr)(pw + r * 2048);
+                        else fa0[r - 8] = *(lds_fptr)(pa + (r - 8) * 2048);
+                    }
+                }
+                if constexpr (m >= 24 && m < 48 && (m - 24) % 3 == 0) {
+                    if (VAR != 1 && more2) piece(std::true_type{}, std::integral_constant<int, (m - 24) / 3>{}, t + 2, u10);
+                }
+                QUAD_MFMA(acc[i][j], fw1[j], fa1[i]);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (m == 7) {
+                    // in flight, oldest first: W(t+1), A(t+1), W(t+2) [if it exists]: retire tile t + 1
+                    if (more2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+        }
+        ub = ubn;
+    }
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");    // the last MFMAs' results (inline asm: no hazard tracking by the compiler)
+    __syncthreads();                           // every wave is done with the ring before it becomes the output image
+    epilogue_staged<256, 256, 4, 8, 8>(acc, ep, C, ldc, M, N, m0, n0, wm * 128, wn * 128, wave, lane, smem);
+}
+
+// ------------------------------------------------------------------------------------------------
 // "pair" kernel: the ping-pong schedule with TWO 32-deep K stages per phase.
 //
 // Measured on the ping-pong kernel (tools/gemm_segments.py, s_memtime stamps, cycles per wave and stage): LOAD phase 600
@@ -2019,6 +2324,36 @@ extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
             gemm_bf16_pair_k<<<grid, block, RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>(
                 (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, pp_group);
         }
+        else if (g_force_kernel >= 40 && g_force_kernel <= 42 && K >= 128 && K % 64 == 0 && lean_ok) {
+            static bool a40 = false;
+            if (!a40) {
+                (void)hipFuncSetAttribute((const void*)gemm_bf16_quad64_k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 10 * Q64_UNIT);
+                (void)hipFuncSetAttribute((const void*)gemm_bf16_quad64_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 10 * Q64_UNIT);
+                (void)hipFuncSetAttribute((const void*)gemm_bf16_quad64_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 10 * Q64_UNIT);
+                a40 = true;
+            }
+#define QUAD64(V) gemm_bf16_quad64_k<V><<<grid, dim3(256), 10 * Q64_UNIT, (hipStream_t)stream>>>( \
+                (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, pp_group)
+            if (g_force_kernel == 40) QUAD64(0); else if (g_force_kernel == 41) QUAD64(1); else QUAD64(2);
+#undef QUAD64
+        }
+        else if (g_force_kernel >= 30 && g_force_kernel <= 36 && K >= 128 && lean_ok) {
+            static bool a30 = false;
+            if (!a30) {
+                (void)hipFuncSetAttribute((const void*)gemm_bf16_quad_k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
+                (void)hipFuncSetAttribute((const void*)gemm_bf16_quad_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
+                (void)hipFuncSetAttribute((const void*)gemm_bf16_quad_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
+                (void)hipFuncSetAttribute((const void*)gemm_bf16_quad_k<3>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
+                (void)hipFuncSetAttribute((const void*)gemm_bf16_quad_k<4>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
+                (void)hipFuncSetAttribute((const void*)gemm_bf16_quad_k<5>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
+                (void)hipFuncSetAttribute((const void*)gemm_bf16_quad_k<6>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
+                a30 = true;
+            }
+#define QUAD(V) gemm_bf16_quad_k<V><<<grid, dim3(256), RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>( \
+                (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, pp_group)
+            if (g_force_kernel == 30) QUAD(0); else if (g_force_kernel == 31) QUAD(1); else if (g_force_kernel == 32) QUAD(2); else if (g_force_kernel == 33) QUAD(3); else if (g_force_kernel == 34) QUAD(4); else if (g_force_kernel == 35) QUAD(5); else QUAD(6);
+#undef QUAD
+        }
         else if (g_force_kernel >= 22 && g_force_kernel <= 27 && K >= 128 && lean_ok) {
             static bool a22 = false;
             if (!a22) {
@@ -2049,7 +2384,7 @@ extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
             gemm_bf16_lean_k<0, 0><<<grid, block, RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>(
                 (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, pp_group);
         }
-        else if ((g_force_kernel == 0 || g_force_kernel == 9 || g_force_kernel == 20 || (g_force_kernel >= 22 && g_force_kernel <= 27)) && K >= 128)
+        else if ((g_force_kernel == 0 || g_force_kernel == 9 || g_force_kernel == 20 || (g_force_kernel >= 22 && g_force_kernel <= 42)) && K >= 128)
             gemm_bf16_pingpong_k<0><<<grid, block, RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>(
                 (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, pp_ticks, pp_group);
         else LAUNCH256(0);

@@ -16,7 +16,7 @@ sys.path[:0] = [str(ROOT), str(ROOT / "licv-vqa_amd")]
 
 import os
 SHAPE = tuple(int(x) for x in os.environ.get("CLOCK_PROBE_SHAPE", "16384,8192,8192").split(","))
-SELECTS = [6, 22, 20]
+SELECTS = [int(x) for x in os.environ.get("CLOCK_PROBE_SELECTS", "6,22,20").split(",")]
 
 
 def run():
@@ -56,7 +56,7 @@ def parse(d):
             t = dur.get(r["Dispatch_Id"])
             if t is None and "Start_Timestamp" in r:
                 t = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
-            if not t or t < 1e-3:
+            if not t or t < 3e-4:
                 continue
             acc[r["Kernel_Name"][:90]].append((float(r["Counter_Value"]) / 8.0 / t, t))
     M, N, K = SHAPE
