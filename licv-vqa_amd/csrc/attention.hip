@@ -509,7 +509,9 @@ extern "C" int licv_attn_fwd(const licv_attn_args* x, void* stream) {
     //        SIMD instead of 3, twice the LDS);
     //  (iv)  v_permlane16/32_swap instead of ds_bpermute for the 4-lane reductions: neutral;
     //  (v)   resident kernel, ViT (257 = 16 x 16 + 1 queries: one wave runs 3 sub-tiles, seven run 2): spreading the key tiles of
-    //        the lone last sub-tile over the 8 waves and merging the partial (m, l, O) states through LDS: 367 -> 395 us.
+    //        the lone last sub-tile over the 8 waves and merging the partial (m, l, O) states through LDS: 367 -> 395 us;
+    //  (vi)  skipping the accumulator rescale as a wave when alpha == 1 in every lane (bit-identical): ViT 362 -> 372 us, language
+    //        self-attention 174 -> 170 us (tools/attn_bench.py): the branch costs what the 20 multiplies did.
     const int hd = p.hd;
     const int64_t qtiles = (x->Sq + ATT_QB - 1) / ATT_QB;
     const int64_t nblk = x->B * x->n_heads * qtiles;
