@@ -326,7 +326,10 @@ def main():
     # per-launch event pairs (roofline.achieved) need the Python-level launches; the launch-bound workloads (hooked generate, the
     # 32-token student shape) are timed on the native layer runner instead and report no per-kernel roofline
     profiled = not (generating or "student" in args.workload or args.no_profiler)
-    if profiled:
+    # sliced configuration (Idefics engine, two batch slices on two streams): the timed region below runs the product path as it is
+    # (no event pairs, native layer runner); the per-launch measurements come from two further regions after it
+    sliced = (profiled and not training and not generating and not is2 and int(getattr(eng, "batch_streams", 1) or 1) > 1 and B >= 4)
+    if profiled and not sliced:
         ops.set_profiler(prof)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     fence()
@@ -349,16 +352,32 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     qps = B * world * args.steps / elapsed
 
-    # With the batch cut in slices on two HIP streams (the product configuration, timed above) a GEMM's start-to-end time includes
-    # the share of the machine the other slice's kernels took, so it says little about the kernel.  The roofline of the dominant
-    # kernel therefore comes from a SECOND timed region of the same step with the slices off (kernels of one stream never overlap):
-    # per-launch HIP event pairs over min(steps, 6) steps, its ms per step reported beside it; the overlapped region's figures
-    # (union of the launch intervals, mean start-to-end time) are kept under "overlapped".
+    # With the batch cut in slices on two HIP streams (the product configuration, timed above without any instrumentation) a GEMM's
+    # start-to-end time includes the share of the machine the other slice's kernels took, so it says little about the kernel.  The
+    # roofline of the dominant kernel therefore comes from a further timed region of the same step with the slices off (kernels of
+    # one stream never overlap): per-launch HIP event pairs over min(steps, 6) steps, its ms per step reported beside it; a short
+    # region with event pairs in the sliced configuration gives the figures kept under "overlapped" (union of the launch intervals,
+    # mean start-to-end time).
     overlapped = None
-    sliced = profiled and not training and not generating and int(getattr(eng, "batch_streams", 1) or 1) > 1 and B >= 4
     if sliced:
         n_sl = int(eng.batch_streams)
-        first = marks[0]
+        o_steps = min(args.steps, 3)                          # short region with event pairs ON in the sliced configuration
+        ops.set_profiler([])                                  # (two untimed steps first: the Python-level path allocates its own buffers)
+        step()
+        step()
+        prof = []
+        ops.set_profiler(prof)
+        first = torch.cuda.Event(enable_timing=True)
+        last = torch.cuda.Event(enable_timing=True)
+        fence()
+        first.record()
+        for i in range(o_steps):
+            out = step()
+        last.record()
+        fence()
+        ops.set_profiler(None)
+        del out
+        o_elapsed = first.elapsed_time(last) * 1e-3
         ev = sorted((first.elapsed_time(e0) * 1e-3, first.elapsed_time(e1) * 1e-3, w) for k, e0, e1, w, *_ in prof if k == "gemm")
         union, hi = 0.0, -1.0
         for a0, a1, _ in ev:
@@ -366,8 +385,9 @@ def main():
                 union += a1 - max(a0, hi)
                 hi = a1
         fl_o = sum(w for _, _, w in ev)
-        overlapped = {"batch_streams": n_sl, "gemm_launches_per_step": len(ev) // max(args.steps, 1),
-                      "gemm_busy_union_share_of_step": union / elapsed, "gemm_tflops_over_union": fl_o / union / 1e12 if union else None,
+        overlapped = {"batch_streams": n_sl, "steps": o_steps, "ms_per_step_with_event_pairs": 1e3 * o_elapsed / o_steps,
+                      "gemm_launches_per_step": len(ev) // max(o_steps, 1),
+                      "gemm_busy_union_share_of_step": union / o_elapsed, "gemm_tflops_over_union": fl_o / union / 1e12 if union else None,
                       "avg_launch_us_start_to_end": 1e6 * sum(a1 - a0 for a0, a1, _ in ev) / max(len(ev), 1)}
         eng.batch_streams = 1
         serial_steps = min(args.steps, 6)
