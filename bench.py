@@ -328,7 +328,7 @@ def main():
     profiled = not (generating or "student" in args.workload or args.no_profiler)
     # sliced configuration (Idefics engine, two batch slices on two streams): the timed region below runs the product path as it is
     # (no event pairs, native layer runner); the per-launch measurements come from two further regions after it
-    sliced = (profiled and not training and not generating and not is2 and int(getattr(eng, "batch_streams", 1) or 1) > 1 and B >= 4)
+    sliced = (profiled and not generating and int(getattr(eng, "batch_streams", 1) or 1) > 1 and B >= 4 and B * S >= 4096)
     if profiled and not sliced:
         ops.set_profiler(prof)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]

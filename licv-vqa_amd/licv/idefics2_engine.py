@@ -165,6 +165,46 @@ class Idefics2Engine:
         self.w, self.arch = weights, weights.arch
         self.fuse_hook_norm = fuse_hook_norm
         self._flags = _HostFlags()
+        # batch slices on HIP streams of their own, as IdeficsEngine.batch_streams (same kernels, bit-identical logits; the partly
+        # filled last round of one slice's GEMMs is filled by the other slice's workgroups).  0 / 1 = off.
+        self.batch_streams = 2
+        self._side_streams = []
+        self._slice_views = {}
+
+    def _views(self, t: Optional[torch.Tensor], cut):
+        """Slices of `t` along dim 0, the SAME view objects on every call for the same parent tensor at the same version: the
+        host-flag cache matches tensors by identity, and a fresh view per call would cost a device read-back per slice per forward."""
+        if t is None:
+            return [None] * (len(cut) - 1)
+        import weakref
+        for k in [k for k, e in self._slice_views.items() if e[0]() is None]:
+            del self._slice_views[k]
+        e = self._slice_views.get(id(t))
+        if e is None or e[0]() is not t or e[1] != t._version or e[2] != cut:
+            e = (weakref.ref(t), t._version, cut, [t[cut[i]:cut[i + 1]] for i in range(len(cut) - 1)])
+            self._slice_views[id(t)] = e
+        return e[3]
+
+    def _forward_slices(self, parts: int, input_ids, attention_mask, pixel_values, pixel_attention_mask, position_ids, **kw):
+        dev = self.w.device
+        B = input_ids.shape[0]
+        cur = torch.cuda.current_stream(dev)
+        while len(self._side_streams) < parts:
+            self._side_streams.append(torch.cuda.Stream(device=dev))
+        cut = tuple(B * i // parts for i in range(parts + 1))
+        ids, am, pv = self._views(input_ids, cut), self._views(attention_mask, cut), self._views(pixel_values, cut)
+        pam, pos = self._views(pixel_attention_mask, cut), self._views(position_ids, cut)
+        outs = []
+        for i in range(parts):
+            st = self._side_streams[i]
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                outs.append(self._forward_one(ids[i], am[i], pv[i], pam[i], position_ids=pos[i], **kw))
+        for i in range(parts):
+            cur.wait_stream(self._side_streams[i])
+        for o in outs:
+            o.record_stream(cur)
+        return torch.cat(outs, 0)
 
     # ----------------------------------------------------------------------------------- vision + connector
     def encode_images(self, pixel_values: torch.Tensor, pixel_attention_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -255,6 +295,18 @@ class Idefics2Engine:
                 position_ids: Optional[torch.Tensor] = None, kv_cache: Optional[KVCache2] = None):
         """Returns logits (B, S, V) bf16.  icv (1, n_hooked, H) fp32 — already alpha-scaled when ``alpha`` is None;
         hook_layers: text-layer ids whose MLP OUTPUT (before the residual add) is edited."""
+        parts = self.batch_streams
+        B, S = input_ids.shape
+        if (parts and parts > 1 and B >= 2 * parts and B * S >= parts * 2048 and capture is None and kv_cache is None
+                and logits_rows is None and image_hidden_states is None and pixel_values is not None):
+            return self._forward_slices(parts, input_ids, attention_mask, pixel_values, pixel_attention_mask, position_ids,
+                                        icv=icv, hook_layers=hook_layers, alpha=alpha)
+        return self._forward_one(input_ids, attention_mask, pixel_values, pixel_attention_mask, image_hidden_states, icv=icv,
+                                 hook_layers=hook_layers, alpha=alpha, capture=capture, logits_rows=logits_rows,
+                                 position_ids=position_ids, kv_cache=kv_cache)
+
+    def _forward_one(self, input_ids, attention_mask=None, pixel_values=None, pixel_attention_mask=None, image_hidden_states=None,
+                     icv=None, hook_layers=None, alpha=None, capture=None, logits_rows=None, position_ids=None, kv_cache=None):
         a, w = self.arch, self.w
         dev = w.device
         B, S = input_ids.shape

@@ -167,22 +167,36 @@ class IdeficsEngine:
         self.batch_streams = 2
         self._side_streams = []
 
-    def _forward_slices(self, parts: int, input_ids, attention_mask, pixel_values, image_attention_mask, image_states, **kw):
+    def _forward_slices(self, parts: int, input_ids, attention_mask, pixel_values, image_attention_mask, image_states,
+                        logits_rows=None, **kw):
         dev = self.w.device
-        B = input_ids.shape[0]
+        B, S = input_ids.shape
         cur = torch.cuda.current_stream(dev)
+        cut = [B * i // parts for i in range(parts + 1)]
+        rows_of = [None] * parts
+        if logits_rows is not None:
+            # selected rows (flattened b * S + s, ascending — the trainer's answer rows): slice i takes the rows of its questions,
+            # re-based; the split points come back in ONE small read (the callers that pass rows have just synchronised to build them)
+            r = logits_rows.reshape(-1)
+            bounds = torch.tensor([c * S for c in cut], device=dev, dtype=r.dtype)
+            info = torch.cat([torch.searchsorted(r, bounds), (r[1:] < r[:-1]).any().reshape(1).to(bounds.dtype)]).tolist()
+            if info[-1] or r.numel() == 0:                            # not ascending (or nothing selected): one plain pass
+                return self._forward_one(input_ids, attention_mask, pixel_values, image_attention_mask, image_states,
+                                         logits_rows=logits_rows, **kw)
+            rows_of = [(r[info[i]:info[i + 1]] - cut[i] * S).contiguous() for i in range(parts)]
         while len(self._side_streams) < parts:
             self._side_streams.append(torch.cuda.Stream(device=dev))
-        cut = [B * i // parts for i in range(parts + 1)]
         outs = []
         for i in range(parts):
+            if logits_rows is not None and rows_of[i].numel() == 0:
+                continue
             st = self._side_streams[i]
             st.wait_stream(cur)                                       # the inputs were produced on the caller's stream
             sl = slice(cut[i], cut[i + 1])
             with torch.cuda.stream(st):
                 outs.append(self._forward_one(input_ids[sl], None if attention_mask is None else attention_mask[sl],
                                               None if pixel_values is None else pixel_values[sl], image_attention_mask[sl],
-                                              None if image_states is None else image_states[sl], **kw))
+                                              None if image_states is None else image_states[sl], logits_rows=rows_of[i], **kw))
         for i in range(parts):
             cur.wait_stream(self._side_streams[i])
         for o in outs:
@@ -264,9 +278,9 @@ class IdeficsEngine:
         parts = self.batch_streams
         B, S = input_ids.shape
         if (parts and parts > 1 and B >= 2 * parts and B * S >= parts * 2048 and capture is None and kv_cache is None
-                and save_hook_inputs is None and logits_rows is None and image_attention_mask is not None):
+                and save_hook_inputs is None and image_attention_mask is not None):
             return self._forward_slices(parts, input_ids, attention_mask, pixel_values, image_attention_mask, image_states,
-                                        icv=icv, hook_layers=hook_layers, alpha=alpha)
+                                        logits_rows=logits_rows, icv=icv, hook_layers=hook_layers, alpha=alpha)
         return self._forward_one(input_ids, attention_mask, pixel_values, image_attention_mask, image_states, icv=icv,
                                  hook_layers=hook_layers, alpha=alpha, capture=capture, kv_cache=kv_cache,
                                  save_hook_inputs=save_hook_inputs, logits_rows=logits_rows)

@@ -47,6 +47,54 @@ def test_sliced_forward_not_taken_when_something_is_captured():
     cap = {}
     eng.forward(**batch, capture=cap)
     assert not eng._side_streams and "final_norm" in cap
-    rows = torch.arange(0, 4 * 1100, 1100, device=DEV)
-    out = eng.forward(**batch, logits_rows=rows)
-    assert out.shape[0] == 4 and not eng._side_streams
+
+
+def test_sliced_forward_with_selected_rows():
+    """logits_rows (the trainer's answer rows, ascending): each slice computes the rows of its own questions; rows in one slice only,
+    and rows out of order (one plain pass) are handled."""
+    from licv import ops
+    from licv.idefics_engine import IdeficsEngine, IdeficsWeights
+    arch = IDEFICS_MID
+    eng = IdeficsEngine(IdeficsWeights(synth_idefics_weights(arch, seed=21, dtype=torch.float32), arch, DEV))
+    B, S = 4, 1100
+    batch = {k: v.to(DEV) for k, v in synth_vqa_batch(arch, B, S, 2, seed=24, dtype=torch.bfloat16).items()}
+    try:
+        ops.set_splitk(False)
+        for rows in (torch.tensor([5, 1099, 1100, 2300, 3299, 3300, 4399], device=DEV), torch.tensor([2200, 2201, 4000], device=DEV),
+                     torch.tensor([3000, 7, 1500], device=DEV)):
+            eng.batch_streams = 1
+            whole = eng.forward(**batch, logits_rows=rows)
+            eng.batch_streams = 2
+            sliced = eng.forward(**batch, logits_rows=rows)
+            torch.cuda.synchronize()
+            assert sliced.shape == whole.shape and torch.equal(sliced, whole), rows.tolist()
+    finally:
+        ops.set_splitk(True)
+
+
+def test_idefics2_sliced_forward_is_bit_identical_and_keeps_host_flags_cached():
+    """Idefics2Engine.batch_streams: same property; the slices are cached view objects, so the identity-keyed host flags (real-image
+    count, <image>-token count) are read back once per slice and not again on the second forward."""
+    from licv import ops
+    from licv.config import IDEFICS2_MID
+    from licv.idefics2_engine import Idefics2Engine, Idefics2Weights
+    from licv.synthetic import synth_idefics2_weights, synth_vqa_batch_idefics2
+    arch = IDEFICS2_MID
+    eng = Idefics2Engine(Idefics2Weights(synth_idefics2_weights(arch, seed=31, dtype=torch.float32), arch, DEV))
+    B, S, N = 4, 1100, 3
+    batch = synth_vqa_batch_idefics2(arch, B, S, N, 2 * arch.v_patch * 3, 2 * arch.v_patch * 4, seed=32, dtype=torch.bfloat16, device=DEV)
+    icv = (torch.randn(1, arch.num_layers, arch.hidden_size, generator=torch.Generator().manual_seed(33)) * 0.05).to(DEV)
+    layers = list(range(arch.num_layers))
+    try:
+        ops.set_splitk(False)
+        eng.batch_streams = 1
+        whole = eng.forward(**batch, icv=icv, hook_layers=layers)
+        eng.batch_streams = 2
+        sliced = eng.forward(**batch, icv=icv, hook_layers=layers)
+        n_entries = len(eng._flags._entries)
+        again = eng.forward(**batch, icv=icv, hook_layers=layers)
+        torch.cuda.synchronize()
+        assert torch.equal(sliced, whole) and torch.equal(again, whole)
+        assert len(eng._flags._entries) == n_entries, "the second sliced forward must hit the host-flag cache"
+    finally:
+        ops.set_splitk(True)
