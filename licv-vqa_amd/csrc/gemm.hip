@@ -1044,7 +1044,9 @@ void gemm_bf16_quad_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* _
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // this stage's fragments are in registers
         __builtin_amdgcn_sched_barrier(0);
         const bool dma = STEADY || s + 4 < ns;
-        const int kb = VAR == 3 ? ((s + 4) * 128) % (K * 2) : (s + 4) * 64;
+        // VAR 7 (timing only, wrong results): every stage re-loads the bytes of stage 0 — the pieces are issued and land as usual but
+        // always hit the vector L1 / L2, which separates the ISSUE cost of a piece from what the memory system behind it costs
+        const int kb = VAR == 3 ? ((s + 4) * 128) % (K * 2) : VAR == 7 ? 0 : (s + 4) * 64;
         const bool rd = STEADY || s + 1 < ns;
         // 64 MFMAs, m = 8 i + j.  m 0-23: one DMA piece of stage s + 4 before every third MFMA.  After m = 23: my pieces of stage
         // s + 1 are retired (counted vmcnt) and the workgroup meets — stage s + 1 is published, the slot of stage s - 1 was freed one
@@ -2337,7 +2339,7 @@ extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
             if (g_force_kernel == 40) QUAD64(0); else if (g_force_kernel == 41) QUAD64(1); else QUAD64(2);
 #undef QUAD64
         }
-        else if (g_force_kernel >= 30 && g_force_kernel <= 36 && K >= 128 && lean_ok) {
+        else if (g_force_kernel >= 30 && g_force_kernel <= 37 && K >= 128 && lean_ok) {
             static bool a30 = false;
             if (!a30) {
                 (void)hipFuncSetAttribute((const void*)gemm_bf16_quad_k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
@@ -2347,11 +2349,12 @@ extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
                 (void)hipFuncSetAttribute((const void*)gemm_bf16_quad_k<4>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
                 (void)hipFuncSetAttribute((const void*)gemm_bf16_quad_k<5>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
                 (void)hipFuncSetAttribute((const void*)gemm_bf16_quad_k<6>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
+                (void)hipFuncSetAttribute((const void*)gemm_bf16_quad_k<7>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
                 a30 = true;
             }
 #define QUAD(V) gemm_bf16_quad_k<V><<<grid, dim3(256), RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>( \
                 (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, pp_group)
-            if (g_force_kernel == 30) QUAD(0); else if (g_force_kernel == 31) QUAD(1); else if (g_force_kernel == 32) QUAD(2); else if (g_force_kernel == 33) QUAD(3); else if (g_force_kernel == 34) QUAD(4); else if (g_force_kernel == 35) QUAD(5); else QUAD(6);
+            if (g_force_kernel == 30) QUAD(0); else if (g_force_kernel == 31) QUAD(1); else if (g_force_kernel == 32) QUAD(2); else if (g_force_kernel == 33) QUAD(3); else if (g_force_kernel == 34) QUAD(4); else if (g_force_kernel == 35) QUAD(5); else if (g_force_kernel == 36) QUAD(6); else QUAD(7);
 #undef QUAD
         }
         else if (g_force_kernel >= 22 && g_force_kernel <= 27 && K >= 128 && lean_ok) {
