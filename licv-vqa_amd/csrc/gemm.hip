@@ -52,6 +52,21 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
     const float ec = poly * __expf(-az * az);                 // erfc(|z|)
     return 0.5f * x * (z >= 0.f ? 2.0f - ec : ec);
 }
+// The same GELU on two values at once: identical operations per element (every multiply and add of the scalar body, in the same
+// order), written on 2-vectors so they issue as v_pk_mul_f32 / v_pk_add_f32 — the epilogue of the fc1 GEMM carries 128 of these per
+// lane and tile (2050 scalar f32 instructions; the packed form halves the non-transcendental part).  Bit-identical to gelu_erf_fast.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_erf_fast2(f32x2 x) {
+    const f32x2 z = x * 0.70710678118654752440f;
+    const f32x2 az = f32x2{fabsf(z[0]), fabsf(z[1])};
+    const f32x2 den = 1.0f + 0.3275911f * az;
+    const f32x2 t = f32x2{fast_rcp(den[0]), fast_rcp(den[1])};
+    const f32x2 poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const f32x2 arg = -az * az;
+    const f32x2 ec = poly * f32x2{__expf(arg[0]), __expf(arg[1])};
+    const f32x2 sel = f32x2{z[0] >= 0.f ? 2.0f - ec[0] : ec[0], z[1] >= 0.f ? 2.0f - ec[1] : ec[1]};
+    return 0.5f * x * sel;
+}
 __device__ __forceinline__ float act_apply(float y, int act) {
     switch (act) {
         case 1: return gelu_erf_fast(y);
@@ -1792,13 +1807,24 @@ void gemm_bf16_flow_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* _
                     static_for<0, 2>([&](auto pc) {
                         constexpr int p = decltype(pc)::value;
                         float y[2][4];
+                        if constexpr (EPI == 1) {                       // erf GELU, two values per packed instruction
 #pragma unroll
-                        for (int h = 0; h < 2; ++h)
+                            for (int h = 0; h < 2; ++h)
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const float v = acc[i][2 * p + h][r] + bv[2 * p + h][r];
-                                y[h][r] = EPI == 0 ? v : act_apply(rbf(v), EPI);
-                            }
+                                for (int r = 0; r < 4; r += 2) {
+                                    const f32x2 g2 = gelu_erf_fast2(f32x2{rbf(acc[i][2 * p + h][r] + bv[2 * p + h][r]),
+                                                                          rbf(acc[i][2 * p + h][r + 1] + bv[2 * p + h][r + 1])});
+                                    y[h][r] = g2[0]; y[h][r + 1] = g2[1];
+                                }
+                        } else {
+#pragma unroll
+                            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const float v = acc[i][2 * p + h][r] + bv[2 * p + h][r];
+                                    y[h][r] = EPI == 0 ? v : act_apply(rbf(v), EPI);
+                                }
+                        }
                         uint32_t a0 = pack_bf2(y[0][0], y[0][1]), a1 = pack_bf2(y[0][2], y[0][3]);
                         uint32_t b0 = pack_bf2(y[1][0], y[1][1]), b1 = pack_bf2(y[1][2], y[1][3]);
                         swap16(a0, b0);
