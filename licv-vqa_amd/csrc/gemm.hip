@@ -1650,11 +1650,11 @@ __device__ __forceinline__ void swap16(uint32_t& a, uint32_t& b) {
     a = r[0]; b = r[1];
 }
 
-template <int EPI>      // 0 plain/bias, 1 GELU(erf), 2 GELU(tanh), 3 ReLU, 4 SwiGLU (N/2 output columns)
+template <int EPI>      // 0 plain/bias, 1 GELU(erf), 2 GELU(tanh), 3 ReLU, 4 SwiGLU (N/2 output columns), 5 bias + bf16 residual (may alias C)
 __global__ __launch_bounds__(512, 2)
 void gemm_bf16_flow_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw,
-                      bf16_t* __restrict__ C, int ldc, int M, int N, int K, int tiles_m, int tiles_n,
-                      const bf16_t* __restrict__ bias, int group) {
+                      bf16_t* C, int ldc, int M, int N, int K, int tiles_m, int tiles_n,
+                      const bf16_t* __restrict__ bias, int group, const bf16_t* res = nullptr, int ld_res = 0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];     // [5 stages][A 16 KiB | W 16 KiB]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1664,6 +1664,8 @@ void gemm_bf16_flow_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* _
     const int fo = ring_off(lane & 15, lane >> 4);
     constexpr int NST = (EPI == 4) ? 8 : 16;                 // epilogue store instructions per wave and tile
     const auto crs = __builtin_amdgcn_make_buffer_rsrc((void*)C, 0, (int)((int64_t)M * ldc * 2), 0x00020000);
+    // EPI 5: the residual rows through a descriptor of their own (rows past M read as zero and are never stored)
+    const auto rrs = __builtin_amdgcn_make_buffer_rsrc((void*)(EPI == 5 ? res : C), 0, (int)((int64_t)M * (EPI == 5 ? ld_res : ldc) * 2), 0x00020000);
     typedef const __attribute__((address_space(3))) char* lds_cptr;
     typedef const __attribute__((address_space(3))) bf16x8* lds_fptr;
     const lds_cptr ring = (lds_cptr)smem;
@@ -1767,11 +1769,31 @@ void gemm_bf16_flow_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* _
 
         const int next = tile + gridDim.x;
         const bool more = next < ntiles;
+        const int colbase = cn0 + wn * 64;                   // wave-uniform; N % 64 == 0 -> a wave is all in or all out
+        // EPI 5: the residual of the block's upper half (8 loads of 16 B per lane) goes out BEFORE the next tile's pieces — vector-memory
+        // operations retire in issue order, so one counted wait, vmcnt(16), retires exactly those loads and leaves the 16 pieces in
+        // flight.  The lower half's loads are issued into the same registers as the upper half's blocks are stored (32 registers for
+        // the residual in all: 64 spill), and are retired with everything older by a vmcnt(0) between the halves.
+        u32x4 rres[4][2];
+        const uint32_t roff0 = EPI == 5 ? (uint32_t)(((cm0 + wm * 128 + (lane & 15)) * ld_res + colbase + ((lane >> 4) & 1) * 16 + (lane >> 5) * 8) * 2) : 0u;
+        if (EPI == 5 && colbase < N) {
+            static_for<0, 4>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                static_for<0, 2>([&](auto pc) {
+                    constexpr int p = decltype(pc)::value;
+                    rres[i][p] = __builtin_amdgcn_raw_buffer_load_b128(rrs, roff0 + (uint32_t)(i * 16 * ld_res * 2 + p * 64), 0, 0);
+                });
+            });
+        }
+        __builtin_amdgcn_sched_barrier(0);
         if (more) { set_tile(next); fill4(); }
         __builtin_amdgcn_sched_barrier(0);
+        if (EPI == 5) {
+            if (more) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
 
         // ---- register-direct epilogue of tile (cm0, cn0)
-        const int colbase = cn0 + wn * 64;                   // wave-uniform; N % 64 == 0 -> a wave is all in or all out
         extra4 = 0;
         if (colbase < N) {
             const int fr = lane & 15, fq = lane >> 4;
@@ -1822,16 +1844,31 @@ void gemm_bf16_flow_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* _
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) {
                                     const float v = acc[i][2 * p + h][r] + bv[2 * p + h][r];
-                                    y[h][r] = EPI == 0 ? v : act_apply(rbf(v), EPI);
+                                    y[h][r] = (EPI == 0 || EPI == 5) ? v : act_apply(rbf(v), EPI);
                                 }
                         }
                         uint32_t a0 = pack_bf2(y[0][0], y[0][1]), a1 = pack_bf2(y[0][2], y[0][3]);
                         uint32_t b0 = pack_bf2(y[1][0], y[1][1]), b1 = pack_bf2(y[1][2], y[1][3]);
                         swap16(a0, b0);
                         swap16(a1, b1);
-                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{a0, a1, b0, b1}, crs,
-                                                               off0 + (uint32_t)(i * 16 * ldc * 2 + p * 64), 0, 0);
+                        u32x4 outv = u32x4{a0, a1, b0, b1};         // 8 consecutive columns of y0 = bf16(acc + bias)
+                        if constexpr (EPI == 5) {                   // out = bf16(residual + y0), as epilogue_rows_res does from the LDS image
+                            float q[8], t[8], z[8];
+                            unpack8(rres[i & 3][p], q);
+                            unpack8(outv, t);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) z[e] = q[e] + t[e];
+                            outv = pack8(z);
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b128(outv, crs, off0 + (uint32_t)(i * 16 * ldc * 2 + p * 64), 0, 0);
+                        if constexpr (EPI == 5 && i < 4)            // this block's residual registers are free: the same block of the lower half
+                            rres[i][p] = __builtin_amdgcn_raw_buffer_load_b128(rrs, roff0 + (uint32_t)((i + 4) * 16 * ld_res * 2 + p * 64), 0, 0);
                     });
+                    if constexpr (EPI == 5 && i == 3) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // lower-half residual landed (and, in order, all before it)
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 });
             } else {
                 // packed column blocks of 16: acc[.][0] gate / acc[.][1] up of output block 2b, acc[.][2] / acc[.][3] of 2b+1
@@ -1851,7 +1888,7 @@ void gemm_bf16_flow_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* _
                     __builtin_amdgcn_raw_buffer_store_b128(u32x4{a0, a1, b0, b1}, crs, off0 + (uint32_t)(i * 16 * ldc * 2), 0, 0);
                 });
             }
-            extra4 = NST / 4;
+            extra4 = EPI == 5 ? 2 : NST / 4;                  // EPI 5: only the lower half's 8 stores are still in flight (vmcnt(0) above)
         }
         __builtin_amdgcn_sched_barrier(0);
         if (!more) break;
@@ -2238,8 +2275,8 @@ static bool flow_scratch_free() {
     static int ok = -1;
     if (ok < 0) {
         ok = 1;
-        const void* fns[5] = {(const void*)gemm_bf16_flow_k<0>, (const void*)gemm_bf16_flow_k<1>, (const void*)gemm_bf16_flow_k<2>,
-                              (const void*)gemm_bf16_flow_k<3>, (const void*)gemm_bf16_flow_k<4>};
+        const void* fns[6] = {(const void*)gemm_bf16_flow_k<0>, (const void*)gemm_bf16_flow_k<1>, (const void*)gemm_bf16_flow_k<2>,
+                              (const void*)gemm_bf16_flow_k<3>, (const void*)gemm_bf16_flow_k<4>, (const void*)gemm_bf16_flow_k<5>};
         for (const void* f : fns) {
             hipFuncAttributes at;
             if (hipFuncGetAttributes(&at, f) != hipSuccess || at.localSizeBytes != 0) ok = 0;
@@ -2291,7 +2328,10 @@ extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
     const bool can256 = (K % BK == 0);
     const bool big = can256 && M >= 512 && N >= 256;
     // flow kernel: epilogues that need only the accumulators (and a bias row), bf16 out, whole waves in or out of N
-    const bool flow_ok = can256 && K >= 128 && M >= 512 && N >= 256 && N % 64 == 0 && e->out_dtype == LICV_BF16 && !e->residual && !e->row_gate &&
+    // ... or a bf16 residual (EPI 5: the ViT out / fc2 projections, usually in place) with no activation, gate or scale
+    const bool flow_res = e->residual && e->residual_dtype == LICV_BF16 && !e->act && !e->swiglu && e->ld_res % 8 == 0 &&
+                          (int64_t)(M + 256) * e->ld_res * 2 < (1ll << 31);
+    const bool flow_ok = can256 && K >= 128 && M >= 512 && N >= 256 && N % 64 == 0 && e->out_dtype == LICV_BF16 && (!e->residual || flow_res) && !e->row_gate &&
                          !e->use_scale && (int64_t)(M + 256) * ldc * 2 < (1ll << 31) && ldc % 8 == 0 &&
                          (!e->bias_bf16 || ((uintptr_t)e->bias_bf16 & 3) == 0);
     const bool use256 = g_force_kernel >= 2 ? can256 : (g_force_kernel == 1 ? false : big);
@@ -2309,11 +2349,16 @@ extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
             (void)hipFuncSetAttribute((const void*)gemm_bf16_flow_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
             (void)hipFuncSetAttribute((const void*)gemm_bf16_flow_k<3>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
             (void)hipFuncSetAttribute((const void*)gemm_bf16_flow_k<4>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_flow_k<5>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
             flow_attr = true;
         }
 #define FLOW(E) gemm_bf16_flow_k<E><<<grid, block, RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>( \
             (const bf16_t*)A, lda, (const bf16_t*)W, ldw, (bf16_t*)C, (int)ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep.bias, pp_group)
-        if (e->swiglu) FLOW(4); else if (e->act == 1) FLOW(1); else if (e->act == 2) FLOW(2); else if (e->act == 3) FLOW(3); else FLOW(0);
+        if (e->residual)
+            gemm_bf16_flow_k<5><<<grid, block, RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>(
+                (const bf16_t*)A, lda, (const bf16_t*)W, ldw, (bf16_t*)C, (int)ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep.bias, pp_group,
+                (const bf16_t*)e->residual, (int)e->ld_res);
+        else if (e->swiglu) FLOW(4); else if (e->act == 1) FLOW(1); else if (e->act == 2) FLOW(2); else if (e->act == 3) FLOW(3); else FLOW(0);
 #undef FLOW
     } else if (use256) {
         const int tiles_m = (int)((M + 255) / 256), tiles_n = (int)((N + 255) / 256);

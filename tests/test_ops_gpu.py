@@ -257,12 +257,12 @@ def test_gemm_large_tile_kernels_match_general_kernel(variant, M, N, K):
         assert (outs[6][:32].float() - ref).abs().max() <= 2 ** -7 * ref.abs().max()
 
 
-@pytest.mark.parametrize("variant", ["plain", "bias", "bias_gelu", "bias_gelu_tanh", "bias_relu", "swiglu"])
+@pytest.mark.parametrize("variant", ["plain", "bias", "bias_gelu", "bias_gelu_tanh", "bias_relu", "swiglu", "bias_res_bf16", "res_bf16_inplace"])
 @pytest.mark.parametrize("M,N,K", [(700, 576, 192), (1030, 1280, 1280), (4200, 4352, 128), (2304, 3840, 1280)])
 def test_gemm_flow_kernel_matches_general_kernel(variant, M, N, K):
     """The persistent "flow" kernel (select 20: register-direct epilogue, stores left in flight under the next tile's main
     loop, next tile's K stages issued before the epilogue) against the general 128x128 kernel (select 1): bit-identical,
-    for every epilogue family it takes, with ragged M, a partial last tile column (N % 256 != 0), the minimum K (4 stages)
+    for every epilogue family it takes (incl. the bf16 residual, separate and in place: its loads share the counted vmcnt waits), with ragged M, a partial last tile column (N % 256 != 0), the minimum K (4 stages)
     and more tiles than CUs (289: a second tile per workgroup, so the counted vmcnt waits see the previous tile's stores)."""
     from licv import _lib
     o = ops()
@@ -280,11 +280,19 @@ def test_gemm_flow_kernel_matches_general_kernel(variant, M, N, K):
         kw["act"] = "relu"
     elif variant == "swiglu":
         kw["swiglu"] = True
+    res = torch.randn(M, N, generator=g(46)).to(torch.bfloat16).to(DEV) if "res" in variant else None
     outs = {}
     try:
         for sel in (1, 20, 20):
             _lib.lib().licv_gemm_select(sel)
-            outs.setdefault(sel, []).append(o.linear(a, w, **kw).clone())
+            if variant == "bias_res_bf16":                       # residual read from one buffer, result written to another
+                outs.setdefault(sel, []).append(o.linear(a, w, residual=res, **kw).clone())
+            elif variant == "res_bf16_inplace":                  # x += a @ w.T, the ViT out / fc2 projections' form
+                x = res.clone()
+                o.linear(a, w, residual=x, out=x)
+                outs.setdefault(sel, []).append(x)
+            else:
+                outs.setdefault(sel, []).append(o.linear(a, w, **kw).clone())
     finally:
         _lib.lib().licv_gemm_select(0)
     assert torch.equal(outs[1][0], outs[20][0]) and torch.equal(outs[20][0], outs[20][1])
