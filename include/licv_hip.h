@@ -125,15 +125,19 @@ int licv_quantize_rows_fp8(const void* x, int x_dtype, void* q_fp8, float* scale
 int licv_gemm_fp8(const void* Aq, int64_t lda, const float* a_scale, const void* Wq, int64_t ldw, const float* w_scale,
                   void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, const licv_gemm_epilogue* e, void* stream);
 
-/* Kernel selection override for tests and A/B timing: 0 = automatic (256x256 LDS-DMA kernel when M >= 512,
- * N >= 256 and K % 64 == 0; else the general 128x128 kernel), 1 = always the 128x128 kernel, 2 = the 256x256
- * kernel whenever K % 64 == 0.  Process-wide. */
+/* Kernel selection override for tests and A/B timing (process-wide).  0 = automatic: for M >= 512, N >= 256, K % 64 == 0 the
+ * persistent "flow" kernel (register-direct asynchronous epilogue) where the epilogue allows it — plain / bias / activation /
+ * SwiGLU / bias + bf16 residual, bf16 out, N % 64 == 0 — else the lean ping-pong kernel with the staged epilogue; the general
+ * 128 x 128 kernel for everything smaller (M <= 32 with long K: licv_gemm_splitk).  1 = always the 128 x 128 kernel; 2 the round-1
+ * single-barrier 256 x 256 kernel; 6 the round-1 ping-pong kernel; 8 persistent ping-pong; 20 flow wherever eligible; 21 pair kernel
+ * (two K stages per phase); 22 lean ping-pong everywhere (23-27: its ordering / diagnostic builds); 30-37 four-wave kernel and its
+ * timing builds; 40-42 four-wave kernel on 64-deep K tiles.  All full-result variants are bit-identical (tests/test_ops_gpu.py). */
 int licv_gemm_select(int which);
 /* A/B switch for the persistent kernel's per-XCD start stagger (default on). */
 int licv_gemm_stagger(int on);
-/* A/B timing knobs of the default kernel (0: per-XCD start stagger in percent, 1: tile-rows per XCD patch; both off by default;
- * 2: take the persistent "flow" kernel — register-direct asynchronous epilogue — for plain / bias / activation / SwiGLU bf16
- * epilogues in auto mode).  licv_gemm_select(20) forces the flow kernel wherever it is eligible. */
+/* Knobs: 0 per-XCD start stagger of the round-1 ping-pong kernel in percent (off); 1 tile-rows per XCD patch (0 = heuristic);
+ * 2 = 0: never take the flow kernel in auto mode; 4 = 0: licv_gemm_splitk_plan always answers "one pass" (split-K off for every
+ * caller, the native layer runner included: the batch-independence tests compare bit for bit). */
 int licv_gemm_experiment(int knob, int value);
 /* 1 if the flow kernel may be dispatched (its code objects use no scratch memory: its counted waits rely on that), else 0 */
 int licv_gemm_flow_available(void);
