@@ -262,6 +262,9 @@ def main():
     if args.gemm_select:
         from licv import _lib
         _lib.lib().licv_gemm_select(args.gemm_select)
+    if os.environ.get("LICV_NO_FOLD"):                        # diagnostic A/B only
+        from licv import _lib
+        _lib.lib().licv_runner_option(0, 0)
     from licv.config import idefics_arch
     from licv.idefics_engine import IdeficsEngine, IdeficsWeights
     from licv.roofline import PEAK_BF16_TFLOPS, PEAK_HBM_GBS, flops_per_question, inject_bytes_per_question
@@ -287,6 +290,8 @@ def main():
         eng = IdeficsEngine(IdeficsWeights(sd, arch, dev))
     if args.batch_streams >= 0 and hasattr(eng, "batch_streams"):
         eng.batch_streams = args.batch_streams
+    if os.environ.get("LICV_NO_FOLD") and hasattr(eng, "fold_residual"):
+        eng.fold_residual = False
     want_g0 = (rank == 0 and world == 1 and not is2 and not training and "generate" not in args.workload and not args.no_gpu_baseline
                and not args.no_hooks)
     if not want_g0:

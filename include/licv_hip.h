@@ -45,6 +45,15 @@ int licv_inject_renorm_add_fwd(const void* branch, int branch_dtype, const float
                                const void* residual, int residual_dtype, float* out, int64_t rows, int64_t hidden,
                                const void* norm_w, void* xn_out, float norm_eps, int norm_flavour, void* stream);
 
+/* The layer-output hook with the layer's LAST RESIDUAL ADD folded in (hf:idefics/modeling_idefics.py:760-763, `hidden_states =
+ * residual + hidden_states` at the end of IdeficsDecoderLayer.forward, then ref:icv_src/icv_model/icv_intervention.py:62-84 on that
+ * output): the tensor edited is h + branch in the stream's dtype (a bf16 stream rounds the sum to bf16, an fp32 stream adds in
+ * fp32 — bit for bit what the down projection's residual epilogue wrote), so the down projection can leave its bf16 branch
+ * through the register-direct GEMM epilogue.  Otherwise as licv_inject_renorm_fwd. */
+int licv_inject_renorm_pre_fwd(const void* h, int h_dtype, const void* branch_bf16, const float* icv_row, const float* alpha,
+                               float* out, int64_t rows, int64_t hidden,
+                               const void* norm_w, void* xn_out, float norm_eps, void* stream);
+
 /* backward of the hook for training (gradients reach icv and alpha only through here;
  * ref:icv_src/icv_module.py:97-98 runs the student pass with grad).  grad_h may be NULL.
  * grad_v_partial: (n_partials, hidden) fp32 workspace, fully overwritten; the caller sums over
@@ -62,6 +71,11 @@ int licv_inject_renorm_bwd(const void* h, int h_dtype, const float* icv_row, con
 int licv_rmsnorm_fwd(const void* x, int x_dtype, const void* w_bf16, void* out_bf16,
                      int64_t rows, int64_t dim, int64_t inner, int64_t ld_x, int64_t ld_out,
                      float eps, int flavour, void* stream);
+/* h += branch in place (the stream's dtype: bf16 rounds the sum; hf:idefics/modeling_idefics.py:741-743, the residual add after
+ * self-attention), then out_bf16 = RMSNorm(h) (the post-attention norm, :745): the o-projection's residual epilogue folded into the
+ * norm that follows it.  Dense rows (ld = dim). */
+int licv_add_rmsnorm_fwd(void* h, int h_dtype, const void* branch_bf16, const void* w_bf16, void* out_bf16,
+                         int64_t rows, int64_t dim, float eps, int flavour, void* stream);
 /* nn.LayerNorm on a bf16 tensor (hf:idefics/vision.py:286-299, perceiver.py:140-141,155-156): fp32
  * statistics, one rounding.  Input rows addressed as for RMSNorm; output row r goes to
  *   out + (r / inner)*ld_out + (r % inner)*dim + (out_group > 0 ? (r / out_group)*out_group_extra : 0)
@@ -262,6 +276,10 @@ typedef struct {
     void* workspace; int64_t workspace_bytes;          /* split-K scratch (licv_workspace_size) */
     void* logits; int64_t ld_logits;                   /* (rows, ld_logits >= vocab_total) bf16 */
 } licv_idefics_text_call;
+/* Options of the runner: 0 = fold the decoder layers' two residual adds into the row kernels that follow (licv_add_rmsnorm_fwd,
+ * licv_inject_renorm_pre_fwd) when M >= 512, so the o / down projections take the register-direct GEMM epilogue (default 1;
+ * bit-identical either way, 0 is for A/B timing). */
+int licv_runner_option(int option, int value);
 int licv_idefics_text_forward(const licv_idefics_text_weights* w, const licv_idefics_text_call* c, void* stream);
 
 /* ---- device-side front-end: integer rules between the collator / processor and the first GEMM ---- */

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK)
 void inject_renorm_fwd_k(const void* __restrict__ h, const float* __restrict__ icv, const float* __restrict__ alpha,
                          float* __restrict__ out, int64_t rows, int hidden,
                          const bf16_t* __restrict__ norm_w, bf16_t* __restrict__ xn, float eps,
-                         const void* __restrict__ res, int res_dt, int norm_flavour) {
+                         const void* __restrict__ res, int res_dt, int norm_flavour, const bf16_t* __restrict__ pre = nullptr) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -50,7 +50,12 @@ void inject_renorm_fwd_k(const void* __restrict__ h, const float* __restrict__ i
     for (int c = 0; c < NCH; ++c) {
         const int i = (c * 64 + lane) * 4;
         if (i < hidden) {
-            const floatx4 hv = RowIO<DT>::load4(h, base + i);
+            floatx4 hv = RowIO<DT>::load4(h, base + i);
+            if (pre) {      // the layer's last residual add, h + branch in the stream's dtype, folded in (it was the down projection's epilogue)
+                const floatx4 bv = RowIO<LICV_BF16>::load4(pre, base + i);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) hv[j] = (DT == LICV_BF16) ? rbf(hv[j] + bv[j]) : hv[j] + bv[j];
+            }
             const floatx4 vv = *reinterpret_cast<const floatx4*>(icv + i);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -200,6 +205,52 @@ void rmsnorm_fwd_k(const void* __restrict__ x, const bf16_t* __restrict__ w, bf1
                 y[j] = wv[j] * (single_round ? n : rbf(n));
             }
             store4_bf16(out, ob + i, y);
+        }
+    }
+}
+
+// h += branch (in place, in the stream's dtype: a bf16 stream rounds the sum — the o-projection's residual epilogue, folded in here so
+// that GEMM writes its bf16 branch through the register-direct epilogue), then the RMSNorm of the new h.
+template <int DT, int NCH>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK)
+void add_rmsnorm_fwd_k(void* __restrict__ h, const bf16_t* __restrict__ branch, const bf16_t* __restrict__ w, bf16_t* __restrict__ out,
+                       int64_t rows, int dim, float eps, int flavour) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int64_t base = row * dim;
+    floatx4 v[NCH];
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int i = (c * 64 + lane) * 4;
+        if (i < dim) {
+            v[c] = RowIO<DT>::load4(h, base + i);
+            const floatx4 bv = RowIO<LICV_BF16>::load4(branch, base + i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[c][j] = (DT == LICV_BF16) ? rbf(v[c][j] + bv[j]) : v[c][j] + bv[j];
+                ss += v[c][j] * v[c][j];
+            }
+            if (DT == LICV_BF16) store4_bf16(h, base + i, v[c]);
+            else *reinterpret_cast<floatx4*>(reinterpret_cast<float*>(h) + base + i) = v[c];
+        }
+    }
+    ss = wave_sum(ss);
+    const float rs = rsqrtf(ss / (float)dim + eps);
+    const bool single_round = (flavour == 1 && DT == LICV_F32);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int i = (c * 64 + lane) * 4;
+        if (i < dim) {
+            const floatx4 wv = RowIO<LICV_BF16>::load4(w, i);
+            floatx4 y;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float n = v[c][j] * rs;
+                y[j] = wv[j] * (single_round ? n : rbf(n));
+            }
+            store4_bf16(out, base + i, y);
         }
     }
 }
@@ -566,12 +617,23 @@ static inline int flat_blocks(int64_t total) {
     default: return licv_set_error(LICV_E_UNSUPPORTED, "row length %lld too large", (long long)dim_); }
 
 static int inject_fwd_impl(const void* h, int h_dtype, const float* icv_row, const float* alpha, float* out, int64_t rows, int64_t hidden,
-                           const void* norm_w, void* xn_out, float norm_eps, const void* res, int res_dt, int norm_flavour, void* stream);
+                           const void* norm_w, void* xn_out, float norm_eps, const void* res, int res_dt, int norm_flavour, void* stream,
+                           const void* pre);
 
 extern "C" int licv_inject_renorm_fwd(const void* h, int h_dtype, const float* icv_row, const float* alpha,
                                       float* out, int64_t rows, int64_t hidden,
                                       const void* norm_w, void* xn_out, float norm_eps, void* stream) {
-    return inject_fwd_impl(h, h_dtype, icv_row, alpha, out, rows, hidden, norm_w, xn_out, norm_eps, nullptr, 0, 0, stream);
+    return inject_fwd_impl(h, h_dtype, icv_row, alpha, out, rows, hidden, norm_w, xn_out, norm_eps, nullptr, 0, 0, stream, nullptr);
+}
+
+// The same hook with the layer's last residual add folded in: the edited tensor is h + branch (the stream's dtype: a bf16 stream
+// rounds the sum, an fp32 stream does not — exactly what the down projection's residual epilogue produced), so that GEMM can
+// write its bf16 branch through the register-direct epilogue instead of a read-modify-write of the fp32 stream.
+extern "C" int licv_inject_renorm_pre_fwd(const void* h, int h_dtype, const void* branch_bf16, const float* icv_row, const float* alpha,
+                                          float* out, int64_t rows, int64_t hidden,
+                                          const void* norm_w, void* xn_out, float norm_eps, void* stream) {
+    LICV_CHECK_ARG(branch_bf16, "inject_renorm_pre_fwd: null branch");
+    return inject_fwd_impl(h, h_dtype, icv_row, alpha, out, rows, hidden, norm_w, xn_out, norm_eps, nullptr, 0, 0, stream, branch_bf16);
 }
 
 extern "C" int licv_inject_renorm_add_fwd(const void* branch, int branch_dtype, const float* icv_row, const float* alpha,
@@ -581,11 +643,12 @@ extern "C" int licv_inject_renorm_add_fwd(const void* branch, int branch_dtype, 
     LICV_CHECK_ARG(residual_dtype == LICV_BF16 || residual_dtype == LICV_F32, "inject_renorm_add_fwd: bad residual dtype");
     LICV_CHECK_ARG(norm_flavour == 0 || norm_flavour == 1, "inject_renorm_add_fwd: bad norm flavour");
     return inject_fwd_impl(branch, branch_dtype, icv_row, alpha, out, rows, hidden, norm_w, xn_out, norm_eps, residual, residual_dtype,
-                           norm_flavour, stream);
+                           norm_flavour, stream, nullptr);
 }
 
 static int inject_fwd_impl(const void* h, int h_dtype, const float* icv_row, const float* alpha, float* out, int64_t rows, int64_t hidden,
-                           const void* norm_w, void* xn_out, float norm_eps, const void* res, int res_dt, int norm_flavour, void* stream) {
+                           const void* norm_w, void* xn_out, float norm_eps, const void* res, int res_dt, int norm_flavour, void* stream,
+                           const void* pre) {
     LICV_CHECK_ARG(h && icv_row && out, "inject_renorm_fwd: null pointer");
     LICV_CHECK_ARG(hidden > 0 && hidden % 4 == 0, "inject_renorm_fwd: hidden (%lld) must be a positive multiple of 4", (long long)hidden);
     LICV_CHECK_ARG(h_dtype == LICV_BF16 || h_dtype == LICV_F32, "inject_renorm_fwd: bad dtype %d", h_dtype);
@@ -597,7 +660,7 @@ static int inject_fwd_impl(const void* h, int h_dtype, const float* icv_row, con
     const dim3 grid(row_blocks(rows)), block(64 * WAVES_PER_BLOCK);
     const bool fuse = norm_w != nullptr;
 #define LAUNCH_INJ(DTV, FUSE) inject_renorm_fwd_k<DTV, N, FUSE><<<grid, block, 0, st>>>( \
-        h, icv_row, alpha, out, rows, (int)hidden, (const bf16_t*)norm_w, (bf16_t*)xn_out, norm_eps, res, res_dt, norm_flavour)
+        h, icv_row, alpha, out, rows, (int)hidden, (const bf16_t*)norm_w, (bf16_t*)xn_out, norm_eps, res, res_dt, norm_flavour, (const bf16_t*)pre)
     if (h_dtype == LICV_F32) { if (fuse) { DISPATCH_NCH(nch, LAUNCH_INJ(LICV_F32, true)); } else { DISPATCH_NCH(nch, LAUNCH_INJ(LICV_F32, false)); } }
     else                     { if (fuse) { DISPATCH_NCH(nch, LAUNCH_INJ(LICV_BF16, true)); } else { DISPATCH_NCH(nch, LAUNCH_INJ(LICV_BF16, false)); } }
 #undef LAUNCH_INJ
@@ -648,6 +711,24 @@ extern "C" int licv_rmsnorm_fwd(const void* x, int x_dtype, const void* w, void*
 #define LAUNCH_RMS(DTV) rmsnorm_fwd_k<DTV, N><<<grid, block, 0, st>>>(x, (const bf16_t*)w, (bf16_t*)out, rows, (int)dim, inner, ld_x, ld_out, eps, flavour)
     if (x_dtype == LICV_F32) { DISPATCH_NCH(nch, LAUNCH_RMS(LICV_F32)); } else { DISPATCH_NCH(nch, LAUNCH_RMS(LICV_BF16)); }
 #undef LAUNCH_RMS
+    LICV_LAUNCH_CHECK();
+    return LICV_OK;
+}
+
+extern "C" int licv_add_rmsnorm_fwd(void* h, int h_dtype, const void* branch_bf16, const void* w, void* out, int64_t rows, int64_t dim,
+                                    float eps, int flavour, void* stream) {
+    LICV_CHECK_ARG(h && branch_bf16 && w && out, "add_rmsnorm_fwd: null pointer");
+    LICV_CHECK_ARG(dim > 0 && dim % 4 == 0, "add_rmsnorm_fwd: dim (%lld) must be a multiple of 4", (long long)dim);
+    LICV_CHECK_ARG(h_dtype == LICV_BF16 || h_dtype == LICV_F32, "add_rmsnorm_fwd: bad dtype %d", h_dtype);
+    LICV_CHECK_ARG(flavour == 0 || flavour == 1, "add_rmsnorm_fwd: bad flavour %d", flavour);
+    if (rows <= 0) return LICV_OK;
+    const int64_t dim_ = dim;
+    const int nch = pick_nch(dim);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(row_blocks(rows)), block(64 * WAVES_PER_BLOCK);
+#define LAUNCH_ARMS(DTV) add_rmsnorm_fwd_k<DTV, N><<<grid, block, 0, st>>>(h, (const bf16_t*)branch_bf16, (const bf16_t*)w, (bf16_t*)out, rows, (int)dim, eps, flavour)
+    if (h_dtype == LICV_F32) { DISPATCH_NCH(nch, LAUNCH_ARMS(LICV_F32)); } else { DISPATCH_NCH(nch, LAUNCH_ARMS(LICV_BF16)); }
+#undef LAUNCH_ARMS
     LICV_LAUNCH_CHECK();
     return LICV_OK;
 }

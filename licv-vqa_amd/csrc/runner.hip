@@ -47,6 +47,13 @@ int linear(const Ctx& x, const void* A, int64_t M, const void* W, int64_t N, int
 }
 }  // namespace
 
+static int g_fold_residual = 1;
+// option 0: fold the decoder layers' residual adds into the row kernels that follow them (default 1; 0 for A/B timing)
+extern "C" int licv_runner_option(int option, int value) {
+    if (option == 0) { g_fold_residual = value; return LICV_OK; }
+    return licv_set_error(LICV_E_BADARG, "runner_option: unknown option %d", option);
+}
+
 extern "C" int licv_idefics_text_forward(const licv_idefics_text_weights* w, const licv_idefics_text_call* c, void* stream) {
     LICV_CHECK_ARG(w && c, "idefics_text_forward: null argument");
     LICV_CHECK_ARG(w->dec && w->embed && w->final_ln && w->lm_head && w->cos && w->sin, "idefics_text_forward: missing weights");
@@ -115,11 +122,28 @@ extern "C" int licv_idefics_text_forward(const licv_idefics_text_weights* w, con
             a.k = cache; a.v = (const char*)cache + H * 2; a.kv_bs = c->cache_max_len * 2 * H; a.kv_rs = 2 * H; a.Sk = c->Sk;
         }
         RUN(licv_attn_fwd(&a, stream));
-        RUN(linear(x, c->o, M, D.o_w, H, H, x.h, H, x.h_dt, x.h, x.h_dt));
-        RUN(licv_rmsnorm_fwd(x.h, x.h_dt, D.post_ln, c->x, M, H, 1, H, H, w->rms_eps, 0, stream));
-        RUN(linear(x, c->x, M, D.gu_w, 2 * I, H, c->act, I, LICV_BF16, nullptr, 0, nullptr, nullptr, 1));
-        RUN(linear(x, c->act, M, D.down_w, H, I, x.h, H, x.h_dt, x.h, x.h_dt));
         const int slot = (c->hook_slot && c->icv) ? c->hook_slot[l] : -1;
+        // Large batches (the 256-tile GEMMs): the two residual adds of the layer leave the GEMM epilogues — a read-modify-write of the
+        // fp32 stream costs the o / down projections 16-28 % — and are folded into the row kernels that follow them (same sums, same
+        // rounding: bit-identical): the projections write their bf16 branch (c->q is free here) through the register-direct epilogue.
+        const bool fold = M >= 512 && g_fold_residual;
+        if (fold) {
+            RUN(linear(x, c->o, M, D.o_w, H, H, c->q, H, LICV_BF16));
+            RUN(licv_add_rmsnorm_fwd(x.h, x.h_dt, c->q, D.post_ln, c->x, M, H, w->rms_eps, 0, stream));
+        } else {
+            RUN(linear(x, c->o, M, D.o_w, H, H, x.h, H, x.h_dt, x.h, x.h_dt));
+            RUN(licv_rmsnorm_fwd(x.h, x.h_dt, D.post_ln, c->x, M, H, 1, H, H, w->rms_eps, 0, stream));
+        }
+        RUN(linear(x, c->x, M, D.gu_w, 2 * I, H, c->act, I, LICV_BF16, nullptr, 0, nullptr, nullptr, 1));
+        if (fold && slot >= 0) {
+            RUN(linear(x, c->act, M, D.down_w, H, I, c->q, H, LICV_BF16));
+            RUN(licv_inject_renorm_pre_fwd(x.h, x.h_dt, c->q, c->icv + (int64_t)slot * H, c->alpha ? c->alpha + slot : nullptr, (float*)c->h32, M, H,
+                                           next_norm(l), c->xn, w->rms_eps, stream));
+            x.h = c->h32; x.h_dt = LICV_F32;
+            xn_valid = true;
+            continue;
+        }
+        RUN(linear(x, c->act, M, D.down_w, H, I, x.h, H, x.h_dt, x.h, x.h_dt));
         if (slot >= 0) {                                   // the hook (ref:icv_src/icv_model/icv_intervention.py:61-86) fused with the next RMSNorm
             RUN(licv_inject_renorm_fwd(x.h, x.h_dt, c->icv + (int64_t)slot * H, c->alpha ? c->alpha + slot : nullptr, (float*)c->h32, M, H,
                                        next_norm(l), c->xn, w->rms_eps, stream));

@@ -170,6 +170,7 @@ class Idefics2Engine:
         self.batch_streams = 2
         self._side_streams = []
         self._slice_views = {}
+        self.fold_residual = True              # o-projection residual add folded into the post-attention RMSNorm (bit-identical; False for A/B)
 
     def _views(self, t: Optional[torch.Tensor], cut):
         """Slices of `t` along dim 0, the SAME view objects on every call for the same parent tensor at the same version: the
@@ -359,8 +360,11 @@ class Idefics2Engine:
                 cache[:, past:Sk] = qkv.view(B, S, ldq)[:, :, qd:]                         # append K|V (device copy)
                 o = ops.attention(qkv, cache, cache.view(-1)[kd:], B, S, Sk, nh, nkv, hd, S * ldq, ldq, kv_cache.max_len * 2 * kd, 2 * kd,
                                   hd ** -0.5, 1, key_valid=key_valid)
-            self._tlin(o.view(M, qd), L, "o_w", residual=h, out=h)
-            x = ops.rmsnorm(h, L.post_ln, a.rms_eps, 1)
+            if M >= 512 and capture is None and self.fold_residual:   # the residual add folded into the norm that follows (as in IdeficsEngine): bit-identical
+                x = ops.add_rmsnorm_(h, self._tlin(o.view(M, qd), L, "o_w"), L.post_ln, a.rms_eps, 1)
+            else:
+                self._tlin(o.view(M, qd), L, "o_w", residual=h, out=h)
+                x = ops.rmsnorm(h, L.post_ln, a.rms_eps, 1)
             act = self._tlin(x, L, "gu_w", swiglu=True)
             del qkv, o, x
             if l in idx_of:

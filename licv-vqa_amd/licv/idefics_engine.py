@@ -364,9 +364,25 @@ class IdeficsEngine:
                 cache[:, past:past + S] = qkv.view(B, S, 3 * H)[:, :, H:]          # append K|V (device copy)
                 o = ops.attention(qkv, cache, cache.view(-1)[H:], B, S, Sk, nh, nh, hd, S * 3 * H, 3 * H,
                                   kv_cache.max_len * 2 * H, 2 * H, hd ** -0.5, 1, key_valid=key_valid)
-            ops.linear(o.view(M, H), D.o_w, residual=h, out=h)
-            x = ops.rmsnorm(h, D.post_ln, a.rms_eps)
+            # Large batches (the 256-tile GEMMs), nothing captured: the layer's two residual adds leave the GEMM epilogues (a
+            # read-modify-write of the fp32 stream costs the o / down projections 16-28 %) and are folded into the row kernels that
+            # follow — same sums, same rounding points, bit-identical — so both projections take the register-direct epilogue
+            fold = M >= 512 and capture is None and save_hook_inputs is None and self.fuse_hook_norm
+            if fold:
+                x = ops.add_rmsnorm_(h, ops.linear(o.view(M, H), D.o_w), D.post_ln, a.rms_eps)
+            else:
+                ops.linear(o.view(M, H), D.o_w, residual=h, out=h)
+                x = ops.rmsnorm(h, D.post_ln, a.rms_eps)
             act = ops.linear(x, D.gu_w, swiglu=True)
+            if fold and l in idx_of:
+                i = idx_of[l]
+                br = ops.linear(act, D.down_w)
+                del qkv, o, act
+                h, xn = ops.inject_renorm(h, icv[0, i], alpha=alpha[0, i:i + 1] if alpha is not None else None,
+                                          out=h if h.dtype == torch.float32 else None, norm_weight=next_norm_weight(l),
+                                          norm_eps=a.rms_eps, pre=br)
+                del br
+                continue
             ops.linear(act, D.down_w, residual=h, out=h)
             del qkv, o, act
             if capture is not None:

@@ -63,9 +63,10 @@ def _bf16c(t: torch.Tensor, name: str):
 # ------------------------------------------------------------------------------------------ hook
 def inject_renorm(h: torch.Tensor, icv_row: torch.Tensor, alpha: Optional[torch.Tensor] = None,
                   out: Optional[torch.Tensor] = None, norm_weight: Optional[torch.Tensor] = None,
-                  norm_eps: float = 1e-6):
+                  norm_eps: float = 1e-6, pre: Optional[torch.Tensor] = None):
     """h: (..., H) bf16/fp32 contiguous; icv_row: (H,) fp32; alpha: 0-d/1-elem fp32 tensor or None.
-    Returns fp32 h' (and the bf16 RMSNorm of h' when norm_weight is given)."""
+    Returns fp32 h' (and the bf16 RMSNorm of h' when norm_weight is given).
+    pre: bf16 branch (same shape) added to h first, in h's dtype — the layer's last residual add folded into the hook."""
     H = h.shape[-1]
     assert h.is_contiguous() and icv_row.dtype == torch.float32 and icv_row.numel() == H and icv_row.is_contiguous()
     rows = h.numel() // H
@@ -77,9 +78,14 @@ def inject_renorm(h: torch.Tensor, icv_row: torch.Tensor, alpha: Optional[torch.
         xn = torch.empty(h.shape, dtype=torch.bfloat16, device=h.device)
     if alpha is not None:
         assert alpha.dtype == torch.float32 and alpha.numel() == 1
-    nbytes = rows * H * (h.element_size() + 4 + (2 if norm_weight is not None else 0))
-    _timed("inject", float(nbytes), lambda: check(_lib.lib().licv_inject_renorm_fwd(
-        _p(h), _dt(h), _p(icv_row), _p(alpha), _p(out), rows, H, _p(norm_weight), _p(xn), float(norm_eps), _stream(h))))
+    nbytes = rows * H * (h.element_size() + 4 + (2 if norm_weight is not None else 0) + (2 if pre is not None else 0))
+    if pre is not None:
+        assert pre.dtype == torch.bfloat16 and pre.is_contiguous() and pre.numel() == h.numel()
+        _timed("inject", float(nbytes), lambda: check(_lib.lib().licv_inject_renorm_pre_fwd(
+            _p(h), _dt(h), _p(pre), _p(icv_row), _p(alpha), _p(out), rows, H, _p(norm_weight), _p(xn), float(norm_eps), _stream(h))))
+    else:
+        _timed("inject", float(nbytes), lambda: check(_lib.lib().licv_inject_renorm_fwd(
+            _p(h), _dt(h), _p(icv_row), _p(alpha), _p(out), rows, H, _p(norm_weight), _p(xn), float(norm_eps), _stream(h))))
     return (out, xn) if norm_weight is not None else out
 
 
@@ -119,6 +125,16 @@ def inject_renorm_bwd(h: torch.Tensor, icv_row: torch.Tensor, alpha: Optional[to
 
 
 # ------------------------------------------------------------------------------------------ norms
+def add_rmsnorm_(h: torch.Tensor, branch: torch.Tensor, w: torch.Tensor, eps: float, flavour: int = 0) -> torch.Tensor:
+    """h += branch (in place, h's dtype: a bf16 stream rounds the sum), returns the bf16 RMSNorm of the new h."""
+    dim = h.shape[-1]
+    assert h.is_contiguous() and branch.is_contiguous() and branch.dtype == torch.bfloat16 and branch.numel() == h.numel()
+    _bf16c(w, "w")
+    out = torch.empty(h.shape, dtype=torch.bfloat16, device=h.device)
+    check(_lib.lib().licv_add_rmsnorm_fwd(_p(h), _dt(h), _p(branch), _p(w), _p(out), h.numel() // dim, dim, float(eps), flavour, _stream(h)))
+    return out
+
+
 def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float, flavour: int = 0, out: Optional[torch.Tensor] = None,
             inner: int = 1, ld_x: Optional[int] = None, ld_out: Optional[int] = None, rows: Optional[int] = None,
             dim: Optional[int] = None):

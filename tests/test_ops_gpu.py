@@ -624,3 +624,31 @@ def test_gemm_skinny_weight_streaming_kernel(M, N, K, epi):
     if epi == "plain":
         exact = (a.double().cpu() @ w.double().cpu().T)
         assert (y1.double().cpu() - exact).abs().max() <= 2.0 ** -8 * exact.abs().max() * 1.01
+
+
+# ------------------------------------------------------------------------------------------- residual adds folded into row kernels
+@pytest.mark.parametrize("stream_dtype", [torch.bfloat16, torch.float32])
+def test_add_rmsnorm_and_hook_with_pre_added_branch_match_the_residual_epilogue(stream_dtype):
+    """h += branch folded into the RMSNorm (o projection) and into the hook (down projection): bit-identical to the GEMM's own
+    residual epilogue followed by the plain kernels, on a bf16 stream (the sum is rounded) and on an fp32 stream."""
+    o = ops()
+    M, H, K = 640, 512, 256
+    a = torch.randn(M, K, generator=g(90)).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(H, K, generator=g(91)) * 0.05).to(torch.bfloat16).to(DEV)
+    lnw = (1 + 0.1 * torch.randn(H, generator=g(92))).to(torch.bfloat16).to(DEV)
+    h0 = torch.randn(M, H, generator=g(93)).to(stream_dtype).to(DEV)
+    icv = (torch.randn(H, generator=g(94)) * 0.3).to(DEV)
+    alpha = torch.tensor([0.7], device=DEV)
+    # reference route: residual epilogue, then the plain kernels
+    h_ref = h0.clone()
+    o.linear(a, w, residual=h_ref, out=h_ref)
+    x_ref = o.rmsnorm(h_ref, lnw, 1e-6)
+    e_ref, xn_ref = o.inject_renorm(h_ref, icv, alpha=alpha, norm_weight=lnw, norm_eps=1e-6)
+    # folded route
+    br = o.linear(a, w)
+    h1 = h0.clone()
+    x1 = o.add_rmsnorm_(h1, br, lnw, 1e-6)
+    assert torch.equal(h1, h_ref) and torch.equal(x1, x_ref)
+    h2 = h0.clone()
+    e2, xn2 = o.inject_renorm(h2, icv, alpha=alpha, norm_weight=lnw, norm_eps=1e-6, pre=br, out=h2 if stream_dtype == torch.float32 else None)
+    assert e2.dtype == torch.float32 and torch.equal(e2, e_ref) and torch.equal(xn2, xn_ref)
