@@ -73,9 +73,10 @@ int licv_rmsnorm_fwd(const void* x, int x_dtype, const void* w_bf16, void* out_b
                      float eps, int flavour, void* stream);
 /* h += branch in place (the stream's dtype: bf16 rounds the sum; hf:idefics/modeling_idefics.py:741-743, the residual add after
  * self-attention), then out_bf16 = RMSNorm(h) (the post-attention norm, :745): the o-projection's residual epilogue folded into the
- * norm that follows it.  Dense rows (ld = dim). */
-int licv_add_rmsnorm_fwd(void* h, int h_dtype, const void* branch_bf16, const void* w_bf16, void* out_bf16,
-                         int64_t rows, int64_t dim, float eps, int flavour, void* stream);
+ * norm that follows it.  Dense rows (ld = dim).  row_gate (rows fp32, may be NULL) and use_scale / scale reproduce the gated
+ * cross-attention layer's epilogue (:789-791, :799-800): branch row -> 0 where the gate is 0, then bf16(scale * branch). */
+int licv_add_rmsnorm_fwd(void* h, int h_dtype, const void* branch_bf16, const float* row_gate, int use_scale, float scale,
+                         const void* w_bf16, void* out_bf16, int64_t rows, int64_t dim, float eps, int flavour, void* stream);
 /* nn.LayerNorm on a bf16 tensor (hf:idefics/vision.py:286-299, perceiver.py:140-141,155-156): fp32
  * statistics, one rounding.  Input rows addressed as for RMSNorm; output row r goes to
  *   out + (r / inner)*ld_out + (r % inner)*dim + (out_group > 0 ? (r / out_group)*out_group_extra : 0)

@@ -214,11 +214,12 @@ void rmsnorm_fwd_k(const void* __restrict__ x, const bf16_t* __restrict__ w, bf1
 template <int DT, int NCH>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK)
 void add_rmsnorm_fwd_k(void* __restrict__ h, const bf16_t* __restrict__ branch, const bf16_t* __restrict__ w, bf16_t* __restrict__ out,
-                       int64_t rows, int dim, float eps, int flavour) {
+                       int64_t rows, int dim, float eps, int flavour, const float* __restrict__ row_gate, int use_scale, float scale) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int64_t base = row * dim;
+    const bool closed = row_gate && row_gate[row] == 0.0f;           // gated cross-attention: a token that attends no image adds nothing
     floatx4 v[NCH];
     float ss = 0.f;
 #pragma unroll
@@ -226,7 +227,12 @@ void add_rmsnorm_fwd_k(void* __restrict__ h, const bf16_t* __restrict__ branch, 
         const int i = (c * 64 + lane) * 4;
         if (i < dim) {
             v[c] = RowIO<DT>::load4(h, base + i);
-            const floatx4 bv = RowIO<LICV_BF16>::load4(branch, base + i);
+            floatx4 bv = RowIO<LICV_BF16>::load4(branch, base + i);
+            if (closed) bv = floatx4{0.f, 0.f, 0.f, 0.f};
+            if (use_scale) {                                          // tanh(alpha) gate, rounded to bf16 as the GEMM epilogue does
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bv[j] = rbf(scale * bv[j]);
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 v[c][j] = (DT == LICV_BF16) ? rbf(v[c][j] + bv[j]) : v[c][j] + bv[j];
@@ -715,8 +721,8 @@ extern "C" int licv_rmsnorm_fwd(const void* x, int x_dtype, const void* w, void*
     return LICV_OK;
 }
 
-extern "C" int licv_add_rmsnorm_fwd(void* h, int h_dtype, const void* branch_bf16, const void* w, void* out, int64_t rows, int64_t dim,
-                                    float eps, int flavour, void* stream) {
+extern "C" int licv_add_rmsnorm_fwd(void* h, int h_dtype, const void* branch_bf16, const float* row_gate, int use_scale, float scale,
+                                    const void* w, void* out, int64_t rows, int64_t dim, float eps, int flavour, void* stream) {
     LICV_CHECK_ARG(h && branch_bf16 && w && out, "add_rmsnorm_fwd: null pointer");
     LICV_CHECK_ARG(dim > 0 && dim % 4 == 0, "add_rmsnorm_fwd: dim (%lld) must be a multiple of 4", (long long)dim);
     LICV_CHECK_ARG(h_dtype == LICV_BF16 || h_dtype == LICV_F32, "add_rmsnorm_fwd: bad dtype %d", h_dtype);
@@ -726,7 +732,8 @@ extern "C" int licv_add_rmsnorm_fwd(void* h, int h_dtype, const void* branch_bf1
     const int nch = pick_nch(dim);
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(row_blocks(rows)), block(64 * WAVES_PER_BLOCK);
-#define LAUNCH_ARMS(DTV) add_rmsnorm_fwd_k<DTV, N><<<grid, block, 0, st>>>(h, (const bf16_t*)branch_bf16, (const bf16_t*)w, (bf16_t*)out, rows, (int)dim, eps, flavour)
+#define LAUNCH_ARMS(DTV) add_rmsnorm_fwd_k<DTV, N><<<grid, block, 0, st>>>(h, (const bf16_t*)branch_bf16, (const bf16_t*)w, (bf16_t*)out, rows, (int)dim, eps, flavour, \
+                                                                           row_gate, use_scale, scale)
     if (h_dtype == LICV_F32) { DISPATCH_NCH(nch, LAUNCH_ARMS(LICV_F32)); } else { DISPATCH_NCH(nch, LAUNCH_ARMS(LICV_BF16)); }
 #undef LAUNCH_ARMS
     LICV_LAUNCH_CHECK();

@@ -71,6 +71,7 @@ extern "C" int licv_idefics_text_forward(const licv_idefics_text_weights* w, con
 
     RUN(licv_embed_gather(c->input_ids, w->embed, w->embed_extra, c->h16, M, H, w->vocab, w->n_extra_vocab, stream));
     bool xn_valid = false;                                 // c->xn holds RMSNorm(h) for the next block (made by the fused hook kernel)
+    bool pending = false; float pending_scale = 0.f;       // a cross layer's MLP branch waits in c->q for the next norm to add it
     auto next_norm = [&](int64_t l) -> const void* {
         if (l + 1 >= w->n_layers) return w->final_ln;
         if ((l + 1) % w->cross_interval == 0) return w->xat[(l + 1) / w->cross_interval].in_ln;
@@ -98,14 +99,25 @@ extern "C" int licv_idefics_text_forward(const licv_idefics_text_weights* w, con
             a.o = c->o; a.B = B; a.Sq = S; a.Sk = Nk; a.n_heads = nh; a.n_kv_heads = nh; a.head_dim = hd;
             a.scale = att_scale; a.mask_mode = 3; a.key_valid = nullptr; a.img_mask = c->img_mask; a.n_img = c->n_img; a.img_len = w->img_len;
             RUN(licv_attn_fwd(&a, stream));
-            RUN(linear(x, c->o, M, X.o_w, H, H, x.h, H, x.h_dt, x.h, x.h_dt, c->gate, &X.gate_attn));
-            RUN(licv_rmsnorm_fwd(x.h, x.h_dt, X.post_ln, c->x, M, H, 1, H, H, w->rms_eps, 0, stream));
-            RUN(linear(x, c->x, M, X.gu_w, 2 * I, H, c->act, I, LICV_BF16, nullptr, 0, nullptr, nullptr, 1));
-            RUN(linear(x, c->act, M, X.down_w, H, I, x.h, H, x.h_dt, x.h, x.h_dt, nullptr, &X.gate_dense));
+            if (M >= 512 && g_fold_residual) {             // both gated residual adds folded into the norms that follow (see below)
+                RUN(linear(x, c->o, M, X.o_w, H, H, c->q, H, LICV_BF16));
+                RUN(licv_add_rmsnorm_fwd(x.h, x.h_dt, c->q, c->gate, 1, X.gate_attn, X.post_ln, c->x, M, H, w->rms_eps, 0, stream));
+                RUN(linear(x, c->x, M, X.gu_w, 2 * I, H, c->act, I, LICV_BF16, nullptr, 0, nullptr, nullptr, 1));
+                RUN(linear(x, c->act, M, X.down_w, H, I, c->q, H, LICV_BF16));
+                pending_scale = X.gate_dense; pending = true;     // added by the decoder layer's input norm
+            } else {
+                RUN(linear(x, c->o, M, X.o_w, H, H, x.h, H, x.h_dt, x.h, x.h_dt, c->gate, &X.gate_attn));
+                RUN(licv_rmsnorm_fwd(x.h, x.h_dt, X.post_ln, c->x, M, H, 1, H, H, w->rms_eps, 0, stream));
+                RUN(linear(x, c->x, M, X.gu_w, 2 * I, H, c->act, I, LICV_BF16, nullptr, 0, nullptr, nullptr, 1));
+                RUN(linear(x, c->act, M, X.down_w, H, I, x.h, H, x.h_dt, x.h, x.h_dt, nullptr, &X.gate_dense));
+            }
         }
         const licv_idefics_dec_w& D = w->dec[l];           // decoder layer (hf:idefics/modeling_idefics.py:645-675), hooked on its output
         const void* xin = c->xn;
-        if (!xn_valid) { RUN(licv_rmsnorm_fwd(x.h, x.h_dt, D.in_ln, c->x, M, H, 1, H, H, w->rms_eps, 0, stream)); xin = c->x; }
+        if (pending) {                                     // the cross layer's MLP branch (in c->q): h += bf16(gate_dense * branch), then the input norm
+            RUN(licv_add_rmsnorm_fwd(x.h, x.h_dt, c->q, nullptr, 1, pending_scale, D.in_ln, c->x, M, H, w->rms_eps, 0, stream));
+            xin = c->x; pending = false;
+        } else if (!xn_valid) { RUN(licv_rmsnorm_fwd(x.h, x.h_dt, D.in_ln, c->x, M, H, 1, H, H, w->rms_eps, 0, stream)); xin = c->x; }
         xn_valid = false;
         RUN(linear(x, xin, M, D.qkv_w, 3 * H, H, c->qkv, 3 * H, LICV_BF16));
         RUN(licv_rotary_fwd(c->qkv, w->cos, w->sin, c->position_ids, M, nh, hd, 3 * H, H, 2, w->rope_len, stream));
@@ -129,7 +141,7 @@ extern "C" int licv_idefics_text_forward(const licv_idefics_text_weights* w, con
         const bool fold = M >= 512 && g_fold_residual;
         if (fold) {
             RUN(linear(x, c->o, M, D.o_w, H, H, c->q, H, LICV_BF16));
-            RUN(licv_add_rmsnorm_fwd(x.h, x.h_dt, c->q, D.post_ln, c->x, M, H, w->rms_eps, 0, stream));
+            RUN(licv_add_rmsnorm_fwd(x.h, x.h_dt, c->q, nullptr, 0, 0.f, D.post_ln, c->x, M, H, w->rms_eps, 0, stream));
         } else {
             RUN(linear(x, c->o, M, D.o_w, H, H, x.h, H, x.h_dt, x.h, x.h_dt));
             RUN(licv_rmsnorm_fwd(x.h, x.h_dt, D.post_ln, c->x, M, H, 1, H, H, w->rms_eps, 0, stream));

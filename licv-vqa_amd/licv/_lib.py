@@ -65,7 +65,7 @@ def lib() -> C.CDLL:
             "licv_inject_renorm_fwd": [P, I, P, P, P, I64, I64, P, P, F, P],
             "licv_inject_renorm_add_fwd": [P, I, P, P, P, I, P, I64, I64, P, P, F, I, P],
             "licv_inject_renorm_pre_fwd": [P, I, P, P, P, P, I64, I64, P, P, F, P],
-            "licv_add_rmsnorm_fwd": [P, I, P, P, P, I64, I64, F, I, P],
+            "licv_add_rmsnorm_fwd": [P, I, P, P, I, F, P, P, I64, I64, F, I, P],
             "licv_runner_option": [I, I],
             "licv_scatter_rows": [P, P, P, I64, I64, P],
             "licv_ce_rows": [P, I, P, P, I64, I64, I64, P, F, P, P, I64, P, I, P],

@@ -332,6 +332,8 @@ class IdeficsEngine:
                 return w.xat[(l + 1) // a.cross_layer_interval].in_ln
             return w.dec[l + 1].in_ln
 
+        foldable = M >= 512 and capture is None and save_hook_inputs is None and self.fuse_hook_norm
+        pending = None                               # a cross layer's MLP branch (and its gate scale) waiting for the next norm to add it
         for l in range(a.num_layers):
             if l % a.cross_layer_interval == 0:
                 X = w.xat[l // a.cross_layer_interval]
@@ -344,13 +346,22 @@ class IdeficsEngine:
                     ops.rmsnorm(kv, X.kn_w, a.rms_eps, out=kv, inner=nh, ld_x=2 * H, ld_out=2 * H, rows=B * Nk * nh, dim=hd)
                 o = ops.attention(q, kv, kv.view(-1)[H:], B, S, Nk, nh, nh, hd, S * H, H, Nk * 2 * H, 2 * H, hd ** -0.5, 3,
                                   img_mask=img_mask, img_len=img_len)
-                ops.linear(o.view(M, H), X.o_w, row_gate=gate, scale=X.gate_attn, residual=h, out=h)
-                x = ops.rmsnorm(h, X.post_ln, a.rms_eps)
-                act = ops.linear(x, X.gu_w, swiglu=True)
-                ops.linear(act, X.down_w, scale=X.gate_dense, residual=h, out=h)
+                if foldable:                                # both gated residual adds folded into the norms that follow (see below)
+                    x = ops.add_rmsnorm_(h, ops.linear(o.view(M, H), X.o_w), X.post_ln, a.rms_eps, row_gate=gate, scale=X.gate_attn)
+                    act = ops.linear(x, X.gu_w, swiglu=True)
+                    pending = (ops.linear(act, X.down_w), X.gate_dense)     # added by the decoder layer's input norm
+                else:
+                    ops.linear(o.view(M, H), X.o_w, row_gate=gate, scale=X.gate_attn, residual=h, out=h)
+                    x = ops.rmsnorm(h, X.post_ln, a.rms_eps)
+                    act = ops.linear(x, X.gu_w, swiglu=True)
+                    ops.linear(act, X.down_w, scale=X.gate_dense, residual=h, out=h)
                 del q, kv, o, act
             D = w.dec[l]
-            x = xn if xn is not None else ops.rmsnorm(h, D.in_ln, a.rms_eps)
+            if pending is not None:
+                x = ops.add_rmsnorm_(h, pending[0], D.in_ln, a.rms_eps, scale=pending[1])
+                pending = None
+            else:
+                x = xn if xn is not None else ops.rmsnorm(h, D.in_ln, a.rms_eps)
             xn = None
             if kv_cache is None:
                 qkv = ops.linear(x, D.qkv_w)
@@ -367,7 +378,7 @@ class IdeficsEngine:
             # Large batches (the 256-tile GEMMs), nothing captured: the layer's two residual adds leave the GEMM epilogues (a
             # read-modify-write of the fp32 stream costs the o / down projections 16-28 %) and are folded into the row kernels that
             # follow — same sums, same rounding points, bit-identical — so both projections take the register-direct epilogue
-            fold = M >= 512 and capture is None and save_hook_inputs is None and self.fuse_hook_norm
+            fold = foldable
             if fold:
                 x = ops.add_rmsnorm_(h, ops.linear(o.view(M, H), D.o_w), D.post_ln, a.rms_eps)
             else:

@@ -125,13 +125,19 @@ def inject_renorm_bwd(h: torch.Tensor, icv_row: torch.Tensor, alpha: Optional[to
 
 
 # ------------------------------------------------------------------------------------------ norms
-def add_rmsnorm_(h: torch.Tensor, branch: torch.Tensor, w: torch.Tensor, eps: float, flavour: int = 0) -> torch.Tensor:
-    """h += branch (in place, h's dtype: a bf16 stream rounds the sum), returns the bf16 RMSNorm of the new h."""
+def add_rmsnorm_(h: torch.Tensor, branch: torch.Tensor, w: torch.Tensor, eps: float, flavour: int = 0,
+                 row_gate: Optional[torch.Tensor] = None, scale: Optional[float] = None) -> torch.Tensor:
+    """h += branch (in place, h's dtype: a bf16 stream rounds the sum), returns the bf16 RMSNorm of the new h.
+    row_gate (rows,) fp32 / scale: the gated cross-attention epilogue (row -> 0 where the gate is 0, then bf16(scale * branch))."""
     dim = h.shape[-1]
+    rows = h.numel() // dim
     assert h.is_contiguous() and branch.is_contiguous() and branch.dtype == torch.bfloat16 and branch.numel() == h.numel()
     _bf16c(w, "w")
+    if row_gate is not None:
+        assert row_gate.dtype == torch.float32 and row_gate.numel() >= rows
     out = torch.empty(h.shape, dtype=torch.bfloat16, device=h.device)
-    check(_lib.lib().licv_add_rmsnorm_fwd(_p(h), _dt(h), _p(branch), _p(w), _p(out), h.numel() // dim, dim, float(eps), flavour, _stream(h)))
+    check(_lib.lib().licv_add_rmsnorm_fwd(_p(h), _dt(h), _p(branch), _p(row_gate), 0 if scale is None else 1, 0.0 if scale is None else float(scale),
+                                          _p(w), _p(out), rows, dim, float(eps), flavour, _stream(h)))
     return out
 
 

@@ -652,3 +652,11 @@ def test_add_rmsnorm_and_hook_with_pre_added_branch_match_the_residual_epilogue(
     h2 = h0.clone()
     e2, xn2 = o.inject_renorm(h2, icv, alpha=alpha, norm_weight=lnw, norm_eps=1e-6, pre=br, out=h2 if stream_dtype == torch.float32 else None)
     assert e2.dtype == torch.float32 and torch.equal(e2, e_ref) and torch.equal(xn2, xn_ref)
+    # the gated cross-attention form: rows with a closed gate add nothing, the rest bf16(scale * branch)
+    gate = (torch.rand(M, generator=g(95)) > 0.4).float().to(DEV)
+    h_ref = h0.clone()
+    o.linear(a, w, row_gate=gate, scale=0.37, residual=h_ref, out=h_ref)
+    x_ref = o.rmsnorm(h_ref, lnw, 1e-6)
+    h3 = h0.clone()
+    x3 = o.add_rmsnorm_(h3, br, lnw, 1e-6, row_gate=gate, scale=0.37)
+    assert torch.equal(h3, h_ref) and torch.equal(x3, x_ref)
