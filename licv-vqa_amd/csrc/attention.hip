@@ -148,9 +148,22 @@ void attn_fwd_k(AttnP a) {
     const int g = lane >> 4, ql = lane & 15;
     const int qtiles = (a.Sq + QBLK - 1) / QBLK;
     int bid = blockIdx.x;
-    const int qt = bid % qtiles; bid /= qtiles;
-    const int head = bid % a.nh;
-    const int b = bid / a.nh;
+    int qt, pair;
+    if (MODE == 1 && qtiles > 1) {
+        // causal: a query tile's work grows with its index (qt + 1 key tiles).  Within chunks of 32 (batch, head) pairs the heavy
+        // tiles are dispatched first and the light ones last, so the tail of the launch is made of short workgroups; a chunk's K/V
+        // (32 pairs) still fits the L2s, which plain "heaviest first over all pairs" would give up
+        constexpr int CP = 32;                              // 16 ... 256 pairs per chunk measured alike (129-137 us); 8: 157 us; plain order: 175-181 us
+        const int npairs = a.B * a.nh, chunk = CP * qtiles;
+        const int c0 = (bid / chunk) * CP, r = bid % chunk;
+        const int csize = min(CP, npairs - c0);
+        qt = qtiles - 1 - r / csize;
+        pair = c0 + r % csize;
+    } else {
+        qt = bid % qtiles; pair = bid / qtiles;
+    }
+    const int head = pair % a.nh;
+    const int b = pair / a.nh;
     const int kvh = head / (a.nh / a.nkv);
     const int q0 = qt * QBLK;
     const int coff = a.Sk - a.Sq;                          // causal offset (decode steps: Sq < Sk)
