@@ -524,7 +524,11 @@ extern "C" int licv_attn_fwd(const licv_attn_args* x, void* stream) {
     //  (v)   resident kernel, ViT (257 = 16 x 16 + 1 queries: one wave runs 3 sub-tiles, seven run 2): spreading the key tiles of
     //        the lone last sub-tile over the 8 waves and merging the partial (m, l, O) states through LDS: 367 -> 395 us;
     //  (vi)  skipping the accumulator rescale as a wave when alpha == 1 in every lane (bit-identical): ViT 362 -> 372 us, language
-    //        self-attention 174 -> 170 us (tools/attn_bench.py): the branch costs what the 20 multiplies did.
+    //        self-attention 174 -> 170 us (tools/attn_bench.py): the branch costs what the 20 multiplies did;
+    //  (vii) resident kernel with 12 / 16 waves per workgroup (3 / 4 per SIMD, 170 / 128 VGPRs): the hot tile loop is 104 VALU + 22
+    //        MFMA + 32 LDS reads + 20 s_waitcnt per 64 keys and runs at ~47 % issue utilisation with 2 waves per SIMD, but the tile
+    //        function needs ~190 registers beside the K/V prefetch: 88 / 158 spills, 362 -> 440 / 575 us.  More waves in flight
+    //        need a tile function rebuilt for <= 120 registers (K / V^T fragments in halves), not a launch parameter.
     const int hd = p.hd;
     const int64_t qtiles = (x->Sq + ATT_QB - 1) / ATT_QB;
     const int64_t nblk = x->B * x->n_heads * qtiles;
