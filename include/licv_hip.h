@@ -146,7 +146,8 @@ int licv_gemm_fp8(const void* Aq, int64_t lda, const float* a_scale, const void*
  * 128 x 128 kernel for everything smaller (M <= 32 with long K: licv_gemm_splitk).  1 = always the 128 x 128 kernel; 2 the round-1
  * single-barrier 256 x 256 kernel; 6 the round-1 ping-pong kernel; 8 persistent ping-pong; 20 flow wherever eligible; 21 pair kernel
  * (two K stages per phase); 22 lean ping-pong everywhere (23-27: its ordering / diagnostic builds); 30-37 four-wave kernel and its
- * timing builds; 40-42 four-wave kernel on 64-deep K tiles.  All full-result variants are bit-identical (tests/test_ops_gpu.py). */
+ * timing builds; 40-42 four-wave kernel on 64-deep K tiles; 50 two workgroups per CU on 128 x 256 tiles.  All full-result variants are
+ * bit-identical (tests/test_ops_gpu.py). */
 int licv_gemm_select(int which);
 /* A/B switch for the persistent kernel's per-XCD start stagger (default on). */
 int licv_gemm_stagger(int on);

@@ -1276,6 +1276,118 @@ void gemm_bf16_quad64_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t*
 }
 
 // ------------------------------------------------------------------------------------------------
+// "duo" kernel (experiment, select 50): TWO workgroups per CU instead of one with two wave groups.  A workgroup is 4 waves (one per
+// SIMD) on a 128 x 256 tile, 128 x 64 per wave (the same 128 accumulators and the same fragment traffic per MFMA as the ping-pong
+// kernels), with a 3-slot ring of 24 KiB stages (A 128 x 32 | W 256 x 32) = 72 KiB, so two workgroups share a CU.  The two waves
+// of a SIMD belong to DIFFERENT workgroups: nothing synchronises them, one's load phase, pipeline fill and — the point — its
+// whole epilogue run beside the other's MFMAs (a K = 1280 tile of the ping-pong kernels spends 25 % of its time in fill +
+// epilogue with the matrix pipe idle).  Price: a W stage is shared by 128 rows instead of 256: +50 % operand traffic from L2.
+// Same K order and rounding: bit-identical results.
+// ------------------------------------------------------------------------------------------------
+#define DUO_STAGES 3
+#define DUO_STAGE_BYTES 24576
+__global__ __launch_bounds__(256, 2)
+void gemm_bf16_duo_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw,
+                     void* __restrict__ C, int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n, GemmEpi ep, int group) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // [3 stages][A 8 KiB | W 16 KiB]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // = wn: columns 64 wave ... of the tile
+    int tm, tn;
+    tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn, group);
+    const int m0 = tm * 128, n0 = tn * 256;
+    const int ns = K / 32;                                           // >= 3
+
+    // DMA: wave w stages A rows [32w, 32w + 32) (2 pieces) and W rows [64w, 64w + 64) (4 pieces) of every stage
+    const bf16_t* srcA[2];
+    const bf16_t* srcW[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = wave * 32 + i * 16 + (lane >> 2);
+        const int chunk = (lane & 3) ^ (((row >> 2) & 1) << 1);
+        srcA[i] = A + (int64_t)min(m0 + row, M - 1) * lda + chunk * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = wave * 64 + i * 16 + (lane >> 2);
+        const int chunk = (lane & 3) ^ (((row >> 2) & 1) << 1);
+        srcW[i] = W + (int64_t)min(n0 + row, N - 1) * ldw + chunk * 8;
+    }
+    auto issue = [&](int slot_bytes) {
+        char* sa = smem + slot_bytes + wave * 2048;
+        char* sw = smem + slot_bytes + 8192 + wave * 4096;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcA[i],
+                                             (__attribute__((address_space(3))) void*)(sa + i * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcW[i],
+                                             (__attribute__((address_space(3))) void*)(sw + i * 1024), 16, 0, 0);
+    };
+    auto advance = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) srcA[i] += 32;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) srcW[i] += 32;
+    };
+
+    floatx4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    typedef const __attribute__((address_space(3))) char* lds_cptr;
+    typedef const __attribute__((address_space(3))) bf16x8* lds_fptr;
+    const lds_cptr ring = (lds_cptr)smem;
+    const int fo = ring_off(lane & 15, lane >> 4);
+    const int constA = fo, constW = 8192 + wave * 4096 + fo;
+    bf16x8 fa[8], fw[4];
+
+    issue(0); advance(); issue(DUO_STAGE_BYTES); advance();
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");         // my pieces of stage 0 have landed
+    __builtin_amdgcn_s_barrier();                            // stage 0 published
+
+    int slot_rd = 0, slot_wr = 2 * DUO_STAGE_BYTES;
+    lds_cptr rdA = ring + constA, rdW = ring + constW;
+    auto stage = [&](int s, auto steady_c) {
+        constexpr bool STEADY = decltype(steady_c)::value;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fw[j] = *(lds_fptr)(rdW + j * 16 * 64);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fa[i] = *(lds_fptr)(rdA + i * 16 * 64);
+        __builtin_amdgcn_sched_barrier(0);
+        if (STEADY) {
+            issue(slot_wr);                                  // stage s + 2 into the slot stage s - 1 used (its readers passed the last barrier)
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // retires my pieces of stage s + 1
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();                        // stage s + 1 published; every wave holds its fragments of stage s
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        slot_wr = slot_rd;
+        slot_rd = slot_rd == 2 * DUO_STAGE_BYTES ? 0 : slot_rd + DUO_STAGE_BYTES;
+        rdA = ring + (constA + slot_rd);
+        rdW = ring + (constW + slot_rd);
+        if (STEADY) advance();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    int s = 0;
+    for (; s + 2 < ns; ++s) stage(s, std::true_type{});
+    for (; s < ns; ++s) stage(s, std::false_type{});
+    __syncthreads();                           // every wave is done with the ring before it becomes the output image
+    epilogue_staged<128, 256, 4, 8, 4>(acc, ep, C, ldc, M, N, m0, n0, 0, wave * 64, wave, lane, smem);
+}
+
+// ------------------------------------------------------------------------------------------------
 // "pair" kernel: the ping-pong schedule with TWO 32-deep K stages per phase.
 //
 // Measured on the ping-pong kernel (tools/gemm_segments.py, s_memtime stamps, cycles per wave and stage): LOAD phase 600
@@ -2397,6 +2509,13 @@ extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
             gemm_bf16_pair_k<<<grid, block, RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>(
                 (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, pp_group);
         }
+        else if (g_force_kernel == 50 && K >= 128) {
+            static bool a50 = false;
+            if (!a50) { (void)hipFuncSetAttribute((const void*)gemm_bf16_duo_k, hipFuncAttributeMaxDynamicSharedMemorySize, DUO_STAGES * DUO_STAGE_BYTES); a50 = true; }
+            const int tm128 = (int)((M + 127) / 128);
+            gemm_bf16_duo_k<<<dim3(tm128 * tiles_n), dim3(256), DUO_STAGES * DUO_STAGE_BYTES, (hipStream_t)stream>>>(
+                (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tm128, tiles_n, ep, 2 * pp_group);
+        }
         else if (g_force_kernel >= 40 && g_force_kernel <= 42 && K >= 128 && K % 64 == 0 && lean_ok) {
             static bool a40 = false;
             if (!a40) {
@@ -2458,7 +2577,7 @@ extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
             gemm_bf16_lean_k<0, 0><<<grid, block, RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>(
                 (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, pp_group);
         }
-        else if ((g_force_kernel == 0 || g_force_kernel == 9 || g_force_kernel == 20 || (g_force_kernel >= 22 && g_force_kernel <= 42)) && K >= 128)
+        else if ((g_force_kernel == 0 || g_force_kernel == 9 || g_force_kernel == 20 || (g_force_kernel >= 22 && g_force_kernel <= 50)) && K >= 128)
             gemm_bf16_pingpong_k<0><<<grid, block, RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>(
                 (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, pp_ticks, pp_group);
         else LAUNCH256(0);

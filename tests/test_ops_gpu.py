@@ -244,13 +244,14 @@ def test_gemm_large_tile_kernels_match_general_kernel(variant, M, N, K):
     outs = {}
     try:
         # 21: the pair kernel (two K stages per ping-pong phase); 30 / 34 / 36: the four-wave kernel (128 x 128 per wave, pieces in a
-        # burst / spread / hand-issued); 40: the four-wave kernel on 64-deep K tiles (takes K % 64 == 0, else falls back)
-        for sel in (1, 2, 6, 8, 21, 22, 30, 34, 36, 40):
+        # burst / spread / hand-issued); 40: the four-wave kernel on 64-deep K tiles (takes K % 64 == 0, else falls back); 50: the
+        # two-workgroups-per-CU kernel (128 x 256 tiles)
+        for sel in (1, 2, 6, 8, 21, 22, 30, 34, 36, 40, 50):
             _lib.lib().licv_gemm_select(sel)
             outs[sel] = o.linear(a, w, **kw).clone()
     finally:
         _lib.lib().licv_gemm_select(0)
-    for sel in (2, 6, 8, 21, 22, 30, 34, 36, 40):
+    for sel in (2, 6, 8, 21, 22, 30, 34, 36, 40, 50):
         assert torch.equal(outs[1], outs[sel]), f"select {sel} differs from the general kernel"
     ref = (a[:32].float() @ w.float().t())
     if variant == "plain":
