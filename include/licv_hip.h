@@ -305,6 +305,11 @@ int licv_merge_image_rows(void* h_bf16, const int64_t* input_ids, const void* im
 int licv_kl_rows_fwd(const void* stu_logits, const void* tea_logits, int dtype,
                      const int64_t* stu_rows, const int64_t* tea_rows, int64_t n_rows, int64_t vocab,
                      int64_t ld_stu, int64_t ld_tea, float temperature, float eps, float* out_rows, void* stream);
+/* d/dT of the same per-row sum (ref:icv_src/icv_module.py:49-52: `temperature` is a Parameter, trainable with learnable_t);
+ * the caller forms dL/dT = T^2 * mean(out_rows) + 2 T * mean(kl_rows).  out_rows fp32 (n_rows). */
+int licv_kl_rows_dtemp(const void* stu_logits, const void* tea_logits, int dtype,
+                       const int64_t* stu_rows, const int64_t* tea_rows, int64_t n_rows, int64_t vocab,
+                       int64_t ld_stu, int64_t ld_tea, float temperature, float eps, float* out_rows, void* stream);
 /* fused AdamW over a flat fp32 buffer; lr per element group given by a split index (alpha first). */
 int licv_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t n_group0,
                     float lr0, float lr1, float beta1, float beta2, float eps, float weight_decay,

@@ -1211,8 +1211,12 @@ void gemm_bf16_quad64_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t*
     for (int i = 0; i < 8; ++i) fa0[i] = *(lds_fptr)(ring + (2 + wm) * Q64_UNIT + fo0 + i * 2048);
 
     int ub = 0;                                              // slot of unit 4 t (W rows 0-127 of the current tile)
-    for (int t = 0; t < nt; ++t) {
-        const bool more1 = t + 1 < nt, more2 = t + 2 < nt;
+    // One K tile.  STEADY (t + 2 < nt): every piece and every read exists — the body is one straight instruction stream, no
+    // branch between the MFMAs (the first version tested `more1` / `more2` at run time around each piece and read: 32 scalar
+    // branches per 128 MFMAs).  The last two tiles run the same body with the run-time tests.
+    auto tile = [&](int t, auto steady_c) {
+        constexpr bool STEADY = decltype(steady_c)::value;
+        const bool more1 = STEADY || t + 1 < nt, more2 = STEADY || t + 2 < nt;
         const int ubn = wrap(ub + 4);                        // slot of unit 4 (t + 1)
         const int u8 = wrap(ub + 8);                         // slot of unit 4 (t + 2): W units of tile t + 2 (free since the barrier of tile t - 1)
         // ---- step (t, 0): MFMAs on set 0; reads of (t, second half) into set 1; pieces of the W units of tile t + 2
@@ -1269,7 +1273,10 @@ void gemm_bf16_quad64_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t*
             });
         }
         ub = ubn;
-    }
+    };
+    int t = 0;
+    for (; t + 2 < nt; ++t) tile(t, std::true_type{});
+    for (; t < nt; ++t) tile(t, std::false_type{});
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");    // the last MFMAs' results (inline asm: no hazard tracking by the compiler)
     __syncthreads();                           // every wave is done with the ring before it becomes the output image
     epilogue_staged<256, 256, 4, 8, 8>(acc, ep, C, ldc, M, N, m0, n0, wm * 128, wn * 128, wave, lane, smem);

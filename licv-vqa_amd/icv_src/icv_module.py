@@ -56,6 +56,7 @@ class VQAICVModule(torch.nn.Module):
                                               requires_grad=bool(_get(self.module_cfg, "learnable_t", False)))
         self.global_step = 0
         self.decay_per_step = None
+        self._t_host = (None, -1)                   # (float value, version counter it was read at): see _temperature_value
 
     # ------------------------------------------------------------------ masks / losses
     def get_mask(self, inputs, mask_length):
@@ -64,6 +65,15 @@ class VQAICVModule(torch.nn.Module):
         steps = torch.arange(ids.shape[1], device=ids.device).unsqueeze(0).expand(ids.shape[0], -1)
         return (steps >= mask_length.to(ids.device).unsqueeze(1)) & (ids != self.interface.tokenizer.pad_token_id)
 
+    def _temperature_value(self) -> float:
+        """The temperature as a host float for the kernels' scalar argument, read back only when the Parameter has changed
+        (an optimiser step with `learnable_t`, or decay_temperature): the steady state makes no device round trip."""
+        t = self.temperature
+        ver = t._version
+        if self._t_host[1] != ver or self._t_host[0] is None:
+            self._t_host = (float(t.detach()), ver)
+        return self._t_host[0]
+
     def calculate_kl_divergence(self, stu_logits, tea_logits):
         """mean over rows of sum_v p*(log(p+eps)-log(q+eps)), times T^2 (ref :121-134).  Rows are given as 2-D
         (rows, V) tensors; the per-row reduction over the vocabulary is one HIP kernel."""
@@ -71,16 +81,17 @@ class VQAICVModule(torch.nn.Module):
         idx = torch.arange(n, device=stu_logits.device)
         rows = ops.kl_rows(stu_logits if stu_logits.stride(1) == 1 else stu_logits.contiguous(),
                            tea_logits if tea_logits.stride(1) == 1 else tea_logits.contiguous(),
-                           idx, idx, V, float(self.temperature), float(self.module_cfg.kl_eps))
-        return rows.to(stu_logits.dtype).mean() * self.temperature ** 2
+                           idx, idx, V, self._temperature_value(), float(self.module_cfg.kl_eps))
+        return rows.to(stu_logits.dtype).mean() * self.temperature.detach().to(rows.device) ** 2
 
     def _kl_from_rows(self, stu_logits, tea_logits, s_rows, t_rows):
         """Same value as calculate_kl_divergence(stu[mask], tea[mask]) without materialising the gathered rows; differentiable
-        w.r.t. the student logits (licv.autograd.MaskedKLFn).  ``temperature`` enters as a constant (``learnable_t`` has no
-        native gradient)."""
+        w.r.t. the student logits and — with ``learnable_t`` (ref :49-52) — w.r.t. ``temperature`` (licv.autograd.MaskedKLFn:
+        the kernels take the temperature as a host scalar, its gradient is one more per-row reduction, `licv_kl_rows_dtemp`)."""
         from licv.autograd import MaskedKLFn
         assert s_rows.numel() == t_rows.numel(), "student and teacher must mask the same number of answer tokens"
-        return MaskedKLFn.apply(stu_logits, tea_logits, s_rows, t_rows, float(self.temperature), float(self.module_cfg.kl_eps))
+        t_param = self.temperature if self.temperature.requires_grad else None
+        return MaskedKLFn.apply(stu_logits, tea_logits, s_rows, t_rows, self._temperature_value(), float(self.module_cfg.kl_eps), t_param)
 
     # ------------------------------------------------------------------ forward (ref :71-119)
     def forward(self, query_inputs, inputs, query_x_length, in_context_length):

@@ -103,6 +103,7 @@ def lib() -> C.CDLL:
             "licv_attn_bwd_small": [C.POINTER(AttnArgs), P, P, I64, I64, P, P, I64, I64, P],
             "licv_kl_rows_bwd": [P, P, I, P, P, I64, I64, I64, I64, F, F, F, P, P, I64, P],
             "licv_kl_rows_fwd": [P, P, I, P, P, I64, I64, I64, I64, F, F, P, P],
+            "licv_kl_rows_dtemp": [P, P, I, P, P, I64, I64, I64, I64, F, F, P, P],
             "licv_adamw_step": [P, P, P, P, I64, I64, F, F, F, F, F, F, I64, F, P],
         }
         for name, args in sig.items():

@@ -72,24 +72,34 @@ class MaskedKLFn(torch.autograd.Function):
     no_grad in the reference, :103-105)."""
 
     @staticmethod
-    def forward(ctx, stu_logits, tea_logits, s_rows, t_rows, temperature: float, eps: float):
+    def forward(ctx, stu_logits, tea_logits, s_rows, t_rows, temperature: float, eps: float, t_param: Optional[torch.Tensor] = None):
+        """`temperature` is the host value the kernels take; `t_param` is the module's temperature Parameter when it is
+        trainable (`learnable_t`, ref:icv_src/icv_module.py:49-52) and only marks the node as differentiable in T."""
         s2, t2 = _rows2d(stu_logits), _rows2d(tea_logits)
         V = s2.shape[1]
         rows = ops.kl_rows(s2, t2, s_rows, t_rows, V, temperature, eps)
         ctx.save_for_backward(stu_logits, tea_logits, s_rows, t_rows)
         ctx.T, ctx.eps = temperature, eps
-        return rows.to(stu_logits.dtype).mean().float() * (temperature * temperature)
+        ctx.t_param = t_param is not None and t_param.requires_grad
+        ctx.t_like = t_param
+        mean = rows.to(stu_logits.dtype).mean().float()
+        ctx.kl_mean = mean if ctx.t_param else None
+        return mean * (temperature * temperature)
 
     @staticmethod
     def backward(ctx, g):
         stu_logits, tea_logits, s_rows, t_rows = ctx.saved_tensors
         s2, t2 = _rows2d(stu_logits), _rows2d(tea_logits)
         V = s2.shape[1]
-        d = ops.kl_rows_bwd(s2, t2, s_rows, t_rows, V, ctx.T, ctx.eps, upstream=1.0,
-                            upstream_dev=g.detach().to(torch.float32).reshape(1).contiguous())
+        g32 = g.detach().to(torch.float32).reshape(1).contiguous()
+        d = ops.kl_rows_bwd(s2, t2, s_rows, t_rows, V, ctx.T, ctx.eps, upstream=1.0, upstream_dev=g32)
         buf, view = _padded_grad(stu_logits.shape, stu_logits.device)
         buf.index_copy_(0, s_rows, d)
-        return view, None, None, None, None, None
+        g_t = None
+        if ctx.t_param:                                              # L = T^2 mean_rows f(T):  dL/dT = T^2 mean f' + 2 T mean f
+            df = ops.kl_rows_dtemp(s2, t2, s_rows, t_rows, V, ctx.T, ctx.eps)
+            g_t = (g32 * (ctx.T * ctx.T * df.mean() + 2.0 * ctx.T * ctx.kl_mean)).reshape(ctx.t_like.shape).to(ctx.t_like.device, ctx.t_like.dtype)
+        return view, None, None, None, None, None, g_t
 
 
 class ShiftedCEFn(torch.autograd.Function):

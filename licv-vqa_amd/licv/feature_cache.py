@@ -74,9 +74,13 @@ class VisionFeatureCache:
 
 
 class TeacherLogitCache:
+    """Teacher answer-row logits per question, bounded by the total number of cached ROWS (each row is V bf16 values on the
+    device: 64 KB at V = 32002, so the default 65536 rows are ~4.2 GB of HBM); oldest questions are evicted first."""
+
     def __init__(self, capacity_rows: int = 65536):
         self.capacity = int(capacity_rows)
         self.store: Dict[Hashable, torch.Tensor] = {}
+        self.rows = 0
         self.hits = self.misses = 0
 
     def lookup(self, keys: Sequence[Hashable]):
@@ -88,6 +92,13 @@ class TeacherLogitCache:
         return got, miss
 
     def insert(self, key: Hashable, rows: torch.Tensor):
-        if len(self.store) >= self.capacity:
-            self.store.pop(next(iter(self.store)))
+        old = self.store.pop(key, None)
+        if old is not None:
+            self.rows -= old.shape[0]
+        n = int(rows.shape[0])
+        if n > self.capacity:
+            return                                           # one question larger than the whole budget: not cached
+        while self.store and self.rows + n > self.capacity:
+            self.rows -= self.store.pop(next(iter(self.store))).shape[0]
         self.store[key] = rows.clone()
+        self.rows += n

@@ -142,10 +142,31 @@ class _HostFlags:
 
     @staticmethod
     def _sig(tensors):
-        return tuple(None if t is None else t._version for t in tensors)
+        """Version counters of the tensors, or None when any of them has none to read: tensors made under
+        `torch.inference_mode()` (ref:inference.py:246,300,324 wrap every entry point in it) do not track one, and a write
+        to such a tensor could not be seen — those inputs are never cached (one 16-byte read-back per forward instead)."""
+        sig = []
+        for t in tensors:
+            if t is None:
+                sig.append(None)
+                continue
+            if t.is_inference():
+                return None
+            try:
+                sig.append(t._version)
+            except RuntimeError:
+                return None
+        return tuple(sig)
+
+    def clear(self):
+        """Drop every entry: for callers that rewrite an input through a path the version counter does not see
+        (`.data`, `set_`, DLPack / numpy aliases, a custom kernel)."""
+        self._entries.clear()
 
     def get(self, *tensors):
         sig = self._sig(tensors)
+        if sig is None:
+            return None
         for refs, vers, value in self._entries:
             if vers == sig and len(refs) == len(tensors) and all((r is None and t is None) or (r is not None and r() is t)
                                                                    for r, t in zip(refs, tensors)):
@@ -154,6 +175,8 @@ class _HostFlags:
 
     def put(self, value, *tensors):
         import weakref
+        if self._sig(tensors) is None:
+            return value
         if len(self._entries) >= self._keep:
             self._entries.pop(0)
         self._entries.append((tuple(None if t is None else weakref.ref(t) for t in tensors), self._sig(tensors), value))
@@ -177,6 +200,8 @@ class Idefics2Engine:
         host-flag cache matches tensors by identity, and a fresh view per call would cost a device read-back per slice per forward."""
         if t is None:
             return [None] * (len(cut) - 1)
+        if _HostFlags._sig((t,)) is None:                  # no version counter (inference tensor): plain views, nothing cached
+            return [t[cut[i]:cut[i + 1]] for i in range(len(cut) - 1)]
         import weakref
         for k in [k for k, e in self._slice_views.items() if e[0]() is None]:
             del self._slice_views[k]

@@ -189,17 +189,16 @@ def set_splitk(on: bool) -> None:
     check(_lib.lib().licv_gemm_experiment(4, 1 if on else 0))
 
 
-_plans: dict = {}
 _ws: dict = {}
 
 
 def _splitk_plan(M: int, N: int, K: int):
-    key = (M, N, K)
-    if key not in _plans:
-        sp, nb = C.c_int(1), C.c_int64(0)
-        check(_lib.lib().licv_gemm_splitk_plan(M, N, K, C.byref(sp), C.byref(nb)))
-        _plans[key] = (sp.value, nb.value)
-    return _plans[key]
+    """The library's own plan, asked on every call (host-only arithmetic): linear() and the native layer runner, which asks
+    the same function, can then never disagree about the kernel of a shape — also when the library-side switch
+    (`licv_gemm_experiment(4, .)`) is toggled directly."""
+    sp, nb = C.c_int(1), C.c_int64(0)
+    check(_lib.lib().licv_gemm_splitk_plan(M, N, K, C.byref(sp), C.byref(nb)))
+    return sp.value, nb.value
 
 
 def _workspace(device, nbytes: int) -> torch.Tensor:
@@ -388,6 +387,17 @@ def kl_rows(stu: torch.Tensor, tea: torch.Tensor, stu_rows: torch.Tensor, tea_ro
     out = torch.empty((n,), dtype=torch.float32, device=stu.device)
     check(_lib.lib().licv_kl_rows_fwd(_p(stu), _p(tea), _dt(stu), _p(stu_rows), _p(tea_rows), n, vocab, stu.stride(0),
                                       tea.stride(0), float(temperature), float(eps), _p(out), _stream(stu)))
+    return out
+
+
+def kl_rows_dtemp(stu: torch.Tensor, tea: torch.Tensor, stu_rows: torch.Tensor, tea_rows: torch.Tensor, vocab: int,
+                  temperature: float, eps: float) -> torch.Tensor:
+    """d/dT of kl_rows' per-row sums (fp32), for a trainable temperature (ref:icv_src/icv_module.py:49-52)."""
+    assert stu.dtype == tea.dtype and stu.dim() == 2 and tea.dim() == 2
+    n = stu_rows.numel()
+    out = torch.empty((n,), dtype=torch.float32, device=stu.device)
+    check(_lib.lib().licv_kl_rows_dtemp(_p(stu), _p(tea), _dt(stu), _p(stu_rows), _p(tea_rows), n, vocab, stu.stride(0),
+                                        tea.stride(0), float(temperature), float(eps), _p(out), _stream(stu)))
     return out
 
 

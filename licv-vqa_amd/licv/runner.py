@@ -66,12 +66,14 @@ class TextRunner:
         self._fn = lib.licv_idefics_text_forward
         self._ws = {}
 
-    def _workspace(self, M: int, rows: int, dev):
+    def _workspace(self, M: int, rows: int, dev, xkv_rows: int = 0):
         a = self.arch
         H, I, V = a.hidden_size, a.intermediate_size, self.w.lm_head.shape[0]
         lib = _lib.lib()
-        need = max(int(lib.licv_workspace_size(m, n, k)) for (m, n, k) in
-                   ((M, H, H), (M, 3 * H, H), (M, 2 * I, H), (M, H, I), (rows, V, H)))
+        shapes = [(M, H, H), (M, 3 * H, H), (M, 2 * I, H), (M, H, I), (rows, V, H)]
+        if xkv_rows > 0:                                    # the cross-attention K|V projection on the image rows (B * Nk, 2H, img_dim)
+            shapes.append((xkv_rows, 2 * H, a.v_embed))
+        need = max(int(lib.licv_workspace_size(m, n, k)) for (m, n, k) in shapes)
         key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
         buf = self._ws.get(key)
         if buf is None or buf.numel() < need:
@@ -126,7 +128,7 @@ class TextRunner:
             c.xkv = new(B * Nk, 2 * H, **bf).data_ptr()
         if logits_rows is not None:
             c.logits_rows, c.n_rows, c.xsel = logits_rows.data_ptr(), rows, new(rows, H, **bf).data_ptr()
-        ws = self._workspace(M, rows, dev)
+        ws = self._workspace(M, rows, dev, B * Nk)
         c.workspace, c.workspace_bytes = ws.data_ptr(), ws.numel()
         logits = torch.empty((rows, ldc), **bf)
         c.logits, c.ld_logits = logits.data_ptr(), ldc

@@ -102,8 +102,27 @@ class IdeficsInterface(LMMInterface):
         self.processor = processor
         # `<image>` id for the device-side image_attention_mask builder: from the tokenizer when it knows the token, else the second
         # additional-vocabulary slot (where the released checkpoints put it)
-        conv = getattr(self.tokenizer, "convert_tokens_to_ids", None)
-        self.image_token_id = conv("<image>") if conv is not None else arch.vocab_size + (1 if arch.additional_vocab_size > 1 else 0)
+        self.image_token_id = self._resolve_image_token_id(self.tokenizer, arch)
+
+    @staticmethod
+    def _resolve_image_token_id(tokenizer, arch) -> int:
+        """`<image>` id: the tokenizer's, when it really knows the token (not None, not its unk id, inside the embedding
+        table); otherwise the additional-vocabulary slot the released checkpoints use.  A silently wrong id would give an
+        all-zero image_attention_mask, i.e. no cross-attention at all, without any error."""
+        n_embed = arch.vocab_size + getattr(arch, "additional_vocab_size", 0)
+        fallback = arch.vocab_size + (1 if getattr(arch, "additional_vocab_size", 0) > 1 else 0)
+        conv = getattr(tokenizer, "convert_tokens_to_ids", None)
+        if conv is None:
+            tid = fallback
+        else:
+            tid = conv("<image>")
+            unk = getattr(tokenizer, "unk_token_id", None)
+            if tid is None or (unk is not None and tid == unk) or not isinstance(tid, int):
+                tid = fallback
+        if not 0 <= int(tid) < max(n_embed, 1):
+            raise ValueError(f"`<image>` token id {tid} is outside the embedding table of {n_embed} rows: "
+                             "the tokenizer and the model configuration do not belong together")
+        return int(tid)
 
     def _image_mask(self, input_ids, pixel_values, image_attention_mask):
         """image_attention_mask as processor.prepare_input builds it (hf:idefics/processing_idefics.py:89-133) when the caller

@@ -125,3 +125,58 @@ def test_apply_icv_intervention_edit_function_tensor_tuple_and_passthrough():
     assert torch.equal(same.cpu(), h)
     got3 = fn(h.to(DEV), "model.layers.3")
     assert (got3.cpu() - O.inject_renorm(h, icv[:, 0].unsqueeze(1))).abs().max() <= 1e-5 * want.abs().max()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_learnable_temperature_gets_its_gradient(dtype):
+    """learnable_t (ref:icv_src/icv_module.py:49-52): `temperature` is a Parameter with requires_grad, and the reference's
+    autograd differentiates  T^2 * mean_rows sum_v p (log(p+eps) - log(q+eps)),  p = softmax(tea/T), q = softmax(stu/T), with
+    respect to it (ref :121-134).  Native: MaskedKLFn + licv_kl_rows_dtemp, against torch autograd of the same formula in fp64
+    on the same (dtype-rounded) logits; the student-logit gradient must be unchanged by the extra output."""
+    from licv.autograd import MaskedKLFn
+    g = torch.Generator().manual_seed(7)
+    R, V, n = 12, 1000, 5
+    stu = (torch.randn(R, V, generator=g) * 2.0).to(dtype).to(DEV)
+    tea = (torch.randn(R, V, generator=g) * 2.0).to(dtype).to(DEV)
+    rows_s = torch.tensor([1, 3, 4, 8, 11], device=DEV)
+    rows_t = torch.tensor([0, 2, 5, 9, 10], device=DEV)
+    for temp in (1.0, 1.7):
+        t_param = torch.nn.Parameter(torch.tensor(temp, device=DEV))
+        s_in = stu.clone().requires_grad_(True)
+        loss = MaskedKLFn.apply(s_in, tea, rows_s, rows_t, temp, 1e-6, t_param)
+        loss.backward()
+        assert t_param.grad is not None and t_param.grad.shape == t_param.shape
+        # reference formula, fp64 autograd
+        T64 = torch.tensor(temp, dtype=torch.float64, requires_grad=True)
+        s64 = stu[rows_s].double().cpu() / T64
+        t64 = tea[rows_t].double().cpu() / T64
+        p, q = torch.softmax(t64, -1), torch.softmax(s64, -1)
+        ref = (p * ((p + 1e-6).log() - (q + 1e-6).log())).sum(-1).mean() * T64 ** 2
+        ref.backward()
+        want = float(T64.grad)
+        got = float(t_param.grad)
+        tol = (2e-2 if dtype == torch.bfloat16 else 2e-4) * max(abs(want), 1e-3) + (5e-3 if dtype == torch.bfloat16 else 1e-5)
+        assert abs(got - want) <= tol, (temp, dtype, got, want)
+        # without the Parameter the node is not differentiable in T and the logit gradient is bit-identical
+        s2 = stu.clone().requires_grad_(True)
+        MaskedKLFn.apply(s2, tea, rows_s, rows_t, temp, 1e-6).backward()
+        assert torch.equal(s2.grad, s_in.grad)
+    assert n == rows_s.numel()
+
+
+def test_module_with_learnable_t_fills_temperature_grad_and_caches_the_host_value(golden):
+    z = golden("g6_loss")
+    mod = _module(temp=2.0)
+    mod.temperature.requires_grad_(True)
+    _load(mod, z)
+    loss_dict, _ = mod(*_args(z))
+    loss_dict["loss"].backward()
+    assert mod.temperature.grad is not None and torch.isfinite(mod.temperature.grad).all()
+    assert mod.icv_encoder.icv.grad is not None
+    # the host copy of T is read once per value of the Parameter, not once per call
+    v0 = mod._t_host
+    mod(*_args(z))
+    assert mod._t_host is v0
+    with torch.no_grad():
+        mod.temperature.mul_(0.5)
+    assert mod._temperature_value() == 1.0

@@ -199,3 +199,34 @@ def test_idefics2_fp8_text_stack_deviation_from_bf16():
     assert float(cos.min()) >= 0.995, f"min cosine {float(cos.min()):.4f}"
     assert all(t.dtype == torch.float32 for t in cap["layer_out"])     # the hooked branch still promotes the stream
     assert not torch.equal(a, b)                                       # the fp8 kernels really ran
+
+
+def test_idefics2_forward_and_generate_under_inference_mode(golden):
+    """ref:inference.py:246,300,324 wrap icv_inference / generate_answers / icl_inference in @torch.inference_mode() and move
+    the inputs with .to(device) INSIDE that scope: inference tensors have no version counter, so the host-flag cache must
+    step aside (one read-back per call) instead of raising — and the results must be those of the ordinary path."""
+    from icv_src.icv_model.icv_intervention import LearnableICVInterventionLMM
+    from lmm_icl_interface import Idefics2Interface
+    z = golden("g8_generate_idefics2")
+    arch = IDEFICS2_TINY
+    sd32 = synth_idefics2_weights(arch, seed=81, dtype=torch.float32)
+    iface = Idefics2Interface(state_dict=sd32, arch=arch, device=DEV)
+    keys = ("input_ids", "attention_mask", "pixel_values", "pixel_attention_mask")
+    host = {k: T(z[f"left_in_{k}"]) for k in keys}
+    icv_h = T(z["icv"])
+    w = LearnableICVInterventionLMM(iface, True, -1, "model.model.text_model.layers.<LAYER_NUM>.mlp", arch.num_layers)
+    kw = dict(max_new_tokens=5, length_penalty=0.0, min_new_tokens=0)
+    batch = {k: v.to(DEV) for k, v in host.items()}
+    want_lg = w(icv=icv_h.to(DEV), **batch)["logits"]
+    want_ids = w.generate(icv=icv_h.to(DEV), **batch, num_beams=3, **kw)
+    with torch.inference_mode():
+        ib = {k: v.to(DEV) for k, v in host.items()}              # created inside the scope: inference tensors
+        icv = icv_h.to(DEV)
+        assert ib["input_ids"].is_inference()
+        for _ in range(2):                                         # twice: nothing stale is kept between calls either
+            got_lg = w(icv=icv, **ib)["logits"]
+            got_ids = w.generate(icv=icv, **ib, num_beams=3, **kw)
+            assert torch.equal(got_lg, want_lg)
+            assert torch.equal(got_ids, want_ids)
+        img = iface.engine.encode_images(ib["pixel_values"], ib["pixel_attention_mask"])
+    assert torch.equal(img, iface.engine.encode_images(batch["pixel_values"], batch["pixel_attention_mask"]))
