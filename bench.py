@@ -122,6 +122,52 @@ def cpu_baseline(arch, S, n_img):
     }
 
 
+def cpu_baseline_generate(arch, S, n_img):
+    """Bounded CPU sample for the hooked-generate workload (ref:inference.py:300-321 shape: 3 beams, 5 new tokens): ONE question
+    through the oracle's own beam search (oracle/generate_ref.py, KV cache, hooks live at every step) on the architecture
+    truncated to 4 and to 8 decoder layers (1 and 2 gated cross-attention layers, 1 ViT layer, 1 perceiver block), bf16; the
+    per-4-layer difference is scaled to the full depth and the vision tower's remaining layers are added from the one-layer
+    timings of `_cpu_baseline_one`."""
+    from licv.synthetic import synth_idefics_weights, synth_vqa_batch
+    from oracle.generate_ref import generate as oracle_generate
+    cores = _host_cores()
+    torch.set_num_threads(cores)
+    dt = torch.bfloat16
+    tm = {}
+    for nl in (4, 8):
+        small = arch.with_(v_layers=1, r_depth=1, num_layers=nl)
+        sd = synth_idefics_weights(small, seed=1, dtype=dt)
+        b = synth_vqa_batch(small, 1, S, n_img, seed=2, min_len=S, dtype=dt)
+        icv = torch.randn(1, nl, arch.hidden_size) * 0.01
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            oracle_generate(sd, small, **b, icv=icv, hook_layers=list(range(nl)), num_beams=3, max_new_tokens=5, length_penalty=0.0,
+                            min_new_tokens=0)
+            tm[f"{nl} layers"] = time.perf_counter() - t0
+        del sd
+    _, one = _cpu_baseline_one(arch, S, n_img, dt)
+    per4 = max(tm["8 layers"] - tm["4 layers"], 0.0)
+    full = (tm["4 layers"] + per4 * (arch.num_layers - 4) / 4 + one["vit_layer"] * (arch.v_layers - 1)
+            + one["perceiver_block"] * (arch.r_depth - 1))
+    return {"value": 1.0 / full, "unit": "questions/s", "cores": cores, "kind": "port", "dtype": "bf16",
+            "sample": (f"1 question (S={S}, {n_img} image) through the CPU oracle's hooked beam search (3 beams, 5 new tokens) at 4 and 8 "
+                       f"decoder layers: " + ", ".join(f"{k} {v:.2f}s" for k, v in tm.items())
+                       + f"; per-4-layer difference scaled to {arch.num_layers} layers + {arch.v_layers - 1} more ViT layers "
+                       f"({one['vit_layer']:.2f}s each) + {arch.r_depth - 1} more perceiver blocks = {full:.1f} s/question")}
+
+
+def gemm_src_sha16() -> str:
+    """Hash of the GEMM sources of THIS tree (same function as tools/pmc_summary.py): a committed PMC summary is quoted in
+    `roofline.traffic` only if it was measured on kernels built from the same sources."""
+    import hashlib
+    csrc = ROOT / "licv-vqa_amd" / "csrc"
+    h = hashlib.sha256()
+    for f in sorted([f for f in csrc.glob("gemm*") if f.is_file()] + [csrc / "common.h"]):
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
 def gpu_unfused_baseline(arch, sd, batch, icv_eff, layers, B, steps=3):
     """"Reference on GPU" denominator: the SAME restatement of the reference path that
     serves as the oracle, run unfused on this GPU through PyTorch-ROCm's own kernels (rocBLAS/hipBLASLt GEMMs, eager attention,
@@ -258,6 +304,14 @@ def main():
         else:
             dist.init_process_group(args.dist_backend)
 
+    dev_name = f"rank{rank}:cuda:{local}:{torch.cuda.get_device_name(local)}"
+    if dist is not None:
+        names = [None] * world
+        dist.all_gather_object(names, dev_name)
+        dist_info = {"dist_backend": dist.get_backend(), "world_size_seen": dist.get_world_size(), "devices": names}
+    else:
+        dist_info = {"dist_backend": None, "world_size_seen": 1, "devices": [dev_name]}
+
     from licv import ops
     if args.gemm_select:
         from licv import _lib
@@ -327,6 +381,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    if training:
+        trainer.allreduce_events = []                                    # HIP event pair around the one collective of an optimiser step
     prof = []
     # per-launch event pairs (roofline.achieved) need the Python-level launches; the launch-bound workloads (hooked generate, the
     # 32-token student shape) are timed on the native layer runner instead and report no per-kernel roofline
@@ -424,11 +480,16 @@ def main():
     gemm_alg = sum(2.0 * (m * k + n * k + m * n) for rec in prof if rec[0] == "gemm" and len(rec) > 4 for (m, n, k) in [rec[4]])
     # roofline.traffic comes from PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over THIS command: a profiler cannot run inside
     # the timed region); the newest committed summary is used and named, with the commit it was measured at
-    pmc = None
+    pmc, pmc_why = None, None
     pmc_files = sorted((ROOT / "profiles").glob("r*_pmc_headline_gemm.json"))
     if args.workload == "idefics9b_32shot_bs8" and not args.no_hooks and pmc_files:
         pmc_file = pmc_files[-1]
         pmc = json.loads(pmc_file.read_text())
+        have, want = pmc.get("gemm_src_sha16"), gemm_src_sha16()
+        if have != want:                                                  # measured on other kernels than the ones that just ran
+            pmc_why = (f"null: the newest committed PMC summary (profiles/{pmc_file.name}, commit {pmc.get('commit', '?')}) was measured on GEMM "
+                       f"sources {have or 'without a recorded hash'}; this tree's are {want} - re-run the PMC passes (tools/r03_profile.sh)")
+            pmc = None
     ti, by, ni = agg("inject")
     fq = {"total": fl / max(roof_steps, 1) / B} if is2 else flops_per_question(arch, S, n_img)   # Idefics2: GEMM flops as launched
     res = {
@@ -447,9 +508,9 @@ def main():
         "roofline": {"bound": "mfma", "kernel": "gemm_bf16_flow_k / gemm_bf16_lean_k (256x256 tile, LDS-DMA ring, two wave groups half a K stage apart; small shapes: gemm_bf16_tile128_k)", "achieved": fl / tg / 1e12 if tg else None,
                      "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": (fl / tg / 1e12) / PEAK_BF16_TFLOPS if tg else None,
                      "traffic": pmc["traffic_bytes_per_launch"] / 1e9 if pmc else None, "traffic_unit": "GB per launch (average over the step's GEMM launches)",
-                     "traffic_source": (f"profiles/{pmc_file.name} (measured at commit {pmc.get('commit', 'of round 1')}, kernels {pmc.get('kernel')}): "
+                     "traffic_source": (f"profiles/{pmc_file.name} (measured at commit {pmc.get('commit', 'of round 1')}, GEMM sources {pmc.get('gemm_src_sha16')}, kernels {pmc.get('kernel')}): "
                                         "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command, summed over the GEMM launches; "
-                                        "FETCH_SIZE x2 (gfx950), counts Infinity-Cache hits as well as HBM") if pmc else None,
+                                        "FETCH_SIZE x2 (gfx950), counts Infinity-Cache hits as well as HBM") if pmc else pmc_why,
                      "algorithmic_GB_per_launch": gemm_alg / ng / 1e9 if ng else None,
                      "achieved_GBps_algorithmic": gemm_alg / tg / 1e9 if tg else None,
                      "launches_per_step": ng // max(roof_steps, 1),
@@ -460,6 +521,25 @@ def main():
         "whole_path": {"tflop_per_question": fq["total"] / 1e12, "achieved_tflops_per_gpu": fq["total"] * B * args.steps / elapsed / 1e12,
                        "frac_of_mfma_peak": fq["total"] * B * args.steps / elapsed / 1e12 / PEAK_BF16_TFLOPS},
     }
+    res.update(dist_info)
+    if generating or "student" in args.workload:
+        # weight-streaming shapes (what the reference really hooks): every weight matrix is read once per pass and used
+        # on 24-256 rows, so the bound of the STEP is the HBM stream of the weights; achieved = those bytes / the step's time
+        from licv.roofline import cross_kv_weight_bytes, weight_bytes
+        wb = weight_bytes(arch)
+        passes = 5 if generating else 1                                  # prefill + 4 single-token steps for 5 new tokens
+        alg = wb["vision"] + wb["perceiver"] + passes * wb["language"] - (passes - 1) * cross_kv_weight_bytes(arch)
+        res["roofline"] = {"bound": "hbm", "kernel": "weight-streaming GEMM family over the whole step (gemm_bf16_skinny_k / gemm_bf16_stream_k / "
+                           "gemm_bf16_splitk_k + finalize; native layer runner)", "achieved": alg / (ms_per_step * 1e-3) / 1e9,
+                           "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": alg / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None,
+                           "algorithmic_GB_per_step": alg / 1e9, "weight_GB": {k: v / 1e9 for k, v in wb.items()}, "weight_passes": passes,
+                           "floor_ms_at_peak": alg / PEAK_HBM_GBS / 1e6,
+                           "note": "bytes = bf16 weights touched per step (vision + perceiver once, language stack once per pass, the "
+                                   "cross-attention K|V projections at the prefill only); activations and KV cache are < 1 % of it"}
+    if training and trainer is not None and trainer.allreduce_events:
+        ar = sorted(e0.elapsed_time(e1) for e0, e1 in trainer.allreduce_events)
+        res["allreduce"] = {"per_optimizer_step_ms_median": ar[len(ar) // 2], "per_optimizer_step_ms_max": ar[-1], "optimizer_steps_timed": len(ar),
+                            "bytes": 4 * (trainer.flat_p.numel() + 1), "what": "one flat fp32 buffer [alpha.grad | icv.grad | kl], SUM then / world"}
     if ni:
         res["hook_kernel"] = {"bound": "hbm", "kernel": "inject_renorm_fwd_k (+fused RMSNorm)", "achieved": by / ti / 1e9,
                               "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": by / ti / 1e9 / PEAK_HBM_GBS,
@@ -475,7 +555,8 @@ def main():
                                    "(row G0) is gpu_unfused_baseline, native/unfused = %.2fx" % g0["native_over_unfused"])
         del sd
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline_idefics2(arch, S, n_img, IDEFICS2_IMAGE[preset]) if is2 else cpu_baseline(arch, S, n_img)
+        res["cpu_baseline"] = (cpu_baseline_idefics2(arch, S, n_img, IDEFICS2_IMAGE[preset]) if is2 else
+                               cpu_baseline_generate(arch, S, n_img) if generating else cpu_baseline(arch, S, n_img))
     if rank == 0:
         print(json.dumps(res), flush=True)
     if dist is not None:

@@ -16,785 +16,7 @@
 // Both issue the MFMA with W as the A operand and A as the B operand, so each lane ends up with 4
 // CONSECUTIVE output columns of one row: 8-byte bf16 / 16-byte fp32 stores, vector bias/residual loads.
 // Workgroup ids are remapped so that the 8 XCDs (private L2s) each own a compact patch of the tile grid.
-#include <type_traits>
-#include "common.h"
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-
-#define BK 64
-
-struct GemmEpi {
-    const bf16_t* bias;
-    const float* row_gate;
-    const void* residual;
-    int residual_dtype;
-    int64_t ld_res;
-    int act;
-    int swiglu;
-    int use_scale;
-    float scale;
-    int out_dtype;
-    const float* a_scale;       // fp8 GEMM only: per-row scale of the quantised activations ...
-    const float* w_scale;       // ... and per-output-channel scale of the quantised weights (NULL for bf16 operands)
-};
-
-// Activations evaluated on bf16-rounded inputs and rounded to bf16 again by the caller, so ~1e-6 relative
-// accuracy is ample; the libm erff/tanhf/expf bodies are 3-5x more VALU work (the GELU epilogue of the ViT fc1
-// GEMM measured 2x the MFMA time with erff).
-__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-__device__ __forceinline__ float gelu_erf_fast(float x) {
-    // 0.5 x (1 + erf(x/sqrt2)); erfc(|z|) by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7), used on the side where
-    // 1 + erf would cancel, so small outputs keep their relative accuracy
-    const float z = x * 0.70710678118654752440f, az = fabsf(z);
-    const float t = fast_rcp(1.0f + 0.3275911f * az);
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float ec = poly * __expf(-az * az);                 // erfc(|z|)
-    return 0.5f * x * (z >= 0.f ? 2.0f - ec : ec);
-}
-// The same GELU on two values at once: identical operations per element (every multiply and add of the scalar body, in the same
-// order), written on 2-vectors so they issue as v_pk_mul_f32 / v_pk_add_f32 — the epilogue of the fc1 GEMM carries 128 of these per
-// lane and tile (2050 scalar f32 instructions; the packed form halves the non-transcendental part).  Bit-identical to gelu_erf_fast.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 gelu_erf_fast2(f32x2 x) {
-    const f32x2 z = x * 0.70710678118654752440f;
-    const f32x2 az = f32x2{fabsf(z[0]), fabsf(z[1])};
-    const f32x2 den = 1.0f + 0.3275911f * az;
-    const f32x2 t = f32x2{fast_rcp(den[0]), fast_rcp(den[1])};
-    const f32x2 poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const f32x2 arg = -az * az;
-    const f32x2 ec = poly * f32x2{__expf(arg[0]), __expf(arg[1])};
-    const f32x2 sel = f32x2{z[0] >= 0.f ? 2.0f - ec[0] : ec[0], z[1] >= 0.f ? 2.0f - ec[1] : ec[1]};
-    return 0.5f * x * sel;
-}
-__device__ __forceinline__ float act_apply(float y, int act) {
-    switch (act) {
-        case 1: return gelu_erf_fast(y);
-        case 2: { const float u = 0.7978845608028654f * (y + 0.044715f * y * y * y);
-                  const float th = 1.0f - 2.0f * fast_rcp(1.0f + __expf(2.0f * u));      // tanh(u)
-                  return 0.5f * y * (1.0f + th); }
-        case 3: return fmaxf(y, 0.0f);
-        default: return y;
-    }
-}
-__device__ __forceinline__ float silu_fast(float v) { return v * fast_rcp(1.0f + __expf(-v)); }
-
-__device__ __forceinline__ int lds_off(int row, int chunk) {       // bytes within a [rows][64] bf16 tile
-    return row * 128 + ((chunk ^ (row & 7)) << 4);
-}
-
-// XCD-aware tile id: blocks b and b+8 share an XCD; give each XCD a contiguous run of tiles, and order tiles
-// in groups of GROUP tile-rows (M fastest inside a group) so a run is a compact 2-D patch of the tile grid.
-__device__ __forceinline__ void tile_coords(int bid, int tiles_m, int tiles_n, int& tm, int& tn, int GROUP = 8) {
-    const int nwg = tiles_m * tiles_n;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    const int per_group = GROUP * tiles_n;
-    const int first_m = (bid / per_group) * GROUP;
-    const int gsize = min(tiles_m - first_m, GROUP);
-    tm = first_m + (bid % per_group) % gsize;
-    tn = (bid % per_group) / gsize;
-}
-
-// compile-time loop: accumulator arrays must only ever be indexed by constants (a runtime index puts them in scratch)
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
-}
-
-// Phase B, generic form: every epilogue option under run-time flags (used only for combinations without a specialisation).
-template <int TM, int TN, int NWAVES, int EPL>            // EPL: output elements per lane (8 = bf16 out, 4 = fp32 out)
-__device__ __noinline__ void epilogue_rows_generic(const GemmEpi& ep, void* __restrict__ C, int64_t ldc, int M, int N, int m0, int n0,
-                                           int wave, int lane, const char* smem) {
-    constexpr int YS = TN * 2 + 16;
-    constexpr bool F32 = (EPL == 4);
-    const bool sw = ep.swiglu != 0;
-    const int tcols = sw ? TN / 2 : TN;                   // output columns this tile produces
-    const int on = sw ? (N >> 1) : N;
-    const int oc0 = sw ? (n0 >> 1) : n0;
-    const int lpr = tcols / EPL;                          // lanes per row
-    const int rpi = 64 / lpr;                             // rows per wave-instruction
-    const int lr = lane / lpr, lcol = (lane % lpr) * EPL;
-    for (int rb = wave * rpi; rb < TM; rb += NWAVES * rpi) {
-        const int row = rb + lr;
-        const int m = m0 + row;
-        const int c = oc0 + lcol;
-        if (m >= M || c >= on) continue;
-        const char* yrow = smem + row * YS;
-        float y[EPL];
-        if (!sw) {
-            if (F32) {
-                const uint2 v = *reinterpret_cast<const uint2*>(yrow + lcol * 2);
-                y[0] = __uint_as_float(v.x << 16); y[1] = __uint_as_float(v.x & 0xffff0000u);
-                y[2] = __uint_as_float(v.y << 16); y[3] = __uint_as_float(v.y & 0xffff0000u);
-            } else {
-                const u32x4 v = *reinterpret_cast<const u32x4*>(yrow + lcol * 2);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { y[2 * e] = __uint_as_float(v[e] << 16); y[2 * e + 1] = __uint_as_float(v[e] & 0xffff0000u); }
-            }
-            if (ep.act) {
-#pragma unroll
-                for (int e = 0; e < EPL; ++e) y[e] = rbf(act_apply(y[e], ep.act));
-            }
-        } else {
-            // output col lcol..lcol+EPL-1 lives in packed cols (lcol/16)*32 + lcol%16 (gate) and +16 (up)
-            const int pc = (lcol >> 4) * 32 + (lcol & 15);
-            float gv[EPL], uv[EPL];
-            if (F32) {
-                const uint2 g2 = *reinterpret_cast<const uint2*>(yrow + pc * 2);
-                const uint2 u2 = *reinterpret_cast<const uint2*>(yrow + (pc + 16) * 2);
-                gv[0] = __uint_as_float(g2.x << 16); gv[1] = __uint_as_float(g2.x & 0xffff0000u);
-                gv[2] = __uint_as_float(g2.y << 16); gv[3] = __uint_as_float(g2.y & 0xffff0000u);
-                uv[0] = __uint_as_float(u2.x << 16); uv[1] = __uint_as_float(u2.x & 0xffff0000u);
-                uv[2] = __uint_as_float(u2.y << 16); uv[3] = __uint_as_float(u2.y & 0xffff0000u);
-            } else {
-                const u32x4 g4 = *reinterpret_cast<const u32x4*>(yrow + pc * 2);
-                const u32x4 u4 = *reinterpret_cast<const u32x4*>(yrow + (pc + 16) * 2);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    gv[2 * e] = __uint_as_float(g4[e] << 16); gv[2 * e + 1] = __uint_as_float(g4[e] & 0xffff0000u);
-                    uv[2 * e] = __uint_as_float(u4[e] << 16); uv[2 * e + 1] = __uint_as_float(u4[e] & 0xffff0000u);
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) y[e] = rbf(rbf(silu_fast(gv[e])) * uv[e]);
-        }
-        if (ep.row_gate && ep.row_gate[m] == 0.0f) {
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) y[e] = 0.0f;
-        }
-        if (ep.use_scale) {
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) y[e] = rbf(ep.scale * y[e]);
-        }
-        const int nv = min(EPL, on - c);
-        if (ep.residual) {
-            if (ep.residual_dtype == LICV_F32) {
-                const float* rp = reinterpret_cast<const float*>(ep.residual) + (int64_t)m * ep.ld_res + c;
-                if (nv == EPL) {
-#pragma unroll
-                    for (int q = 0; q < EPL / 4; ++q) {
-                        const floatx4 rv = *reinterpret_cast<const floatx4*>(rp + 4 * q);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) y[4 * q + e] = rv[e] + y[4 * q + e];
-                    }
-                } else for (int e = 0; e < nv; ++e) y[e] = rp[e] + y[e];
-            } else {
-                const bf16_t* rp = reinterpret_cast<const bf16_t*>(ep.residual) + (int64_t)m * ep.ld_res + c;
-                if (nv == EPL && !F32) {
-                    const u32x4 rv = *reinterpret_cast<const u32x4*>(rp);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        y[2 * e] = rbf(__uint_as_float(rv[e] << 16) + y[2 * e]);
-                        y[2 * e + 1] = rbf(__uint_as_float(rv[e] & 0xffff0000u) + y[2 * e + 1]);
-                    }
-                } else for (int e = 0; e < nv; ++e) y[e] = rbf(bf2f(rp[e]) + y[e]);
-            }
-        }
-        if (F32) {
-            float* cp = reinterpret_cast<float*>(C) + (int64_t)m * ldc + c;
-            if (nv == 4) *reinterpret_cast<floatx4*>(cp) = floatx4{y[0], y[1], y[2], y[3]};
-            else for (int e = 0; e < nv; ++e) cp[e] = y[e];
-        } else {
-            bf16_t* cp = reinterpret_cast<bf16_t*>(C) + (int64_t)m * ldc + c;
-            if (nv == 8) {
-                u32x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (uint32_t)f2bf(y[2 * e]) | ((uint32_t)f2bf(y[2 * e + 1]) << 16);
-                *reinterpret_cast<u32x4*>(cp) = o;
-            } else for (int e = 0; e < nv; ++e) cp[e] = f2bf(y[e]);
-        }
-    }
-}
-
-
-// Phase B of the staged epilogue (see below): compact run-time loops over the rows of the LDS image, one specialisation
-// per epilogue family.  Measured on the all-flags-at-run-time form: 600 basic blocks / 22 KiB of code, 7.6 us per
-// 256 x 256 tile just to copy a finished bf16 image out (13 us with a residual, 19 us with GELU) on an otherwise idle
-// chip — per-element branches on ep.act / ep.swiglu / residual dtype the compiler cannot hoist out of a noinline
-// body.  Each family below is branch-free inside its row loop.
-struct RowMap {                 // lane -> (row group, first output column) for EPL consecutive output columns per lane
-    int lr, lcol, rstep, c, nv;
-};
-template <int TN, int NWAVES, int EPL>
-__device__ __forceinline__ RowMap row_map(int tcols, int oc0, int on, int wave, int lane, int& rb_first) {
-    const int lpr = tcols / EPL, rpi = 64 / lpr;
-    RowMap r;
-    r.lr = lane / lpr; r.lcol = (lane % lpr) * EPL; r.rstep = NWAVES * rpi; r.c = oc0 + r.lcol; r.nv = min(EPL, on - r.c);
-    rb_first = wave * rpi;
-    return r;
-}
-__device__ __forceinline__ void unpack8(const u32x4& v, float (&y)[8]) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { y[2 * e] = __uint_as_float(v[e] << 16); y[2 * e + 1] = __uint_as_float(v[e] & 0xffff0000u); }
-}
-__device__ __forceinline__ u32x4 pack8(const float (&y)[8]) {
-    u32x4 o;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = (uint32_t)f2bf(y[2 * e]) | ((uint32_t)f2bf(y[2 * e + 1]) << 16);
-    return o;
-}
-__device__ __forceinline__ void store_bf16_row(bf16_t* cp, const float (&y)[8], int nv) {
-    if (nv == 8) *reinterpret_cast<u32x4*>(cp) = pack8(y);
-    else for (int e = 0; e < nv; ++e) cp[e] = f2bf(y[e]);
-}
-
-// no activation / residual / gate, bf16 out: the LDS image already holds the result -> 16-byte copies
-template <int TM, int TN, int NWAVES>
-__device__ __noinline__ void epilogue_rows_plain(void* __restrict__ C, int64_t ldc, int M, int N, int m0, int n0, int wave, int lane,
-                                                 const char* smem) {
-    constexpr int YS = TN * 2 + 16;
-    int rb0;
-    const RowMap r = row_map<TN, NWAVES, 8>(TN, n0, N, wave, lane, rb0);
-    if (r.c >= N) return;
-    for (int rb = rb0; rb < TM; rb += r.rstep) {
-        const int row = rb + r.lr, m = m0 + row;
-        if (m >= M) break;
-        const u32x4 v = *reinterpret_cast<const u32x4*>(smem + row * YS + r.lcol * 2);
-        bf16_t* cp = reinterpret_cast<bf16_t*>(C) + (int64_t)m * ldc + r.c;
-        if (r.nv == 8) *reinterpret_cast<u32x4*>(cp) = v;
-        else for (int e = 0; e < r.nv; ++e) cp[e] = (bf16_t)(e & 1 ? v[e >> 1] >> 16 : v[e >> 1] & 0xffffu);
-    }
-}
-
-// activation only (ACT: 1 erf-GELU, 2 tanh-GELU, 3 ReLU), bf16 out
-template <int TM, int TN, int NWAVES, int ACT>
-__device__ __noinline__ void epilogue_rows_act(void* __restrict__ C, int64_t ldc, int M, int N, int m0, int n0, int wave, int lane,
-                                               const char* smem) {
-    constexpr int YS = TN * 2 + 16;
-    int rb0;
-    const RowMap r = row_map<TN, NWAVES, 8>(TN, n0, N, wave, lane, rb0);
-    if (r.c >= N) return;
-    for (int rb = rb0; rb < TM; rb += r.rstep) {
-        const int row = rb + r.lr, m = m0 + row;
-        if (m >= M) break;
-        float y[8];
-        unpack8(*reinterpret_cast<const u32x4*>(smem + row * YS + r.lcol * 2), y);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) y[e] = act_apply(y[e], ACT);
-        store_bf16_row(reinterpret_cast<bf16_t*>(C) + (int64_t)m * ldc + r.c, y, r.nv);
-    }
-}
-
-// SwiGLU pairing of the interleaved gate|up image, bf16 out (N/2 output columns)
-template <int TM, int TN, int NWAVES>
-__device__ __noinline__ void epilogue_rows_swiglu(void* __restrict__ C, int64_t ldc, int M, int N, int m0, int n0, int wave, int lane,
-                                                  const char* smem) {
-    constexpr int YS = TN * 2 + 16;
-    int rb0;
-    const RowMap r = row_map<TN, NWAVES, 8>(TN / 2, n0 >> 1, N >> 1, wave, lane, rb0);
-    if (r.c >= (N >> 1)) return;
-    const int pc = (r.lcol >> 4) * 32 + (r.lcol & 15);    // output cols lcol.. live in packed cols pc.. (gate) and pc+16.. (up)
-    for (int rb = rb0; rb < TM; rb += r.rstep) {
-        const int row = rb + r.lr, m = m0 + row;
-        if (m >= M) break;
-        const char* yrow = smem + row * YS;
-        float g[8], u[8], y[8];
-        unpack8(*reinterpret_cast<const u32x4*>(yrow + pc * 2), g);
-        unpack8(*reinterpret_cast<const u32x4*>(yrow + (pc + 16) * 2), u);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) y[e] = rbf(silu_fast(g[e])) * u[e];
-        store_bf16_row(reinterpret_cast<bf16_t*>(C) + (int64_t)m * ldc + r.c, y, r.nv);
-    }
-}
-
-// residual add (same dtype in and out: bf16 stream or fp32 stream), optional row gate and tanh-gate scale.  The residual
-// rows are fetched PF row-groups ahead: nothing else runs on the CU to hide their latency.
-template <int TM, int TN, int NWAVES, bool F32>
-__device__ __noinline__ void epilogue_rows_res(const GemmEpi& ep, void* __restrict__ C, int64_t ldc, int M, int N, int m0, int n0,
-                                               int wave, int lane, const char* smem) {
-    constexpr int YS = TN * 2 + 16;
-    constexpr int EPL = F32 ? 4 : 8, ESZ = F32 ? 4 : 2, PF = F32 ? 8 : 4;
-    int rb0;
-    const RowMap r = row_map<TN, NWAVES, EPL>(TN, n0, N, wave, lane, rb0);
-    if (r.c >= N) return;
-    const bool full = r.nv == EPL;
-    const char* res = reinterpret_cast<const char*>(ep.residual);
-    const float* gate = ep.row_gate;
-    const bool scaled = ep.use_scale != 0;
-    const float scale = ep.scale;
-    // rolling prefetch: PF row-groups of residual in flight; slot u is refilled for group g + PF right after group g
-    // has consumed it
-    auto fetch = [&](int rb) -> u32x4 {
-        u32x4 v = u32x4{0u, 0u, 0u, 0u};
-        const int m = m0 + rb + r.lr;
-        if (rb < TM && m < M) {
-            const char* rp = res + ((int64_t)m * ep.ld_res + r.c) * ESZ;
-            if (full) v = *reinterpret_cast<const u32x4*>(rp);
-            else for (int e = 0; e < r.nv; ++e) {
-                if (F32) v[e] = reinterpret_cast<const uint32_t*>(rp)[e];
-                else v[e >> 1] |= (uint32_t)reinterpret_cast<const bf16_t*>(rp)[e] << ((e & 1) * 16);
-            }
-        }
-        return v;
-    };
-    u32x4 rv[PF];
-#pragma unroll
-    for (int u = 0; u < PF; ++u) rv[u] = fetch(rb0 + u * r.rstep);
-    for (; rb0 < TM; rb0 += PF * r.rstep) {
-#pragma unroll
-        for (int u = 0; u < PF; ++u) {
-            const int rb = rb0 + u * r.rstep;
-            const int row = rb + r.lr, m = m0 + row;
-            if (rb >= TM || m >= M) break;
-            const u32x4 rcur = rv[u];
-            rv[u] = fetch(rb + PF * r.rstep);
-            float y[EPL];
-            if (F32) {
-                const uint2 v = *reinterpret_cast<const uint2*>(smem + row * YS + r.lcol * 2);
-                y[0] = __uint_as_float(v.x << 16); y[1] = __uint_as_float(v.x & 0xffff0000u);
-                y[2] = __uint_as_float(v.y << 16); y[3] = __uint_as_float(v.y & 0xffff0000u);
-            } else {
-                float t[8];
-                unpack8(*reinterpret_cast<const u32x4*>(smem + row * YS + r.lcol * 2), t);
-#pragma unroll
-                for (int e = 0; e < EPL; ++e) y[e] = t[e];
-            }
-            if (gate && gate[m] == 0.0f) {
-#pragma unroll
-                for (int e = 0; e < EPL; ++e) y[e] = 0.0f;
-            }
-            if (scaled) {
-#pragma unroll
-                for (int e = 0; e < EPL; ++e) y[e] = rbf(scale * y[e]);
-            }
-            if (F32) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) y[e] = __uint_as_float(rcur[e]) + y[e];
-                float* cp = reinterpret_cast<float*>(C) + (int64_t)m * ldc + r.c;
-                if (full) *reinterpret_cast<floatx4*>(cp) = floatx4{y[0], y[1], y[2], y[3]};
-                else for (int e = 0; e < r.nv; ++e) cp[e] = y[e];
-            } else {
-                float q[8];
-                unpack8(rcur, q);
-                float z[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) z[e] = q[e] + y[e < EPL ? e : 0];
-                store_bf16_row(reinterpret_cast<bf16_t*>(C) + (int64_t)m * ldc + r.c, z, r.nv);
-            }
-        }
-    }
-}
-
-template <int TM, int TN, int NWAVES>
-__device__ __forceinline__ void epilogue_rows(const GemmEpi& ep, void* __restrict__ C, int64_t ldc, int M, int N, int m0, int n0,
-                                              int wave, int lane, const char* smem) {
-    const bool bf_out = ep.out_dtype == LICV_BF16;
-    const bool simple = !ep.residual && !ep.row_gate && !ep.use_scale && bf_out;
-    if (simple && ep.swiglu)                 epilogue_rows_swiglu<TM, TN, NWAVES>(C, ldc, M, N, m0, n0, wave, lane, smem);
-    else if (simple && ep.act == 0)          epilogue_rows_plain<TM, TN, NWAVES>(C, ldc, M, N, m0, n0, wave, lane, smem);
-    else if (simple && ep.act == 1)          epilogue_rows_act<TM, TN, NWAVES, 1>(C, ldc, M, N, m0, n0, wave, lane, smem);
-    else if (simple && ep.act == 2)          epilogue_rows_act<TM, TN, NWAVES, 2>(C, ldc, M, N, m0, n0, wave, lane, smem);
-    else if (simple && ep.act == 3)          epilogue_rows_act<TM, TN, NWAVES, 3>(C, ldc, M, N, m0, n0, wave, lane, smem);
-    else if (ep.residual && !ep.swiglu && !ep.act && ep.residual_dtype == LICV_BF16 && bf_out)
-        epilogue_rows_res<TM, TN, NWAVES, false>(ep, C, ldc, M, N, m0, n0, wave, lane, smem);
-    else if (ep.residual && !ep.swiglu && !ep.act && ep.residual_dtype == LICV_F32 && !bf_out)
-        epilogue_rows_res<TM, TN, NWAVES, true>(ep, C, ldc, M, N, m0, n0, wave, lane, smem);
-    else if (bf_out) epilogue_rows_generic<TM, TN, NWAVES, 8>(ep, C, ldc, M, N, m0, n0, wave, lane, smem);
-    else             epilogue_rows_generic<TM, TN, NWAVES, 4>(ep, C, ldc, M, N, m0, n0, wave, lane, smem);
-}
-
-// ------------------------------------------------------------------------------------------------
-// LDS-staged epilogue (all kernels).  Two measured problems of storing straight from the accumulator layout:
-// 32-byte row fragments per store, and — far worse — code size: the element-wise epilogue (erf / tanh / exp
-// bodies under run-time flags) unrolled over every accumulator register is hundreds of KiB of straight-line
-// code that misses the instruction cache on every tile (~30 us per 256x256 tile, more than the MFMAs of a
-// K=1280 tile).  So: phase A (unrolled, tiny) only does y0 = bf16(acc + bias) and parks the wave's block in
-// an LDS image of the tile (row stride +16 B against bank conflicts); after one barrier, phase B is a compact
-// run-time LOOP over full rows — 16 B per lane, whole 256/512-byte row segments — that applies activation /
-// SwiGLU pairing / row gate / tanh-gate scale / residual on the bf16 values (exactly where the unfused torch
-// ops would round) and stores bf16 or fp32.
-// ------------------------------------------------------------------------------------------------
-// timing-only instrumentation (tools/gemm_phases.py): when set, wave 0 of every pingpong workgroup records
-// wall_clock64() at [0] start, [1] stage 0 published, [2] main loop done, [3] output image in LDS, [4] end
-__device__ long long* g_dbg_ts = nullptr;
-extern "C" int licv_gemm_debug_timestamps(void* dev_buffer) {
-    long long* p = (long long*)dev_buffer;
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_ts), &p, sizeof(p)) == hipSuccess ? LICV_OK : LICV_E_HIP;
-}
-
-template <int TM, int TN, int NWAVES, int MT, int NT, bool SCALED = false>
-__device__ __forceinline__ void epilogue_staged(floatx4 (&acc)[MT][NT], const GemmEpi& ep, void* __restrict__ C, int64_t ldc,
-                                                int M, int N, int m0, int n0, int wrow0, int wcol0, int wave, int lane, char* smem,
-                                                long long* ts = nullptr, const float (*bias_pre)[4] = nullptr) {
-    constexpr int YS = TN * 2 + 16;                       // LDS row stride in bytes
-    // ---- phase A: registers -> LDS image of y0 = bf16(acc + bias)
-    {
-        const int rl = wrow0 + (lane & 15);
-        const int cq = (lane >> 4) * 4;
-        float bv[NT][4];
-        static_for<0, NT>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            const int ncol = n0 + wcol0 + j * 16 + cq;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                bv[j][r] = bias_pre ? bias_pre[j][r] : ((ep.bias && ncol + r < N) ? bf2f(ep.bias[ncol + r]) : 0.f);
-        });
-        float cs[NT][4];
-        if (SCALED) {
-            static_for<0, NT>([&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                const int ncol = n0 + wcol0 + j * 16 + cq;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) cs[j][r] = ncol + r < N ? ep.w_scale[ncol + r] : 0.f;
-            });
-        }
-        static_for<0, MT>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            const float rs = SCALED ? ep.a_scale[min(m0 + rl + i * 16, M - 1)] : 1.0f;
-            static_for<0, NT>([&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                uint2 u;
-                if (SCALED) {       // fp8 operands: C = (Aq . Wq^T) * a_scale[m] * w_scale[n]
-                    u.x = (uint32_t)f2bf(acc[i][j][0] * rs * cs[j][0] + bv[j][0]) | ((uint32_t)f2bf(acc[i][j][1] * rs * cs[j][1] + bv[j][1]) << 16);
-                    u.y = (uint32_t)f2bf(acc[i][j][2] * rs * cs[j][2] + bv[j][2]) | ((uint32_t)f2bf(acc[i][j][3] * rs * cs[j][3] + bv[j][3]) << 16);
-                } else {
-                    u.x = (uint32_t)f2bf(acc[i][j][0] + bv[j][0]) | ((uint32_t)f2bf(acc[i][j][1] + bv[j][1]) << 16);
-                    u.y = (uint32_t)f2bf(acc[i][j][2] + bv[j][2]) | ((uint32_t)f2bf(acc[i][j][3] + bv[j][3]) << 16);
-                }
-                *reinterpret_cast<uint2*>(smem + (rl + i * 16) * YS + (wcol0 + j * 16 + cq) * 2) = u;
-            });
-        });
-    }
-    __syncthreads();
-    if (ts) ts[3] = wall_clock64();
-    // ---- phase B: compact loop over rows; lane -> 8 (bf16 out) or 4 (fp32 out) consecutive OUTPUT columns
-    epilogue_rows<TM, TN, NWAVES>(ep, C, ldc, M, N, m0, n0, wave, lane, smem);
-}
-
-// ------------------------------------------------------------------------------------------------
-// 256 x 256 x 64, 8 waves, LDS-DMA staging
-// ------------------------------------------------------------------------------------------------
-#define T256_STAGE 65536          // A 32 KiB | W 32 KiB
-#define T256_LDS 139264           // two stages (128 KiB); the staged epilogue's 256 x 528 B output image needs 132 KiB
-
-template <int ABL>     // ablation builds for timing only: 1 = no DMA in the loop, 2 = DMA + barrier only (no LDS reads / MFMA)
-__global__ __launch_bounds__(512, 2)
-void gemm_bf16_tile256_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw,
-                         void* __restrict__ C, int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n, GemmEpi ep) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];     // [2 stages][A 32 KiB | W 32 KiB]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably wave-uniform (LDS-DMA base)
-    const int wm = wave >> 2, wn = wave & 3;
-    int tm, tn;
-    tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn);
-    const int m0 = tm * 256, n0 = tn * 256;
-
-    // ---- LDS-DMA source addresses: wave w stages rows [32w, 32w+32) of both tiles, 8 rows (1 KiB) per
-    // instruction; lane l -> row l/8, LDS position l%8, which holds source chunk (l%8) ^ (row & 7).
-    const int srow = lane >> 3, spos = lane & 7;
-    const bf16_t* srcA[4];
-    const bf16_t* srcW[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = wave * 32 + i * 8 + srow;
-        const int chunk = spos ^ (row & 7);
-        srcA[i] = A + (int64_t)min(m0 + row, M - 1) * lda + chunk * 8;
-        srcW[i] = W + (int64_t)min(n0 + row, N - 1) * ldw + chunk * 8;
-    }
-    auto stage = [&](int kt, int st) {
-        char* sa = smem + st * T256_STAGE + wave * 32 * 128;
-        char* sw = sa + 32768;
-        const int64_t koff = (int64_t)kt * BK;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + koff),
-                                             (__attribute__((address_space(3))) void*)(sa + i * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[i] + koff),
-                                             (__attribute__((address_space(3))) void*)(sw + i * 1024), 16, 0, 0);
-        }
-    };
-
-    floatx4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
-
-    const int nkt = K / BK;
-    stage(0, 0);
-    const int frow = lane & 15, fchunk = lane >> 4;
-    for (int kt = 0; kt < nkt; ++kt) {
-        __syncthreads();                       // drains this wave's DMA (vmcnt(0)) + everyone done with tile kt-1
-        if (ABL != 1 && kt + 1 < nkt) stage(kt + 1, (kt + 1) & 1);
-        if (ABL == 2) continue;
-        const char* sa = smem + (kt & 1) * T256_STAGE + (wm * 128) * 128;
-        const char* sw = smem + (kt & 1) * T256_STAGE + 32768 + (wn * 64) * 128;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 fa[8], fw[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) fw[j] = *reinterpret_cast<const bf16x8*>(sw + lds_off(j * 16 + frow, kk * 4 + fchunk));
-#pragma unroll
-            for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sa + lds_off(i * 16 + frow, kk * 4 + fchunk));
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
-        }
-    }
-    __syncthreads();                           // every wave is done with the ring before it becomes the output image
-    epilogue_staged<256, 256, 8, 8, 4>(acc, ep, C, ldc, M, N, m0, n0, wm * 128, wn * 64, wave, lane, smem);
-}
-
-// ------------------------------------------------------------------------------------------------
-// 256 x 256 tile, K-stages of 32, 5-deep LDS ring (160 KiB), counted vmcnt: "ring" kernel
-//   * stage = A[256 x 32] | W[256 x 32] = 32 KiB, filled by 4 LDS-DMA pieces per wave (16 rows x 64 B each);
-//   * the DMA runs 3 stages ahead of the MFMAs and is never drained inside the loop: each iteration waits
-//     only for the stage whose fragments it is about to read (s_waitcnt vmcnt(8) leaves 2 stages in flight),
-//     then one raw s_barrier (no vmcnt(0) fence) publishes it to the workgroup;
-//   * fragments of stage s+1 are read into a second register set while the 32 MFMAs of stage s execute.
-//   LDS rows are 64 B; chunk position = chunk ^ (((row>>2)&1)<<1) keeps ds_read_b128 conflict-free.
-// ------------------------------------------------------------------------------------------------
-#define RING_STAGES 5
-#define RING_STAGE_BYTES 32768
-
-__device__ __forceinline__ int ring_off(int row, int chunk) {      // bytes within a [256][32] bf16 half-stage
-    return row * 64 + ((chunk ^ (((row >> 2) & 1) << 1)) << 4);
-}
-
-__device__ __forceinline__ void wait_vmcnt(int n) {                 // n is wave-uniform: 12, 8, 4 or 0
-    if (n >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if (n == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-__global__ __launch_bounds__(512, 2)
-void gemm_bf16_ring_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw,
-                      void* __restrict__ C, int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n, GemmEpi ep) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];     // [5 stages][A 16 KiB | W 16 KiB]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-    int tm, tn;
-    tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn);
-    const int m0 = tm * 256, n0 = tn * 256;
-
-    // DMA sources: wave w fills rows [32w, 32w+32) of both operands, 16 rows per piece
-    const bf16_t* srcA[2];
-    const bf16_t* srcW[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = wave * 32 + i * 16 + (lane >> 2);
-        const int chunk = (lane & 3) ^ (((row >> 2) & 1) << 1);
-        srcA[i] = A + (int64_t)min(m0 + row, M - 1) * lda + chunk * 8;
-        srcW[i] = W + (int64_t)min(n0 + row, N - 1) * ldw + chunk * 8;
-    }
-    auto issue = [&](int s) {
-        char* sa = smem + (s % RING_STAGES) * RING_STAGE_BYTES + wave * 32 * 64;
-        char* sw = sa + 16384;
-        const int64_t koff = (int64_t)s * 32;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + koff),
-                                             (__attribute__((address_space(3))) void*)(sa + i * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[i] + koff),
-                                             (__attribute__((address_space(3))) void*)(sw + i * 1024), 16, 0, 0);
-        }
-    };
-
-    floatx4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
-
-    const int ns = K / 32;                                   // >= 4 (host guarantees K >= 128)
-    const int frow = lane & 15, fchunk = lane >> 4;
-    const int fo = ring_off(frow, fchunk);                   // (row & 15) part of the offset is lane constant
-    auto read_frags = [&](int s, bf16x8 (&fa)[8], bf16x8 (&fw)[4]) {
-        const char* sa = smem + (s % RING_STAGES) * RING_STAGE_BYTES + (wm * 128) * 64 + fo;
-        const char* sw = smem + (s % RING_STAGES) * RING_STAGE_BYTES + 16384 + (wn * 64) * 64 + fo;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) fw[j] = *reinterpret_cast<const bf16x8*>(sw + j * 16 * 64);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 64);
-    };
-    auto mma = [&](bf16x8 (&fa)[8], bf16x8 (&fw)[4]) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
-    };
-
-    // prologue: 4 stages in flight, stage 0 published, its fragments in registers
-    issue(0); issue(1); issue(2); issue(3);
-    wait_vmcnt(12);
-    __builtin_amdgcn_s_barrier();
-    bf16x8 fa0[8], fw0[4], fa1[8], fw1[4];
-    read_frags(0, fa0, fw0);
-
-    // iteration s: publish stage s+1, refill the slot stage s-1 used, prefetch fragments of s+1, MFMAs of s
-    auto step = [&](int s, bf16x8 (&fac)[8], bf16x8 (&fwc)[4], bf16x8 (&fan)[8], bf16x8 (&fwn)[4]) {
-        if (s + 1 < ns) {
-            wait_vmcnt(4 * min(2, ns - 2 - s));            // loads issued after stage s+1: stages s+2, s+3 (if they exist)
-            __builtin_amdgcn_s_barrier();
-            if (s + 4 < ns) issue(s + 4);
-            read_frags(s + 1, fan, fwn);
-        }
-        mma(fac, fwc);
-    };
-    for (int s = 0; s < ns; s += 2) {
-        step(s, fa0, fw0, fa1, fw1);
-        step(s + 1, fa1, fw1, fa0, fw0);
-    }
-    __syncthreads();                           // every wave is done with the ring before it becomes the output image
-    epilogue_staged<256, 256, 8, 8, 4>(acc, ep, C, ldc, M, N, m0, n0, wm * 128, wn * 64, wave, lane, smem);
-}
-
-// ------------------------------------------------------------------------------------------------
-// "ping-pong" kernel: same 256 x 256 tile / 32-deep K-stages / 5-slot LDS-DMA ring as the ring kernel, but the
-// two waves that share a SIMD (w and w+4) run half a stage apart: while one issues its 32 MFMAs (COMPUTE
-// phase, registers only) its partner runs its LOAD phase (12 fragment ds_reads of its next stage, 4 LDS-DMA
-// pieces for the stage 4 ahead, the counted vmcnt wait that retires the NEXT stage's pieces, lgkmcnt(0)).
-// One s_barrier per half-stage keeps the two groups complementary, publishes landed stages, and orders slot
-// reuse: a slot is refilled only after a barrier that follows the lgkmcnt(0) of its last readers.
-// ------------------------------------------------------------------------------------------------
-template <int ABL>     // ABL 1: timing-only build without the epilogue
-__global__ __launch_bounds__(512, 2)
-void gemm_bf16_pingpong_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw,
-                          void* __restrict__ C, int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n, GemmEpi ep, int stagger_ticks, int group) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];     // [5 stages][A 16 KiB | W 16 KiB]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;                         // group = wm: waves 0-3 lead, 4-7 trail
-    long long* ts = (ABL != 6 && g_dbg_ts && tid == 0) ? g_dbg_ts + (int64_t)blockIdx.x * 8 : nullptr;
-    if (ts) ts[0] = wall_clock64();
-    int tm, tn;
-    tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn, ABL == 5 ? 8 : group);
-    const int m0 = tm * 256, n0 = tn * 256;
-    // ABL 5 = split-K producer: blockIdx.y selects a range of `group` K stages; C is the fp32 workspace ([split][M_pad][N_pad])
-    const int kbase = ABL == 5 ? (int)blockIdx.y * group : 0;
-
-    const bf16_t* srcA[2];
-    const bf16_t* srcW[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = wave * 32 + i * 16 + (lane >> 2);
-        const int chunk = (lane & 3) ^ (((row >> 2) & 1) << 1);
-        srcA[i] = A + (int64_t)min(m0 + row, M - 1) * lda + chunk * 8;
-        srcW[i] = W + (int64_t)min(n0 + row, N - 1) * ldw + chunk * 8;
-    }
-    const int ns = ABL == 5 ? min(group, K / 32 - kbase) : K / 32;   // stages this workgroup runs (>= 4, host-guaranteed)
-    // First-round start stagger by XCD (blockIdx % 8): every tile of a GEMM takes the same time, so all 256 CUs reach
-    // their epilogue together and its HBM traffic arrives as one burst (measured 3.5-3.9 TB/s for 8-38 us per tile while
-    // the MFMA pipes idle).  Offsetting the XCDs by an eighth of a tile time each spreads the bursts; later workgroups
-    // inherit the offset from the workgroup they replace.
-    if (stagger_ticks > 0 && blockIdx.x < 256) {
-        const long long t_start = wall_clock64(), wait = (long long)(blockIdx.x & 7) * stagger_ticks;
-        while (wall_clock64() - t_start < wait) __builtin_amdgcn_s_sleep(16);
-    }
-    auto issue = [&](int s) {
-        char* sa = smem + (s % RING_STAGES) * RING_STAGE_BYTES + wave * 32 * 64;
-        char* sw = sa + 16384;
-        if (ABL == 2) return;                                    // timing-only ablation: no operand stream at all
-        const int64_t koff = (int64_t)(kbase + s) * 32, koffw = koff;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + koff),
-                                             (__attribute__((address_space(3))) void*)(sa + i * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[i] + koffw),
-                                             (__attribute__((address_space(3))) void*)(sw + i * 1024), 16, 0, 0);
-        }
-    };
-
-    floatx4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
-
-    const int fo = ring_off(lane & 15, lane >> 4);
-    bf16x8 fa[8], fw[4];
-
-    issue(0); issue(1); issue(2); issue(3);
-    wait_vmcnt(12);                                          // my pieces of stage 0 have landed
-    __builtin_amdgcn_s_barrier();                            // stage 0 published
-    if (ts) ts[1] = wall_clock64();
-    if (wm == 1) __builtin_amdgcn_s_barrier();               // trailing group starts half a stage later
-
-    // ABL 6 (diagnostic build, results unaffected): every wave stamps s_memtime around the segments of ONE mid-loop stage into
-    // g_dbg_ts[(block * 8 + wave) * 8 + i]: 0 load-phase start, 1 fragment reads issued, 2 DMA pieces issued, 3 counted vmcnt
-    // passed, 4 lgkmcnt(0) passed, 5 barrier passed (compute starts), 6 MFMAs issued, 7 second barrier passed
-    unsigned long long stamp[8];
-    const int probe = (ABL == 6 && g_dbg_ts) ? ns / 2 : -1;
-#define STAMP(i) do { if (ABL == 6 && s == probe) { __builtin_amdgcn_sched_barrier(0); stamp[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
-    for (int s = 0; s < ns; ++s) {
-        // ---- LOAD phase (partner computes)
-        {
-            const char* sa = smem + (s % RING_STAGES) * RING_STAGE_BYTES + (wm * 128) * 64 + fo;
-            const char* sw = smem + (s % RING_STAGES) * RING_STAGE_BYTES + 16384 + (wn * 64) * 64 + fo;
-            STAMP(0);
-            if (ABL != 3 || s == 0) {                            // ABL 3 (timing only): fragments read once, never again
-#pragma unroll
-                for (int j = 0; j < 4; ++j) fw[j] = *reinterpret_cast<const bf16x8*>(sw + j * 16 * 64);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 64);
-            }
-            STAMP(1);
-            if (s + 4 < ns) issue(s + 4);
-            STAMP(2);
-            wait_vmcnt(4 * max(0, min(3, ns - 2 - s)));      // retire my pieces of stage s+1; later stages stay in flight
-            STAMP(3);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            STAMP(4);
-        }
-        __builtin_amdgcn_s_barrier();
-        STAMP(5);
-        // ---- COMPUTE phase (partner loads)
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-        if (ABL != 4) {                                          // ABL 4 (timing only): no MFMAs
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) asm volatile("" :: "v"(fa[i]));
-#pragma unroll
-            for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(fw[j]));
-        }
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        STAMP(6);
-        __builtin_amdgcn_s_barrier();
-        STAMP(7);
-    }
-#undef STAMP
-    if (ABL == 6 && probe >= 0 && lane == 0) {                    // after the loop: a store inside it would sit on the counted vmcnt
-        long long* o = g_dbg_ts + ((int64_t)blockIdx.x * 8 + wave) * 8;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = (long long)stamp[i];
-    }
-    if (wm == 0) __builtin_amdgcn_s_barrier();               // leading group: match the barrier count
-    if (ts) ts[2] = wall_clock64();
-    if (ABL == 1) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(acc[i][j]));
-        return;
-    }
-    if (ABL == 5) {                                          // fp32 partial tile -> this split's workspace slice
-        const int64_t np = (int64_t)tiles_n * 256;
-        float* slice = reinterpret_cast<float*>(C) + (int64_t)blockIdx.y * ((int64_t)tiles_m * 256) * np;
-        const int rl = m0 + wm * 128 + (lane & 15), c0 = n0 + wn * 64 + (lane >> 4) * 4;
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                *reinterpret_cast<floatx4*>(slice + (int64_t)(rl + i * 16) * np + c0 + j * 16) = acc[i][j];
-        return;
-    }
-    epilogue_staged<256, 256, 8, 8, 4>(acc, ep, C, ldc, M, N, m0, n0, wm * 128, wn * 64, wave, lane, smem, ts);
-    if (ts) ts[4] = wall_clock64();
-}
+#include "gemm_common.h"
 
 // ------------------------------------------------------------------------------------------------
 // "lean" ping-pong kernel: the ping-pong schedule, ring and K order unchanged (bit-identical results), with the per-stage
@@ -969,165 +191,6 @@ void gemm_bf16_lean_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* _
 }
 
 // ------------------------------------------------------------------------------------------------
-// "quad" kernel: 256 x 256 tile on FOUR waves, one per SIMD, each owning a 128 x 128 block of the tile in 256 accumulator
-// registers (the whole 512-entry register file is one wave's).  Same ring (5 x [A 256 x 32 | W 256 x 32]), same K order and
-// rounding as the kernels above — bit-identical results — but
-//   * a wave reads 16 KiB of fragments per 64 MFMAs where a 128 x 64 wave reads 12 KiB per 32: a third less LDS traffic per
-//     flop (energy: the chip holds its clock by power, MI355X_MICROARCH.md 'DVFS give-back'), half the waves, half the
-//     barrier arrivals;
-//   * there is no partner wave to hide behind, so everything that is not an MFMA is slotted between the wave's own MFMAs:
-//     the 8 LDS-DMA pieces of stage s+4 (`buffer_load_dwordx4 ... offen lds`: one VGPR offset per piece that never changes,
-//     the K advance in the scalar offset — no vector ALU) between the first 32 MFMAs of stage s, the 16 fragment reads of
-//     stage s+1 (into the other register set) between the last 32;
-//   * one barrier per stage, in the MIDDLE of the MFMA stream (the pipe still holds queued work when the wave parks):
-//     before it the wave's own pieces of stage s+1 are retired by a counted vmcnt(24); after it stage s+1 is readable and —
-//     because every wave passed its lgkmcnt(0) for stage s at the top of this body — the slot of stage s is free for the
-//     DMA of stage s+5, issued in the first half of the next body.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void wait_vmcnt8(int n) {                // waits vmcnt(8 * n); n is wave-uniform, 0..3
-    if (n >= 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-    else if (n == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else if (n == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-// The accumulators are pinned to the AGPR half of the register file through the instruction's operand constraint: left to
-// itself the allocator spreads 256 accumulators over both halves and shuffles them with v_accvgpr moves inside the loop.
-#define QUAD_MFMA(c, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b))
-
-template <int VAR>      // 0 production; timing-only builds: 1 no DMA inside the loop; 2 no fragment reads inside the loop; 3 DMA pieces of 8 whole lines
-__global__ __launch_bounds__(256)
-void gemm_bf16_quad_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw,
-                      void* __restrict__ C, int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n, GemmEpi ep, int group) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];     // [5 stages][A 16 KiB | W 16 KiB]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    int tm, tn;
-    tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn, group);
-    const int m0 = tm * 256, n0 = tn * 256;
-    const int ns = K / 32;                                           // >= 4, host-guaranteed
-
-    // DMA: wave w stages rows [64w, 64w + 64) of both operands, 16 rows x 64 B per piece.  Buffer resources start at the tile's
-    // corner; rows past M / N re-read the last valid row (clamped offsets: always in bounds, the records field is not relied on)
-    const auto rA = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (int64_t)m0 * lda), 0, 0xFFFFFFFF, 0x00020000);
-    const auto rW = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (int64_t)n0 * ldw), 0, 0xFFFFFFFF, 0x00020000);
-    int offA[4], offW[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = VAR == 3 ? wave * 64 + i * 8 + (lane >> 3) : wave * 64 + i * 16 + (lane >> 2);
-        const int chunk = VAR == 3 ? (lane & 7) : (lane & 3) ^ (((row >> 2) & 1) << 1);     // VAR 3 (timing only, wrong results): whole 128-B lines per row
-        offA[i] = min(row, M - 1 - m0) * (int)lda * 2 + chunk * 16;
-        offW[i] = min(row, N - 1 - n0) * (int)ldw * 2 + chunk * 16;
-    }
-    typedef __attribute__((address_space(3))) char* lds_ptr;
-    typedef const __attribute__((address_space(3))) char* lds_cptr;
-    typedef const __attribute__((address_space(3))) bf16x8* lds_fptr;
-    const lds_ptr ring_w = (lds_ptr)smem;
-    const lds_cptr ring = (lds_cptr)smem;
-    const int lds_base = __builtin_amdgcn_readfirstlane((int)(uintptr_t)ring_w);     // LDS byte address of the ring (M0 arithmetic of VAR 6)
-    auto piece = [&](int q, int kbytes, int slot_bytes) {           // q 0-3: A rows, 4-7: W rows; q is a compile-time constant at every call
-        if (q < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, ring_w + slot_bytes + wave * 4096 + q * 1024, 16, offA[q & 3], kbytes, 0, 0);
-        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, ring_w + slot_bytes + 16384 + wave * 4096 + (q & 3) * 1024, 16, offW[q & 3], kbytes, 0, 0);
-    };
-    auto issue_all = [&](int s, int slot_bytes) {
-        static_for<0, 8>([&](auto qc) { piece(decltype(qc)::value, s * 64, slot_bytes); });
-    };
-
-    floatx4 acc[8][8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
-
-    const int fo = ring_off(lane & 15, lane >> 4);
-    const int constA = wm * 8192 + fo, constW = 16384 + wn * 8192 + fo;
-    bf16x8 fa0[8], fw0[8], fa1[8], fw1[8];
-
-    issue_all(0, 0); issue_all(1, RING_STAGE_BYTES); issue_all(2, 2 * RING_STAGE_BYTES); issue_all(3, 3 * RING_STAGE_BYTES);
-    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");        // my pieces of stage 0 have landed
-    __builtin_amdgcn_s_barrier();                            // stage 0 published
-#pragma unroll
-    for (int j = 0; j < 8; ++j) fw0[j] = *(lds_fptr)(ring + constW + j * 1024);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) fa0[i] = *(lds_fptr)(ring + constA + i * 1024);
-
-    int slot_nx = RING_STAGE_BYTES, slot_wr = 4 * RING_STAGE_BYTES;  // ring slots (byte offsets) of stage s + 1 and of stage s + 4
-    // One K stage: MFMAs on (fac, fwc) = stage s; fragments of stage s + 1 into (fan, fwn)
-    auto body = [&](int s, bf16x8 (&fac)[8], bf16x8 (&fwc)[8], bf16x8 (&fan)[8], bf16x8 (&fwn)[8], auto steady_c) {
-        constexpr bool STEADY = decltype(steady_c)::value;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // this stage's fragments are in registers
-        __builtin_amdgcn_sched_barrier(0);
-        const bool dma = STEADY || s + 4 < ns;
-        // VAR 7 (timing only, wrong results): every stage re-loads the bytes of stage 0 — the pieces are issued and land as usual but
-        // always hit the vector L1 / L2, which separates the ISSUE cost of a piece from what the memory system behind it costs
-        const int kb = VAR == 3 ? ((s + 4) * 128) % (K * 2) : VAR == 7 ? 0 : (s + 4) * 64;
-        const bool rd = STEADY || s + 1 < ns;
-        // 64 MFMAs, m = 8 i + j.  m 0-23: one DMA piece of stage s + 4 before every third MFMA.  After m = 23: my pieces of stage
-        // s + 1 are retired (counted vmcnt) and the workgroup meets — stage s + 1 is published, the slot of stage s - 1 was freed one
-        // barrier ago.  m 24-39: one fragment read of stage s + 1 before each MFMA.  m 40-63: MFMAs only (they cover the reads' latency,
-        // so the lgkmcnt(0) at the top of the next body does not wait).
-        static_for<0, 64>([&](auto mc) {
-            constexpr int m = decltype(mc)::value;
-            constexpr int i = m >> 3, j = m & 7;
-            constexpr bool SPREAD = STEADY && (VAR == 4 || VAR == 5 || VAR == 6);
-            // VAR 6: as VAR 4 with the piece written out by hand — M0 (the LDS destination) stepped in the gap BEFORE the one that
-            // carries the load, so no wait state is needed between them, and nothing but those two instructions per piece
-            if constexpr (SPREAD && VAR == 6 && m % 8 == 0) {
-                constexpr int q = m / 8;
-                if constexpr (q == 0) asm volatile("s_mov_b32 m0, %0" :: "s"(lds_base + slot_wr + wave * 4096) : "memory");
-                else if constexpr (q == 4) asm volatile("s_add_u32 m0, m0, 0x3400" ::: "memory");
-                else asm volatile("s_add_u32 m0, m0, 0x400" ::: "memory");
-            }
-            if constexpr (SPREAD && VAR == 6 && m % 8 == 1) {
-                constexpr int q = m / 8;
-                if constexpr (q < 4) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" :: "v"(offA[q & 3]), "s"(rA), "s"(kb) : "memory");
-                else asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" :: "v"(offW[q & 3]), "s"(rW), "s"(kb) : "memory");
-            }
-            if constexpr (!SPREAD && m < 24 && m % 3 == 0) {
-                if (VAR != 1 && dma) piece(m / 3, kb, slot_wr);
-            }
-            // VAR 4: the pieces spread over the whole stage, one before every eighth MFMA; VAR 5: the same, and wave w two MFMAs
-            // (32 cycles, two pieces' worth of texture-path time) behind wave w - 1, so that the four waves' pieces never queue
-            if constexpr (SPREAD && VAR == 4 && m % 8 == 0) piece(m / 8, kb, slot_wr);
-            if constexpr (SPREAD && VAR == 5 && m % 2 == 0 && (m & 7) < 8) {
-                if (wave == ((m & 7) >> 1)) piece(m / 8, kb, slot_wr);
-            }
-            if constexpr (m >= 24 && m < 40) {
-                constexpr int q = m - 24;
-                if (VAR != 2 && rd) {
-                    if constexpr (q < 8) fwn[q] = *(lds_fptr)(ring + slot_nx + constW + q * 1024);
-                    else fan[q - 8] = *(lds_fptr)(ring + slot_nx + constA + (q - 8) * 1024);
-                }
-            }
-            QUAD_MFMA(acc[i][j], fwc[j], fac[i]);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (m == 23) {
-                if (SPREAD) asm volatile("s_waitcnt vmcnt(19)" ::: "memory");       // stages s+2, s+3 and the three pieces of s+4 issued so far
-                else if (STEADY) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-                else wait_vmcnt8(max(0, min(3, ns - 2 - s)));
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        });
-        slot_wr = slot_wr == 4 * RING_STAGE_BYTES ? 0 : slot_wr + RING_STAGE_BYTES;
-        slot_nx = slot_nx == 4 * RING_STAGE_BYTES ? 0 : slot_nx + RING_STAGE_BYTES;
-    };
-    int s = 0;
-    for (; s + 5 < ns; s += 2) {
-        body(s, fa0, fw0, fa1, fw1, std::true_type{});
-        body(s + 1, fa1, fw1, fa0, fw0, std::true_type{});
-    }
-    for (; s < ns; s += 2) {
-        body(s, fa0, fw0, fa1, fw1, std::false_type{});
-        if (s + 1 < ns) body(s + 1, fa1, fw1, fa0, fw0, std::false_type{});
-    }
-    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");    // the last MFMAs' results (inline asm: no hazard tracking by the compiler)
-    __syncthreads();                           // every wave is done with the ring before it becomes the output image
-    epilogue_staged<256, 256, 4, 8, 8>(acc, ep, C, ldc, M, N, m0, n0, wm * 128, wn * 128, wave, lane, smem);
-}
-
-// ------------------------------------------------------------------------------------------------
 // "quad64" kernel: the quad kernel on 64-deep K tiles, so that an LDS-DMA piece is 8 rows x 128 B — whole cache lines — instead
 // of 16 rows x 64 B (measured on the quad kernel with a timing-only build: whole-line pieces are worth +10-14 %; the texture
 // path handles a 64-lane request line by line).
@@ -1283,225 +346,6 @@ void gemm_bf16_quad64_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t*
 }
 
 // ------------------------------------------------------------------------------------------------
-// "duo" kernel (experiment, select 50): TWO workgroups per CU instead of one with two wave groups.  A workgroup is 4 waves (one per
-// SIMD) on a 128 x 256 tile, 128 x 64 per wave (the same 128 accumulators and the same fragment traffic per MFMA as the ping-pong
-// kernels), with a 3-slot ring of 24 KiB stages (A 128 x 32 | W 256 x 32) = 72 KiB, so two workgroups share a CU.  The two waves
-// of a SIMD belong to DIFFERENT workgroups: nothing synchronises them, one's load phase, pipeline fill and — the point — its
-// whole epilogue run beside the other's MFMAs (a K = 1280 tile of the ping-pong kernels spends 25 % of its time in fill +
-// epilogue with the matrix pipe idle).  Price: a W stage is shared by 128 rows instead of 256: +50 % operand traffic from L2.
-// Same K order and rounding: bit-identical results.
-// ------------------------------------------------------------------------------------------------
-#define DUO_STAGES 3
-#define DUO_STAGE_BYTES 24576
-__global__ __launch_bounds__(256, 2)
-void gemm_bf16_duo_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw,
-                     void* __restrict__ C, int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n, GemmEpi ep, int group) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];     // [3 stages][A 8 KiB | W 16 KiB]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // = wn: columns 64 wave ... of the tile
-    int tm, tn;
-    tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn, group);
-    const int m0 = tm * 128, n0 = tn * 256;
-    const int ns = K / 32;                                           // >= 3
-
-    // DMA: wave w stages A rows [32w, 32w + 32) (2 pieces) and W rows [64w, 64w + 64) (4 pieces) of every stage
-    const bf16_t* srcA[2];
-    const bf16_t* srcW[4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = wave * 32 + i * 16 + (lane >> 2);
-        const int chunk = (lane & 3) ^ (((row >> 2) & 1) << 1);
-        srcA[i] = A + (int64_t)min(m0 + row, M - 1) * lda + chunk * 8;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = wave * 64 + i * 16 + (lane >> 2);
-        const int chunk = (lane & 3) ^ (((row >> 2) & 1) << 1);
-        srcW[i] = W + (int64_t)min(n0 + row, N - 1) * ldw + chunk * 8;
-    }
-    auto issue = [&](int slot_bytes) {
-        char* sa = smem + slot_bytes + wave * 2048;
-        char* sw = smem + slot_bytes + 8192 + wave * 4096;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcA[i],
-                                             (__attribute__((address_space(3))) void*)(sa + i * 1024), 16, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcW[i],
-                                             (__attribute__((address_space(3))) void*)(sw + i * 1024), 16, 0, 0);
-    };
-    auto advance = [&]() {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) srcA[i] += 32;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) srcW[i] += 32;
-    };
-
-    floatx4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
-
-    typedef const __attribute__((address_space(3))) char* lds_cptr;
-    typedef const __attribute__((address_space(3))) bf16x8* lds_fptr;
-    const lds_cptr ring = (lds_cptr)smem;
-    const int fo = ring_off(lane & 15, lane >> 4);
-    const int constA = fo, constW = 8192 + wave * 4096 + fo;
-    bf16x8 fa[8], fw[4];
-
-    issue(0); advance(); issue(DUO_STAGE_BYTES); advance();
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");         // my pieces of stage 0 have landed
-    __builtin_amdgcn_s_barrier();                            // stage 0 published
-
-    int slot_rd = 0, slot_wr = 2 * DUO_STAGE_BYTES;
-    lds_cptr rdA = ring + constA, rdW = ring + constW;
-    auto stage = [&](int s, auto steady_c) {
-        constexpr bool STEADY = decltype(steady_c)::value;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) fw[j] = *(lds_fptr)(rdW + j * 16 * 64);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) fa[i] = *(lds_fptr)(rdA + i * 16 * 64);
-        __builtin_amdgcn_sched_barrier(0);
-        if (STEADY) {
-            issue(slot_wr);                                  // stage s + 2 into the slot stage s - 1 used (its readers passed the last barrier)
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // retires my pieces of stage s + 1
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();                        // stage s + 1 published; every wave holds its fragments of stage s
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        slot_wr = slot_rd;
-        slot_rd = slot_rd == 2 * DUO_STAGE_BYTES ? 0 : slot_rd + DUO_STAGE_BYTES;
-        rdA = ring + (constA + slot_rd);
-        rdW = ring + (constW + slot_rd);
-        if (STEADY) advance();
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    int s = 0;
-    for (; s + 2 < ns; ++s) stage(s, std::true_type{});
-    for (; s < ns; ++s) stage(s, std::false_type{});
-    __syncthreads();                           // every wave is done with the ring before it becomes the output image
-    epilogue_staged<128, 256, 4, 8, 4>(acc, ep, C, ldc, M, N, m0, n0, 0, wave * 64, wave, lane, smem);
-}
-
-// ------------------------------------------------------------------------------------------------
-// "pair" kernel: the ping-pong schedule with TWO 32-deep K stages per phase.
-//
-// Measured on the ping-pong kernel (tools/gemm_segments.py, s_memtime stamps, cycles per wave and stage): LOAD phase 600
-// (12 fragment reads 236 — the LDS port, 4 waves x 12 KiB; 4 DMA pieces 152; counted vmcnt 108; lgkmcnt 68; barrier 36),
-// COMPUTE phase 600 (32 MFMAs), second barrier 320: 1536 per stage against 1024 if the matrix pipe never waited.  Each
-// phase is about as long as the partner's, so every barrier costs its skew, and there are two per 32 K.  With two stages
-// per phase the load phase (~950) fits under the partner's 64 MFMAs (~1200) and the barrier count per K halves — the
-// 256 x 256 x 64 geometry of the vendor library's kernels, on the same five 32 KiB ring slots:
-//   * interval H(2P): leaders read pair P (stages 2P, 2P+1) while trailers run the MFMAs of pair P-1; H(2P+1): the reverse;
-//   * BOTH groups issue the DMA of stages 2P+3 and 2P+4 during H(2P) — the leaders at the head of their load phase, the
-//     trailers at the head of their compute phase — into the slots of pair P-1, which nobody reads any more; both retire
-//     pair P+1 (counted vmcnt(4): stage 2P+4 stays in flight) before the barrier that ends H(2P+1), two intervals after the
-//     issue, and the leaders first read pair P+1 after that barrier.
-// Same tile, same K order, same epilogue: bit-identical to the ping-pong kernel.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512, 2)
-void gemm_bf16_pair_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw,
-                      void* __restrict__ C, int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n, GemmEpi ep, int group) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];     // [5 stages][A 16 KiB | W 16 KiB]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;                         // waves 0-3 lead, 4-7 trail by one interval
-    int tm, tn;
-    tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn, group);
-    const int m0 = tm * 256, n0 = tn * 256;
-    const bf16_t* srcA[2];
-    const bf16_t* srcW[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = wave * 32 + i * 16 + (lane >> 2);
-        const int chunk = (lane & 3) ^ (((row >> 2) & 1) << 1);
-        srcA[i] = A + (int64_t)min(m0 + row, M - 1) * lda + chunk * 8;
-        srcW[i] = W + (int64_t)min(n0 + row, N - 1) * ldw + chunk * 8;
-    }
-    const int ns = K / 32, npair = ns >> 1;                  // K % 64 == 0 and K >= 128: npair >= 2
-    auto issue = [&](int s) {
-        char* sa = smem + (s % RING_STAGES) * RING_STAGE_BYTES + wave * 32 * 64;
-        char* sw = sa + 16384;
-        const int64_t koff = (int64_t)s * 32;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + koff),
-                                             (__attribute__((address_space(3))) void*)(sa + i * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[i] + koff),
-                                             (__attribute__((address_space(3))) void*)(sw + i * 1024), 16, 0, 0);
-        }
-    };
-    floatx4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
-    const int fo = ring_off(lane & 15, lane >> 4);
-    bf16x8 fa0[8], fw0[4], fa1[8], fw1[4];
-    auto read_stage = [&](int s, bf16x8 (&fa)[8], bf16x8 (&fw)[4]) {
-        const char* sa = smem + (s % RING_STAGES) * RING_STAGE_BYTES + (wm * 128) * 64 + fo;
-        const char* sw = smem + (s % RING_STAGES) * RING_STAGE_BYTES + 16384 + (wn * 64) * 64 + fo;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) fw[j] = *reinterpret_cast<const bf16x8*>(sw + j * 16 * 64);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 64);
-    };
-    auto mma = [&](bf16x8 (&fa)[8], bf16x8 (&fw)[4]) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
-    };
-    // DMA of the two stages that become free when pair P is the one being read: 2P+3 and 2P+4 (P = 0: stage 3 went out in the prologue)
-    auto issue_for = [&](int P) {
-        if (P > 0 && 2 * P + 3 < ns) issue(2 * P + 3);
-        if (2 * P + 4 < ns) issue(2 * P + 4);
-    };
-    // all but stage 2P+4 (if it exists) retired: pair P+1 has landed
-    auto retire_next = [&](int P) { wait_vmcnt(2 * P + 4 < ns ? 4 : 0); };
-
-    issue(0); issue(1); issue(2); issue(3);
-    wait_vmcnt(8);                                           // my pieces of pair 0 have landed
-    __builtin_amdgcn_s_barrier();                            // pair 0 published
-    if (wm == 1) { issue_for(0); __builtin_amdgcn_s_barrier(); }     // trailers: the H(0) issue, then start one interval later
-
-    for (int P = 0; P < npair; ++P) {
-        // ---- LOAD phase (partner computes)
-        read_stage(2 * P, fa0, fw0);
-        read_stage(2 * P + 1, fa1, fw1);
-        if (wm == 0) issue_for(P);                           // leaders: H(2P)
-        else if (P + 1 < npair) retire_next(P);              // trailers: pair P+1 must be in before the barrier that ends H(2P+1)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        // ---- COMPUTE phase (partner loads)
-        __builtin_amdgcn_sched_barrier(0);
-        if (wm == 1) issue_for(P + 1);                       // trailers: H(2P+2) = the leaders' load phase of pair P+1
-        __builtin_amdgcn_s_setprio(1);
-        mma(fa0, fw0);
-        mma(fa1, fw1);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (wm == 0 && P + 1 < npair) retire_next(P);        // leaders: the same deadline, the end of H(2P+1)
-        __builtin_amdgcn_s_barrier();
-    }
-    if (wm == 0) __builtin_amdgcn_s_barrier();               // leading group: match the barrier count
-    epilogue_staged<256, 256, 8, 8, 4>(acc, ep, C, ldc, M, N, m0, n0, wm * 128, wn * 64, wave, lane, smem);
-}
-
-// ------------------------------------------------------------------------------------------------
 // fp8 (OCP e4m3) operands: the SAME kernel in bytes — a ring stage is still 64 B per operand row (= 64 fp8 K-elements
 // instead of 32 bf16), the DMA, swizzle and fragment reads are byte-identical; each 16-byte fragment feeds two
 // v_mfma_f32_16x16x32_fp8_fp8 (its low and high 8 bytes: A and W use the same byte -> k assignment, and a dot product
@@ -1583,144 +427,6 @@ void gemm_fp8_pingpong_k(const char* __restrict__ A, int64_t lda, const char* __
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();
     epilogue_staged<256, 256, 8, 8, 4, true>(acc, ep, C, ldc, M, N, m0, n0, wm * 128, wn * 64, wave, lane, smem);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Persistent ping-pong kernel: one workgroup per CU walks its share of the tile grid.  Between two tiles the
-// LDS-DMA of the NEXT tile's first three K-stages is issued into ring slots 0-2 BEFORE the current tile's
-// epilogue runs, so the pipeline fill (~2-3 us of DMA latency per tile) hides under the epilogue instead of
-// following a workgroup relaunch; the epilogue's output image then lives in the two remaining slots (64 KiB)
-// and is produced in four 64-row passes.  Same main loop, same math, same results as gemm_bf16_pingpong_k.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512, 2)
-void gemm_bf16_persist_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw,
-                         void* __restrict__ C, int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n, GemmEpi ep,
-                         int stagger_sleeps) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];     // [5 stages][A 16 KiB | W 16 KiB]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-    const int ntiles = tiles_m * tiles_n;
-    // Equal tiles keep all 256 CUs in lockstep: every CU reaches its epilogue at once, the chip alternates
-    // between a pure-MFMA phase and a pure HBM-write burst (measured ~7-10 us per 256x256 tile).  Start the
-    // 8 XCD groups (workgroups b, b+8, ... share an XCD and keep sharing operand slices through their L2)
-    // an eighth of a tile apart so one group's write burst lands under the other groups' MFMAs.
-    for (int i = 0, n = (blockIdx.x & 7) * stagger_sleeps; i < n; ++i) __builtin_amdgcn_s_sleep(64);
-    const int ns = K / 32;                                   // >= 4
-    const int fo = ring_off(lane & 15, lane >> 4);
-    char* const ybase = smem + 3 * RING_STAGE_BYTES;         // output image region: ring slots 3 and 4
-    constexpr int YS = 256 * 2 + 16;
-
-    const bf16_t* srcA[2];
-    const bf16_t* srcW[2];
-    int m0 = 0, n0 = 0;
-    auto set_tile = [&](int t) {
-        int tm, tn;
-        tile_coords(t, tiles_m, tiles_n, tm, tn);
-        m0 = tm * 256; n0 = tn * 256;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = wave * 32 + i * 16 + (lane >> 2);
-            const int chunk = (lane & 3) ^ (((row >> 2) & 1) << 1);
-            srcA[i] = A + (int64_t)min(m0 + row, M - 1) * lda + chunk * 8;
-            srcW[i] = W + (int64_t)min(n0 + row, N - 1) * ldw + chunk * 8;
-        }
-    };
-    auto issue = [&](int s) {
-        char* sa = smem + (s % RING_STAGES) * RING_STAGE_BYTES + wave * 32 * 64;
-        char* sw = sa + 16384;
-        const int64_t koff = (int64_t)s * 32;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + koff),
-                                             (__attribute__((address_space(3))) void*)(sa + i * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[i] + koff),
-                                             (__attribute__((address_space(3))) void*)(sw + i * 1024), 16, 0, 0);
-        }
-    };
-
-    // tile ids are dealt so that the 32 workgroups of an XCD (ids b, b+8, ...) walk a contiguous run together
-    int tile = blockIdx.x;
-    if (tile >= ntiles) return;
-    set_tile(tile);
-    issue(0); issue(1); issue(2);
-    for (;;) {
-        const int cm0 = m0, cn0 = n0;                        // coordinates of the tile being computed
-        floatx4 acc[8][4];
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
-        bf16x8 fa[8], fw[4];
-        issue(3);
-        wait_vmcnt(12);                                      // everything older than the 12 youngest ops: stage 0 is in
-        __builtin_amdgcn_s_barrier();
-        if (wm == 1) __builtin_amdgcn_s_barrier();           // trailing group starts half a stage later
-        for (int s = 0; s < ns; ++s) {
-            {
-                const char* sa = smem + (s % RING_STAGES) * RING_STAGE_BYTES + (wm * 128) * 64 + fo;
-                const char* sw = smem + (s % RING_STAGES) * RING_STAGE_BYTES + 16384 + (wn * 64) * 64 + fo;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) fw[j] = *reinterpret_cast<const bf16x8*>(sw + j * 16 * 64);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 64);
-                if (s + 4 < ns) issue(s + 4);
-                wait_vmcnt(4 * max(0, min(3, ns - 2 - s)));
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-        }
-        if (wm == 0) __builtin_amdgcn_s_barrier();           // leading group: match the barrier count
-
-        // ---- next tile's pipeline fill goes out before this tile's epilogue
-        const int next = tile + gridDim.x;
-        const bool more = next < ntiles;
-        if (more) { set_tile(next); issue(0); issue(1); issue(2); }
-
-        // ---- epilogue in four 64-row passes through the 64 KiB output image
-        {
-            const int cq = (lane >> 4) * 4;
-            float bv[4][4];
-            static_for<0, 4>([&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                const int ncol = cn0 + wn * 64 + j * 16 + cq;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) bv[j][r] = (ep.bias && ncol + r < N) ? bf2f(ep.bias[ncol + r]) : 0.f;
-            });
-            static_for<0, 4>([&](auto pc) {
-                constexpr int P = decltype(pc)::value;
-                if (wm == (P >> 1)) {
-                    static_for<0, 4>([&](auto ic) {
-                        constexpr int i = decltype(ic)::value;
-                        constexpr int I = 4 * (P & 1) + i;
-                        static_for<0, 4>([&](auto jc) {
-                            constexpr int j = decltype(jc)::value;
-                            uint2 u;
-                            u.x = (uint32_t)f2bf(acc[I][j][0] + bv[j][0]) | ((uint32_t)f2bf(acc[I][j][1] + bv[j][1]) << 16);
-                            u.y = (uint32_t)f2bf(acc[I][j][2] + bv[j][2]) | ((uint32_t)f2bf(acc[I][j][3] + bv[j][3]) << 16);
-                            *reinterpret_cast<uint2*>(ybase + (i * 16 + (lane & 15)) * YS + (wn * 64 + j * 16 + cq) * 2) = u;
-                        });
-                    });
-                }
-                __syncthreads();
-                epilogue_rows<64, 256, 8>(ep, C, ldc, M, N, cm0 + 64 * P, cn0, wave, lane, ybase);
-                __syncthreads();
-            });
-        }
-        if (!more) break;
-        tile = next;
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2364,27 +1070,38 @@ void pack_gate_up_k(const bf16_t* __restrict__ g, const bf16_t* __restrict__ u, 
     }
 }
 
-static int g_stagger = 0;        // per-XCD start stagger of the persistent kernel: measured slower, off
-// pingpong kernel, per-XCD first-round start stagger in percent of the estimated tile time / 8 (0 = off).
-// (A rotated K traversal per tile was also tried: -3 ... -25 %, lockstep K sweeps are what makes L2 sharing work.)
-static int g_pp_stagger = 0;
+// experiments live in gemm_experiments.hip
+extern "C" int licv_gemm_exp_launch(int which, const GemmArgs* g);
+extern "C" int licv_gemm_exp_splitk_producer(const GemmArgs* g, void* workspace, int t256m, int t256n, int splits, int per32);
+extern "C" int licv_gemm_exp_knob(int knob, int value);
+extern "C" int licv_gemm_exp_debug_timestamps(void* dev_buffer);
+
+// timing-only instrumentation (tools/gemm_phases.py, gemm_segments.py, gemm_series.py): a device buffer the diagnostic builds
+// (gemm_bf16_lean_k<0, 7 | 8 | 9>, the experiments' ping-pong kernel) write their stamps to
+extern "C" int licv_gemm_debug_timestamps(void* dev_buffer) {
+    const int rc = set_dbg_ts(dev_buffer);
+    return rc != LICV_OK ? rc : licv_gemm_exp_debug_timestamps(dev_buffer);
+}
+
 static int g_pp_group = 0;      // experiment knob: tile-rows per XCD patch group (0 = heuristic)
 static int g_splitk_enabled = 1;
-static int g_flow_default = 1;  // auto mode takes the flow kernel where it is eligible and measured faster (knob 2 of licv_gemm_experiment)
-extern "C" int licv_gemm_stagger(int on) { g_stagger = on; return LICV_OK; }
-// A/B timing knobs of the default (ping-pong) kernel, all measured neutral-to-negative and off by default:
-//   knob 0: per-XCD first-round start stagger, percent of an eighth of the estimated tile time (0 = off)
+static int g_flow_default = 1;  // auto mode takes the flow kernels where they are eligible (knob 2 of licv_gemm_experiment; 0 = staged epilogues only)
+// A/B timing knobs:
+//   knob 0: (experiments' ping-pong kernel) per-XCD first-round start stagger, percent of an eighth of the estimated tile time
 //   knob 1: tile-rows per XCD patch group (0 = the default 8)
-//   knob 2: 0 = never take the flow kernel by default;  knob 4: 0 = licv_gemm_splitk_plan always answers "one pass" (the
+//   knob 2: 0 = never take a flow kernel by default;  knob 4: 0 = licv_gemm_splitk_plan always answers "one pass" (the
 //   batch-independence tests switch split-K off for every caller, the native layer runner included)
 extern "C" int licv_gemm_experiment(int knob, int value) {
-    if (knob == 0) g_pp_stagger = value; else if (knob == 1) g_pp_group = value; else if (knob == 2) g_flow_default = value;
+    if (knob == 0) return licv_gemm_exp_knob(0, value);
+    else if (knob == 1) g_pp_group = value; else if (knob == 2) g_flow_default = value;
     else if (knob == 4) g_splitk_enabled = value;
     else return licv_set_error(LICV_E_BADARG, "gemm_experiment: unknown knob %d", knob);
     return LICV_OK;
 }
 static int g_num_cus = 256;        // persistent grid size (queried once)
-static int g_force_kernel = 0;     // 0 auto, 1 tile128, 2 tile256 (tests / A-B timing), 20 flow kernel where eligible
+// 0 auto; 1 tile128; 20 the 8-wave flow kernel where eligible (else lean); 22-27 lean variants; 40-42 quad64 variants (staged
+// epilogue); 60 the 4-wave flow64 kernel where eligible; every other value names a kernel of gemm_experiments.hip
+static int g_force_kernel = 0;
 extern "C" int licv_gemm_select(int which) { g_force_kernel = which; return LICV_OK; }
 
 // The flow kernel's counted s_waitcnt vmcnt(N) assume that the ONLY vector-memory operations a wave issues are its LDS-DMA
@@ -2431,168 +1148,75 @@ extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
             g_num_cus = cus;
+        const int ring = RING_STAGES * RING_STAGE_BYTES;
         (void)hipFuncSetAttribute((const void*)gemm_bf16_tile128_k, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_persist_k, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_pingpong_k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_pingpong_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_pingpong_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_pingpong_k<3>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_pingpong_k<4>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_ring_k, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_tile256_k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, T256_LDS);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_tile256_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, T256_LDS);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_tile256_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, T256_LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_lean_k<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, ring);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_lean_k<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, ring);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_lean_k<0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, ring);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_lean_k<0, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, ring);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_lean_k<0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, ring);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_lean_k<0, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, ring);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_quad64_k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 10 * Q64_UNIT);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_quad64_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 10 * Q64_UNIT);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_quad64_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 10 * Q64_UNIT);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_flow_k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, ring);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_flow_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, ring);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_flow_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, ring);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_flow_k<3>, hipFuncAttributeMaxDynamicSharedMemorySize, ring);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_flow_k<4>, hipFuncAttributeMaxDynamicSharedMemorySize, ring);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_flow_k<5>, hipFuncAttributeMaxDynamicSharedMemorySize, ring);
         attr_set = true;
     }
-    const bool can256 = (K % BK == 0);
+    const int fk = g_force_kernel;
+    const bool can256 = (K % BK == 0) && K >= 128;
     const bool big = can256 && M >= 512 && N >= 256;
-    // flow kernel: epilogues that need only the accumulators (and a bias row), bf16 out, whole waves in or out of N
+    const bool lean_ok = lda * 510 < (1ll << 31) && ldw * 510 < (1ll << 31);     // 32-bit lane offsets of the DMA sources
+    const int tiles_m = (int)((M + 255) / 256), tiles_n = (int)((N + 255) / 256);
+    // tile-rows per XCD patch: 8 (a 32-CU XCD then works on an 8 x 4 patch); with <= 6 tile-columns an 8-row group is 40-48
+    // tiles and the patch straddles two groups -> 2-row groups keep it compact (measured +6 % at N = 1280, K = 5120)
+    const int pp_group = g_pp_group > 0 ? g_pp_group : (tiles_n <= 6 ? 2 : 8);
+    // a kernel of gemm_experiments.hip, by number
+    const bool product_sel = fk == 0 || fk == 1 || fk == 20 || (fk >= 22 && fk <= 27) || (fk >= 40 && fk <= 42) || fk == 60;
+    if (!product_sel && K % BK == 0) {
+        GemmArgs ga{A, lda, W, ldw, C, ldc, (int)M, (int)N, (int)K, ep, (hipStream_t)stream, g_pp_group, g_num_cus};
+        if (licv_gemm_exp_launch(fk, &ga) == 1) { LICV_LAUNCH_CHECK(); return LICV_OK; }
+    }
+    // flow kernels: epilogues that need only the accumulators (and a bias row), bf16 out, whole waves in or out of N
     // ... or a bf16 residual (EPI 5: the ViT out / fc2 projections, usually in place) with no activation, gate or scale
     const bool flow_res = e->residual && e->residual_dtype == LICV_BF16 && !e->act && !e->swiglu && e->ld_res % 8 == 0 &&
                           (int64_t)(M + 256) * e->ld_res * 2 < (1ll << 31);
-    const bool flow_ok = can256 && K >= 128 && M >= 512 && N >= 256 && N % 64 == 0 && e->out_dtype == LICV_BF16 && (!e->residual || flow_res) && !e->row_gate &&
-                         !e->use_scale && (int64_t)(M + 256) * ldc * 2 < (1ll << 31) && ldc % 8 == 0 &&
+    const bool flow_ok = can256 && M >= 512 && N >= 256 && N % 64 == 0 && e->out_dtype == LICV_BF16 && (!e->residual || flow_res) && !e->row_gate &&
+                         !e->use_scale && (int64_t)(M + 256) * ldc * 2 < (1ll << 31) && ldc % 8 == 0 && lean_ok &&
                          (!e->bias_bf16 || ((uintptr_t)e->bias_bf16 & 3) == 0);
-    const bool use256 = g_force_kernel >= 2 ? can256 : (g_force_kernel == 1 ? false : big);
-    // auto mode takes it where it measured faster than the staged epilogue: short K (the epilogue is a large share of the tile:
-    // ViT QKV / fc1, cross-attention K|V; +3-5 %), not the K = 4096 shapes (-4 ... 0 %)
+    const bool use256 = fk == 1 ? false : (fk == 0 ? big : can256);
     const bool flow_auto = g_flow_default != 0;
-    if (use256 && flow_ok && flow_scratch_free() && (g_force_kernel == 20 || (g_force_kernel == 0 && flow_auto))) {
-        const int tiles_m = (int)((M + 255) / 256), tiles_n = (int)((N + 255) / 256);
-        const int pp_group = g_pp_group > 0 ? g_pp_group : (tiles_n <= 6 ? 2 : 8);
+    if (use256 && flow_ok && flow_scratch_free() && (fk == 20 || (fk == 0 && flow_auto))) {
         const dim3 grid(min(tiles_m * tiles_n, g_num_cus)), block(512);
-        static bool flow_attr = false;
-        if (!flow_attr) {
-            (void)hipFuncSetAttribute((const void*)gemm_bf16_flow_k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
-            (void)hipFuncSetAttribute((const void*)gemm_bf16_flow_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
-            (void)hipFuncSetAttribute((const void*)gemm_bf16_flow_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
-            (void)hipFuncSetAttribute((const void*)gemm_bf16_flow_k<3>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
-            (void)hipFuncSetAttribute((const void*)gemm_bf16_flow_k<4>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
-            (void)hipFuncSetAttribute((const void*)gemm_bf16_flow_k<5>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
-            flow_attr = true;
-        }
-#define FLOW(E) gemm_bf16_flow_k<E><<<grid, block, RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>( \
+        const int ring = RING_STAGES * RING_STAGE_BYTES;
+#define FLOW(E) gemm_bf16_flow_k<E><<<grid, block, ring, (hipStream_t)stream>>>( \
             (const bf16_t*)A, lda, (const bf16_t*)W, ldw, (bf16_t*)C, (int)ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep.bias, pp_group)
         if (e->residual)
-            gemm_bf16_flow_k<5><<<grid, block, RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>(
+            gemm_bf16_flow_k<5><<<grid, block, ring, (hipStream_t)stream>>>(
                 (const bf16_t*)A, lda, (const bf16_t*)W, ldw, (bf16_t*)C, (int)ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep.bias, pp_group,
                 (const bf16_t*)e->residual, (int)e->ld_res);
         else if (e->swiglu) FLOW(4); else if (e->act == 1) FLOW(1); else if (e->act == 2) FLOW(2); else if (e->act == 3) FLOW(3); else FLOW(0);
 #undef FLOW
-    } else if (use256) {
-        const int tiles_m = (int)((M + 255) / 256), tiles_n = (int)((N + 255) / 256);
+    } else if (use256 && lean_ok) {
         const dim3 grid(tiles_m * tiles_n), block(512);
-        // estimated tile time: K/32 stages x ~0.85 us + ~15 us of fill/epilogue, in 10 ns ticks; an eighth of it per XCD
-        // tile-rows per XCD patch: 8 (a 32-CU XCD then works on an 8 x 4 patch); with <= 6 tile-columns an 8-row group is 40-48
-        // tiles and the patch straddles two groups -> 2-row groups keep it compact (measured +6 % at N = 1280, K = 5120)
-        const int pp_group = g_pp_group > 0 ? g_pp_group : (tiles_n <= 6 ? 2 : 8);
-        const bool lean_ok = lda * 510 < (1ll << 31) && ldw * 510 < (1ll << 31);     // 32-bit lane offsets of the DMA sources
-        const int pp_ticks = (g_pp_stagger > 0 && tiles_m * tiles_n >= 2 * g_num_cus)
-                                 ? (int)(((K / 32) * 85 + 1500) / 8 * g_pp_stagger / 100) : 0;
-#define LAUNCH256(ABL) gemm_bf16_tile256_k<ABL><<<grid, block, T256_LDS, (hipStream_t)stream>>>( \
-            (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep)
-        if (g_force_kernel == 3) LAUNCH256(1); else if (g_force_kernel == 4) LAUNCH256(2);
-        else if (g_force_kernel == 5 && K >= 128)
-            gemm_bf16_ring_k<<<grid, block, RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>(
-                (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep);
-        else if (g_force_kernel == 7 && K >= 128)
-            gemm_bf16_pingpong_k<1><<<grid, block, RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>(
-                (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, pp_ticks, pp_group);
-        else if (g_force_kernel >= 10 && g_force_kernel <= 12 && K >= 128) {      // timing-only ablations of the main loop (wrong results)
-#define PP_ABL(X) gemm_bf16_pingpong_k<X><<<grid, block, RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>( \
-                (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, pp_ticks, pp_group)
-            if (g_force_kernel == 10) PP_ABL(2); else if (g_force_kernel == 11) PP_ABL(3); else PP_ABL(4);
-#undef PP_ABL
-        }
-        else if (g_force_kernel == 13 && K >= 128) {             // diagnostic build with per-segment s_memtime stamps
-            static bool a6 = false;
-            if (!a6) { (void)hipFuncSetAttribute((const void*)gemm_bf16_pingpong_k<6>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES); a6 = true; }
-            gemm_bf16_pingpong_k<6><<<grid, block, RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>(
-                (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, pp_ticks, pp_group);
-        }
-        else if (g_force_kernel == 21 && K >= 128) {
-            static bool a21 = false;
-            if (!a21) { (void)hipFuncSetAttribute((const void*)gemm_bf16_pair_k, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES); a21 = true; }
-            gemm_bf16_pair_k<<<grid, block, RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>(
-                (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, pp_group);
-        }
-        else if (g_force_kernel == 50 && K >= 128) {
-            static bool a50 = false;
-            if (!a50) { (void)hipFuncSetAttribute((const void*)gemm_bf16_duo_k, hipFuncAttributeMaxDynamicSharedMemorySize, DUO_STAGES * DUO_STAGE_BYTES); a50 = true; }
-            const int tm128 = (int)((M + 127) / 128);
-            gemm_bf16_duo_k<<<dim3(tm128 * tiles_n), dim3(256), DUO_STAGES * DUO_STAGE_BYTES, (hipStream_t)stream>>>(
-                (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tm128, tiles_n, ep, 2 * pp_group);
-        }
-        else if (g_force_kernel >= 40 && g_force_kernel <= 42 && K >= 128 && K % 64 == 0 && lean_ok) {
-            static bool a40 = false;
-            if (!a40) {
-                (void)hipFuncSetAttribute((const void*)gemm_bf16_quad64_k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 10 * Q64_UNIT);
-                (void)hipFuncSetAttribute((const void*)gemm_bf16_quad64_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 10 * Q64_UNIT);
-                (void)hipFuncSetAttribute((const void*)gemm_bf16_quad64_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 10 * Q64_UNIT);
-                a40 = true;
-            }
+        const int ring = RING_STAGES * RING_STAGE_BYTES;
 #define QUAD64(V) gemm_bf16_quad64_k<V><<<grid, dim3(256), 10 * Q64_UNIT, (hipStream_t)stream>>>( \
-                (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, pp_group)
-            if (g_force_kernel == 40) QUAD64(0); else if (g_force_kernel == 41) QUAD64(1); else QUAD64(2);
+            (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, pp_group)
+#define LEAN(V) gemm_bf16_lean_k<0, V><<<grid, block, ring, (hipStream_t)stream>>>( \
+            (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, pp_group)
+        if (fk == 40) QUAD64(0); else if (fk == 41) QUAD64(1); else if (fk == 42) QUAD64(2);
+        else if (fk == 23) LEAN(1); else if (fk == 24) LEAN(2); else if (fk == 25) LEAN(9); else if (fk == 26) LEAN(8); else if (fk == 27) LEAN(7);
+        else LEAN(0);
 #undef QUAD64
-        }
-        else if (g_force_kernel >= 30 && g_force_kernel <= 37 && K >= 128 && lean_ok) {
-            static bool a30 = false;
-            if (!a30) {
-                (void)hipFuncSetAttribute((const void*)gemm_bf16_quad_k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
-                (void)hipFuncSetAttribute((const void*)gemm_bf16_quad_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
-                (void)hipFuncSetAttribute((const void*)gemm_bf16_quad_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
-                (void)hipFuncSetAttribute((const void*)gemm_bf16_quad_k<3>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
-                (void)hipFuncSetAttribute((const void*)gemm_bf16_quad_k<4>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
-                (void)hipFuncSetAttribute((const void*)gemm_bf16_quad_k<5>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
-                (void)hipFuncSetAttribute((const void*)gemm_bf16_quad_k<6>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
-                (void)hipFuncSetAttribute((const void*)gemm_bf16_quad_k<7>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
-                a30 = true;
-            }
-#define QUAD(V) gemm_bf16_quad_k<V><<<grid, dim3(256), RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>( \
-                (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, pp_group)
-            if (g_force_kernel == 30) QUAD(0); else if (g_force_kernel == 31) QUAD(1); else if (g_force_kernel == 32) QUAD(2); else if (g_force_kernel == 33) QUAD(3); else if (g_force_kernel == 34) QUAD(4); else if (g_force_kernel == 35) QUAD(5); else if (g_force_kernel == 36) QUAD(6); else QUAD(7);
-#undef QUAD
-        }
-        else if (g_force_kernel >= 22 && g_force_kernel <= 27 && K >= 128 && lean_ok) {
-            static bool a22 = false;
-            if (!a22) {
-                (void)hipFuncSetAttribute((const void*)gemm_bf16_lean_k<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
-                (void)hipFuncSetAttribute((const void*)gemm_bf16_lean_k<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
-                (void)hipFuncSetAttribute((const void*)gemm_bf16_lean_k<0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
-                (void)hipFuncSetAttribute((const void*)gemm_bf16_lean_k<0, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
-                (void)hipFuncSetAttribute((const void*)gemm_bf16_lean_k<0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
-                (void)hipFuncSetAttribute((const void*)gemm_bf16_lean_k<0, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
-                a22 = true;
-            }
-#define LEAN(V) gemm_bf16_lean_k<0, V><<<grid, block, RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>( \
-                (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, pp_group)
-            if (g_force_kernel == 22) LEAN(0); else if (g_force_kernel == 23) LEAN(1); else if (g_force_kernel == 24) LEAN(2); else if (g_force_kernel == 25) LEAN(9); else if (g_force_kernel == 26) LEAN(8); else LEAN(7);
 #undef LEAN
-        }
-        else if (g_force_kernel == 6 && K >= 128)
-            gemm_bf16_pingpong_k<0><<<grid, block, RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>(
-                (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, pp_ticks, pp_group);
-        else if (g_force_kernel == 8 && K >= 128)        // measured: no faster than relaunching (kept for A/B)
-            gemm_bf16_persist_k<<<dim3(min(tiles_m * tiles_n, g_num_cus)), block, RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>(
-                (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep,
-                // one tile ~ K/32 stages x ~1300 cycles; s_sleep 64 = 4096 cycles; an eighth of a tile per XCD group
-                (tiles_m * tiles_n > g_num_cus && g_stagger) ? (int)((K / 32) * 1300 / 8 / 4096 + 1) : 0);
-        else if ((g_force_kernel == 0 || g_force_kernel == 20) && K >= 128 && lean_ok) {
-            static bool a0 = false;
-            if (!a0) { (void)hipFuncSetAttribute((const void*)gemm_bf16_lean_k<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES); a0 = true; }
-            gemm_bf16_lean_k<0, 0><<<grid, block, RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>(
-                (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, pp_group);
-        }
-        else if ((g_force_kernel == 0 || g_force_kernel == 9 || g_force_kernel == 20 || (g_force_kernel >= 22 && g_force_kernel <= 50)) && K >= 128)
-            gemm_bf16_pingpong_k<0><<<grid, block, RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>(
-                (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, pp_ticks, pp_group);
-        else LAUNCH256(0);
-#undef LAUNCH256
     } else {
-        const int tiles_m = (int)((M + 127) / 128), tiles_n = (int)((N + 127) / 128);
-        gemm_bf16_tile128_k<<<dim3(tiles_m * tiles_n), dim3(256), 65536, (hipStream_t)stream>>>(
-            (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep);
+        const int t128m = (int)((M + 127) / 128), t128n = (int)((N + 127) / 128);
+        gemm_bf16_tile128_k<<<dim3(t128m * t128n), dim3(256), 65536, (hipStream_t)stream>>>(
+            (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, t128m, t128n, ep);
     }
     LICV_LAUNCH_CHECK();
     return LICV_OK;
@@ -2718,19 +1342,17 @@ extern "C" int licv_gemm_bf16_splitk(const void* A, int64_t lda, const void* W, 
     hipStream_t st = (hipStream_t)stream;
     if (big) {
         static bool attr5 = false;
-        if (!attr5) {
-            (void)hipFuncSetAttribute((const void*)gemm_bf16_pingpong_k<5>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
-            (void)hipFuncSetAttribute((const void*)gemm_bf16_lean_k<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES);
-            attr5 = true;
-        }
+        if (!attr5) { (void)hipFuncSetAttribute((const void*)gemm_bf16_lean_k<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES); attr5 = true; }
         const int t256m = (int)(mp / 256), t256n = (int)(npad / 256);
         const int stages = (int)(K / 32), per32 = (stages + splits - 1) / splits;
-        if (lda * 510 < (1ll << 31) && ldw * 510 < (1ll << 31) && g_force_kernel != 6)
+        LICV_CHECK_ARG(lda * 510 < (1ll << 31) && ldw * 510 < (1ll << 31), "gemm_bf16_splitk: leading dimensions too large for the 256-tile producer");
+        if (g_force_kernel != 6)
             gemm_bf16_lean_k<1, 0><<<dim3(t256m * t256n, splits), dim3(512), RING_STAGES * RING_STAGE_BYTES, st>>>(
                 (const bf16_t*)A, lda, (const bf16_t*)W, ldw, workspace, 0, (int)M, (int)N, (int)K, t256m, t256n, ep, per32);
-        else
-            gemm_bf16_pingpong_k<5><<<dim3(t256m * t256n, splits), dim3(512), RING_STAGES * RING_STAGE_BYTES, st>>>(
-                (const bf16_t*)A, lda, (const bf16_t*)W, ldw, workspace, 0, (int)M, (int)N, (int)K, t256m, t256n, ep, 0, per32);
+        else {                                                 // A/B only: the round-1 ping-pong kernel as the producer
+            GemmArgs ga{A, lda, W, ldw, C, ldc, (int)M, (int)N, (int)K, ep, st, g_pp_group, g_num_cus};
+            licv_gemm_exp_splitk_producer(&ga, workspace, t256m, t256n, splits, per32);
+        }
         // the finalize kernel walks 128 x 128 tiles of the same [split][M_pad][N_pad] workspace
         gemm_splitk_finalize_k<<<dim3((int)(mp / 128) * (int)(npad / 128)), dim3(256), 65536, st>>>((const float*)workspace, C, ldc, (int)M, (int)N,
             (int)(mp / 128), (int)(npad / 128), splits, ep, 0);
@@ -2779,3 +1401,4 @@ extern "C" int licv_pack_gate_up(const void* gate, const void* up, void* packed,
     LICV_LAUNCH_CHECK();
     return LICV_OK;
 }
+

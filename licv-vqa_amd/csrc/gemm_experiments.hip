@@ -1,0 +1,936 @@
+// GEMM kernel variants that were built, measured and NOT adopted (DESIGN.md section 5 has the numbers): kept compiled and selectable
+// through licv_gemm_select() so that the kernels-agree test keeps them bit-identical to the product kernels and A/B timings can be
+// repeated.  Nothing on the product path launches anything in this file.
+//   select 2-4        gemm_bf16_tile256_k   256 x 256 x 64, two 64 KiB stages, one barrier per K tile (round 1, first version) + ablations
+//   select 5          gemm_bf16_ring_k      5-slot ring of 32-deep stages, counted vmcnt, all waves in lockstep
+//   select 6,7,10-13  gemm_bf16_pingpong_k  round-1 default: two wave groups half a stage apart (+ timing-only ablations, stamps)
+//   select 8          gemm_bf16_persist_k   persistent ping-pong with the next tile's fill issued before the epilogue
+//   select 21         gemm_bf16_pair_k      two 32-deep stages per phase
+//   select 30-37      gemm_bf16_quad_k      four waves, 128 x 128 per wave, 32-deep stages (64-byte DMA rows)
+//   select 50         gemm_bf16_duo_k       two 4-wave workgroups per CU on 128 x 256 tiles
+#include "gemm_common.h"
+
+// ------------------------------------------------------------------------------------------------
+// 256 x 256 x 64, 8 waves, LDS-DMA staging
+// ------------------------------------------------------------------------------------------------
+#define T256_STAGE 65536          // A 32 KiB | W 32 KiB
+#define T256_LDS 139264           // two stages (128 KiB); the staged epilogue's 256 x 528 B output image needs 132 KiB
+
+template <int ABL>     // ablation builds for timing only: 1 = no DMA in the loop, 2 = DMA + barrier only (no LDS reads / MFMA)
+__global__ __launch_bounds__(512, 2)
+void gemm_bf16_tile256_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw,
+                         void* __restrict__ C, int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n, GemmEpi ep) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // [2 stages][A 32 KiB | W 32 KiB]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably wave-uniform (LDS-DMA base)
+    const int wm = wave >> 2, wn = wave & 3;
+    int tm, tn;
+    tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * 256, n0 = tn * 256;
+
+    // ---- LDS-DMA source addresses: wave w stages rows [32w, 32w+32) of both tiles, 8 rows (1 KiB) per
+    // instruction; lane l -> row l/8, LDS position l%8, which holds source chunk (l%8) ^ (row & 7).
+    const int srow = lane >> 3, spos = lane & 7;
+    const bf16_t* srcA[4];
+    const bf16_t* srcW[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = wave * 32 + i * 8 + srow;
+        const int chunk = spos ^ (row & 7);
+        srcA[i] = A + (int64_t)min(m0 + row, M - 1) * lda + chunk * 8;
+        srcW[i] = W + (int64_t)min(n0 + row, N - 1) * ldw + chunk * 8;
+    }
+    auto stage = [&](int kt, int st) {
+        char* sa = smem + st * T256_STAGE + wave * 32 * 128;
+        char* sw = sa + 32768;
+        const int64_t koff = (int64_t)kt * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + koff),
+                                             (__attribute__((address_space(3))) void*)(sa + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[i] + koff),
+                                             (__attribute__((address_space(3))) void*)(sw + i * 1024), 16, 0, 0);
+        }
+    };
+
+    floatx4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    const int nkt = K / BK;
+    stage(0, 0);
+    const int frow = lane & 15, fchunk = lane >> 4;
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();                       // drains this wave's DMA (vmcnt(0)) + everyone done with tile kt-1
+        if (ABL != 1 && kt + 1 < nkt) stage(kt + 1, (kt + 1) & 1);
+        if (ABL == 2) continue;
+        const char* sa = smem + (kt & 1) * T256_STAGE + (wm * 128) * 128;
+        const char* sw = smem + (kt & 1) * T256_STAGE + 32768 + (wn * 64) * 128;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 fa[8], fw[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fw[j] = *reinterpret_cast<const bf16x8*>(sw + lds_off(j * 16 + frow, kk * 4 + fchunk));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sa + lds_off(i * 16 + frow, kk * 4 + fchunk));
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();                           // every wave is done with the ring before it becomes the output image
+    epilogue_staged<256, 256, 8, 8, 4>(acc, ep, C, ldc, M, N, m0, n0, wm * 128, wn * 64, wave, lane, smem);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 256 x 256 tile, K-stages of 32, 5-deep LDS ring (160 KiB), counted vmcnt: "ring" kernel
+//   * stage = A[256 x 32] | W[256 x 32] = 32 KiB, filled by 4 LDS-DMA pieces per wave (16 rows x 64 B each);
+//   * the DMA runs 3 stages ahead of the MFMAs and is never drained inside the loop: each iteration waits
+//     only for the stage whose fragments it is about to read (s_waitcnt vmcnt(8) leaves 2 stages in flight),
+//     then one raw s_barrier (no vmcnt(0) fence) publishes it to the workgroup;
+//   * fragments of stage s+1 are read into a second register set while the 32 MFMAs of stage s execute.
+//   LDS rows are 64 B; chunk position = chunk ^ (((row>>2)&1)<<1) keeps ds_read_b128 conflict-free.
+// ------------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(512, 2)
+void gemm_bf16_ring_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw,
+                      void* __restrict__ C, int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n, GemmEpi ep) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // [5 stages][A 16 KiB | W 16 KiB]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    int tm, tn;
+    tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * 256, n0 = tn * 256;
+
+    // DMA sources: wave w fills rows [32w, 32w+32) of both operands, 16 rows per piece
+    const bf16_t* srcA[2];
+    const bf16_t* srcW[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = wave * 32 + i * 16 + (lane >> 2);
+        const int chunk = (lane & 3) ^ (((row >> 2) & 1) << 1);
+        srcA[i] = A + (int64_t)min(m0 + row, M - 1) * lda + chunk * 8;
+        srcW[i] = W + (int64_t)min(n0 + row, N - 1) * ldw + chunk * 8;
+    }
+    auto issue = [&](int s) {
+        char* sa = smem + (s % RING_STAGES) * RING_STAGE_BYTES + wave * 32 * 64;
+        char* sw = sa + 16384;
+        const int64_t koff = (int64_t)s * 32;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + koff),
+                                             (__attribute__((address_space(3))) void*)(sa + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[i] + koff),
+                                             (__attribute__((address_space(3))) void*)(sw + i * 1024), 16, 0, 0);
+        }
+    };
+
+    floatx4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    const int ns = K / 32;                                   // >= 4 (host guarantees K >= 128)
+    const int frow = lane & 15, fchunk = lane >> 4;
+    const int fo = ring_off(frow, fchunk);                   // (row & 15) part of the offset is lane constant
+    auto read_frags = [&](int s, bf16x8 (&fa)[8], bf16x8 (&fw)[4]) {
+        const char* sa = smem + (s % RING_STAGES) * RING_STAGE_BYTES + (wm * 128) * 64 + fo;
+        const char* sw = smem + (s % RING_STAGES) * RING_STAGE_BYTES + 16384 + (wn * 64) * 64 + fo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fw[j] = *reinterpret_cast<const bf16x8*>(sw + j * 16 * 64);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 64);
+    };
+    auto mma = [&](bf16x8 (&fa)[8], bf16x8 (&fw)[4]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
+    };
+
+    // prologue: 4 stages in flight, stage 0 published, its fragments in registers
+    issue(0); issue(1); issue(2); issue(3);
+    wait_vmcnt(12);
+    __builtin_amdgcn_s_barrier();
+    bf16x8 fa0[8], fw0[4], fa1[8], fw1[4];
+    read_frags(0, fa0, fw0);
+
+    // iteration s: publish stage s+1, refill the slot stage s-1 used, prefetch fragments of s+1, MFMAs of s
+    auto step = [&](int s, bf16x8 (&fac)[8], bf16x8 (&fwc)[4], bf16x8 (&fan)[8], bf16x8 (&fwn)[4]) {
+        if (s + 1 < ns) {
+            wait_vmcnt(4 * min(2, ns - 2 - s));            // loads issued after stage s+1: stages s+2, s+3 (if they exist)
+            __builtin_amdgcn_s_barrier();
+            if (s + 4 < ns) issue(s + 4);
+            read_frags(s + 1, fan, fwn);
+        }
+        mma(fac, fwc);
+    };
+    for (int s = 0; s < ns; s += 2) {
+        step(s, fa0, fw0, fa1, fw1);
+        step(s + 1, fa1, fw1, fa0, fw0);
+    }
+    __syncthreads();                           // every wave is done with the ring before it becomes the output image
+    epilogue_staged<256, 256, 8, 8, 4>(acc, ep, C, ldc, M, N, m0, n0, wm * 128, wn * 64, wave, lane, smem);
+}
+
+// ------------------------------------------------------------------------------------------------
+// "ping-pong" kernel: same 256 x 256 tile / 32-deep K-stages / 5-slot LDS-DMA ring as the ring kernel, but the
+// two waves that share a SIMD (w and w+4) run half a stage apart: while one issues its 32 MFMAs (COMPUTE
+// phase, registers only) its partner runs its LOAD phase (12 fragment ds_reads of its next stage, 4 LDS-DMA
+// pieces for the stage 4 ahead, the counted vmcnt wait that retires the NEXT stage's pieces, lgkmcnt(0)).
+// One s_barrier per half-stage keeps the two groups complementary, publishes landed stages, and orders slot
+// reuse: a slot is refilled only after a barrier that follows the lgkmcnt(0) of its last readers.
+// ------------------------------------------------------------------------------------------------
+template <int ABL>     // ABL 1: timing-only build without the epilogue
+__global__ __launch_bounds__(512, 2)
+void gemm_bf16_pingpong_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw,
+                          void* __restrict__ C, int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n, GemmEpi ep, int stagger_ticks, int group) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // [5 stages][A 16 KiB | W 16 KiB]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;                         // group = wm: waves 0-3 lead, 4-7 trail
+    long long* ts = (ABL != 6 && g_dbg_ts && tid == 0) ? g_dbg_ts + (int64_t)blockIdx.x * 8 : nullptr;
+    if (ts) ts[0] = wall_clock64();
+    int tm, tn;
+    tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn, ABL == 5 ? 8 : group);
+    const int m0 = tm * 256, n0 = tn * 256;
+    // ABL 5 = split-K producer: blockIdx.y selects a range of `group` K stages; C is the fp32 workspace ([split][M_pad][N_pad])
+    const int kbase = ABL == 5 ? (int)blockIdx.y * group : 0;
+
+    const bf16_t* srcA[2];
+    const bf16_t* srcW[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = wave * 32 + i * 16 + (lane >> 2);
+        const int chunk = (lane & 3) ^ (((row >> 2) & 1) << 1);
+        srcA[i] = A + (int64_t)min(m0 + row, M - 1) * lda + chunk * 8;
+        srcW[i] = W + (int64_t)min(n0 + row, N - 1) * ldw + chunk * 8;
+    }
+    const int ns = ABL == 5 ? min(group, K / 32 - kbase) : K / 32;   // stages this workgroup runs (>= 4, host-guaranteed)
+    // First-round start stagger by XCD (blockIdx % 8): every tile of a GEMM takes the same time, so all 256 CUs reach
+    // their epilogue together and its HBM traffic arrives as one burst (measured 3.5-3.9 TB/s for 8-38 us per tile while
+    // the MFMA pipes idle).  Offsetting the XCDs by an eighth of a tile time each spreads the bursts; later workgroups
+    // inherit the offset from the workgroup they replace.
+    if (stagger_ticks > 0 && blockIdx.x < 256) {
+        const long long t_start = wall_clock64(), wait = (long long)(blockIdx.x & 7) * stagger_ticks;
+        while (wall_clock64() - t_start < wait) __builtin_amdgcn_s_sleep(16);
+    }
+    auto issue = [&](int s) {
+        char* sa = smem + (s % RING_STAGES) * RING_STAGE_BYTES + wave * 32 * 64;
+        char* sw = sa + 16384;
+        if (ABL == 2) return;                                    // timing-only ablation: no operand stream at all
+        const int64_t koff = (int64_t)(kbase + s) * 32, koffw = koff;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + koff),
+                                             (__attribute__((address_space(3))) void*)(sa + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[i] + koffw),
+                                             (__attribute__((address_space(3))) void*)(sw + i * 1024), 16, 0, 0);
+        }
+    };
+
+    floatx4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    const int fo = ring_off(lane & 15, lane >> 4);
+    bf16x8 fa[8], fw[4];
+
+    issue(0); issue(1); issue(2); issue(3);
+    wait_vmcnt(12);                                          // my pieces of stage 0 have landed
+    __builtin_amdgcn_s_barrier();                            // stage 0 published
+    if (ts) ts[1] = wall_clock64();
+    if (wm == 1) __builtin_amdgcn_s_barrier();               // trailing group starts half a stage later
+
+    // ABL 6 (diagnostic build, results unaffected): every wave stamps s_memtime around the segments of ONE mid-loop stage into
+    // g_dbg_ts[(block * 8 + wave) * 8 + i]: 0 load-phase start, 1 fragment reads issued, 2 DMA pieces issued, 3 counted vmcnt
+    // passed, 4 lgkmcnt(0) passed, 5 barrier passed (compute starts), 6 MFMAs issued, 7 second barrier passed
+    unsigned long long stamp[8];
+    const int probe = (ABL == 6 && g_dbg_ts) ? ns / 2 : -1;
+#define STAMP(i) do { if (ABL == 6 && s == probe) { __builtin_amdgcn_sched_barrier(0); stamp[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+    for (int s = 0; s < ns; ++s) {
+        // ---- LOAD phase (partner computes)
+        {
+            const char* sa = smem + (s % RING_STAGES) * RING_STAGE_BYTES + (wm * 128) * 64 + fo;
+            const char* sw = smem + (s % RING_STAGES) * RING_STAGE_BYTES + 16384 + (wn * 64) * 64 + fo;
+            STAMP(0);
+            if (ABL != 3 || s == 0) {                            // ABL 3 (timing only): fragments read once, never again
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fw[j] = *reinterpret_cast<const bf16x8*>(sw + j * 16 * 64);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 64);
+            }
+            STAMP(1);
+            if (s + 4 < ns) issue(s + 4);
+            STAMP(2);
+            wait_vmcnt(4 * max(0, min(3, ns - 2 - s)));      // retire my pieces of stage s+1; later stages stay in flight
+            STAMP(3);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            STAMP(4);
+        }
+        __builtin_amdgcn_s_barrier();
+        STAMP(5);
+        // ---- COMPUTE phase (partner loads)
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        if (ABL != 4) {                                          // ABL 4 (timing only): no MFMAs
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("" :: "v"(fa[i]));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(fw[j]));
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        STAMP(6);
+        __builtin_amdgcn_s_barrier();
+        STAMP(7);
+    }
+#undef STAMP
+    if (ABL == 6 && probe >= 0 && lane == 0) {                    // after the loop: a store inside it would sit on the counted vmcnt
+        long long* o = g_dbg_ts + ((int64_t)blockIdx.x * 8 + wave) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (long long)stamp[i];
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();               // leading group: match the barrier count
+    if (ts) ts[2] = wall_clock64();
+    if (ABL == 1) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(acc[i][j]));
+        return;
+    }
+    if (ABL == 5) {                                          // fp32 partial tile -> this split's workspace slice
+        const int64_t np = (int64_t)tiles_n * 256;
+        float* slice = reinterpret_cast<float*>(C) + (int64_t)blockIdx.y * ((int64_t)tiles_m * 256) * np;
+        const int rl = m0 + wm * 128 + (lane & 15), c0 = n0 + wn * 64 + (lane >> 4) * 4;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<floatx4*>(slice + (int64_t)(rl + i * 16) * np + c0 + j * 16) = acc[i][j];
+        return;
+    }
+    epilogue_staged<256, 256, 8, 8, 4>(acc, ep, C, ldc, M, N, m0, n0, wm * 128, wn * 64, wave, lane, smem, ts);
+    if (ts) ts[4] = wall_clock64();
+}
+
+// ------------------------------------------------------------------------------------------------
+// "quad" kernel: 256 x 256 tile on FOUR waves, one per SIMD, each owning a 128 x 128 block of the tile in 256 accumulator
+// registers (the whole 512-entry register file is one wave's).  Same ring (5 x [A 256 x 32 | W 256 x 32]), same K order and
+// rounding as the kernels above — bit-identical results — but
+//   * a wave reads 16 KiB of fragments per 64 MFMAs where a 128 x 64 wave reads 12 KiB per 32: a third less LDS traffic per
+//     flop (energy: the chip holds its clock by power, MI355X_MICROARCH.md 'DVFS give-back'), half the waves, half the
+//     barrier arrivals;
+//   * there is no partner wave to hide behind, so everything that is not an MFMA is slotted between the wave's own MFMAs:
+//     the 8 LDS-DMA pieces of stage s+4 (`buffer_load_dwordx4 ... offen lds`: one VGPR offset per piece that never changes,
+//     the K advance in the scalar offset — no vector ALU) between the first 32 MFMAs of stage s, the 16 fragment reads of
+//     stage s+1 (into the other register set) between the last 32;
+//   * one barrier per stage, in the MIDDLE of the MFMA stream (the pipe still holds queued work when the wave parks):
+//     before it the wave's own pieces of stage s+1 are retired by a counted vmcnt(24); after it stage s+1 is readable and —
+//     because every wave passed its lgkmcnt(0) for stage s at the top of this body — the slot of stage s is free for the
+//     DMA of stage s+5, issued in the first half of the next body.
+// ------------------------------------------------------------------------------------------------
+
+template <int VAR>      // 0 production; timing-only builds: 1 no DMA inside the loop; 2 no fragment reads inside the loop; 3 DMA pieces of 8 whole lines
+__global__ __launch_bounds__(256)
+void gemm_bf16_quad_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw,
+                      void* __restrict__ C, int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n, GemmEpi ep, int group) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // [5 stages][A 16 KiB | W 16 KiB]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int tm, tn;
+    tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn, group);
+    const int m0 = tm * 256, n0 = tn * 256;
+    const int ns = K / 32;                                           // >= 4, host-guaranteed
+
+    // DMA: wave w stages rows [64w, 64w + 64) of both operands, 16 rows x 64 B per piece.  Buffer resources start at the tile's
+    // corner; rows past M / N re-read the last valid row (clamped offsets: always in bounds, the records field is not relied on)
+    const auto rA = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (int64_t)m0 * lda), 0, 0xFFFFFFFF, 0x00020000);
+    const auto rW = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (int64_t)n0 * ldw), 0, 0xFFFFFFFF, 0x00020000);
+    int offA[4], offW[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = VAR == 3 ? wave * 64 + i * 8 + (lane >> 3) : wave * 64 + i * 16 + (lane >> 2);
+        const int chunk = VAR == 3 ? (lane & 7) : (lane & 3) ^ (((row >> 2) & 1) << 1);     // VAR 3 (timing only, wrong results): whole 128-B lines per row
+        offA[i] = min(row, M - 1 - m0) * (int)lda * 2 + chunk * 16;
+        offW[i] = min(row, N - 1 - n0) * (int)ldw * 2 + chunk * 16;
+    }
+    typedef __attribute__((address_space(3))) char* lds_ptr;
+    typedef const __attribute__((address_space(3))) char* lds_cptr;
+    typedef const __attribute__((address_space(3))) bf16x8* lds_fptr;
+    const lds_ptr ring_w = (lds_ptr)smem;
+    const lds_cptr ring = (lds_cptr)smem;
+    const int lds_base = __builtin_amdgcn_readfirstlane((int)(uintptr_t)ring_w);     // LDS byte address of the ring (M0 arithmetic of VAR 6)
+    auto piece = [&](int q, int kbytes, int slot_bytes) {           // q 0-3: A rows, 4-7: W rows; q is a compile-time constant at every call
+        if (q < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, ring_w + slot_bytes + wave * 4096 + q * 1024, 16, offA[q & 3], kbytes, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, ring_w + slot_bytes + 16384 + wave * 4096 + (q & 3) * 1024, 16, offW[q & 3], kbytes, 0, 0);
+    };
+    auto issue_all = [&](int s, int slot_bytes) {
+        static_for<0, 8>([&](auto qc) { piece(decltype(qc)::value, s * 64, slot_bytes); });
+    };
+
+    floatx4 acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    const int fo = ring_off(lane & 15, lane >> 4);
+    const int constA = wm * 8192 + fo, constW = 16384 + wn * 8192 + fo;
+    bf16x8 fa0[8], fw0[8], fa1[8], fw1[8];
+
+    issue_all(0, 0); issue_all(1, RING_STAGE_BYTES); issue_all(2, 2 * RING_STAGE_BYTES); issue_all(3, 3 * RING_STAGE_BYTES);
+    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");        // my pieces of stage 0 have landed
+    __builtin_amdgcn_s_barrier();                            // stage 0 published
+#pragma unroll
+    for (int j = 0; j < 8; ++j) fw0[j] = *(lds_fptr)(ring + constW + j * 1024);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fa0[i] = *(lds_fptr)(ring + constA + i * 1024);
+
+    int slot_nx = RING_STAGE_BYTES, slot_wr = 4 * RING_STAGE_BYTES;  // ring slots (byte offsets) of stage s + 1 and of stage s + 4
+    // One K stage: MFMAs on (fac, fwc) = stage s; fragments of stage s + 1 into (fan, fwn)
+    auto body = [&](int s, bf16x8 (&fac)[8], bf16x8 (&fwc)[8], bf16x8 (&fan)[8], bf16x8 (&fwn)[8], auto steady_c) {
+        constexpr bool STEADY = decltype(steady_c)::value;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // this stage's fragments are in registers
+        __builtin_amdgcn_sched_barrier(0);
+        const bool dma = STEADY || s + 4 < ns;
+        // VAR 7 (timing only, wrong results): every stage re-loads the bytes of stage 0 — the pieces are issued and land as usual but
+        // always hit the vector L1 / L2, which separates the ISSUE cost of a piece from what the memory system behind it costs
+        const int kb = VAR == 3 ? ((s + 4) * 128) % (K * 2) : VAR == 7 ? 0 : (s + 4) * 64;
+        const bool rd = STEADY || s + 1 < ns;
+        // 64 MFMAs, m = 8 i + j.  m 0-23: one DMA piece of stage s + 4 before every third MFMA.  After m = 23: my pieces of stage
+        // s + 1 are retired (counted vmcnt) and the workgroup meets — stage s + 1 is published, the slot of stage s - 1 was freed one
+        // barrier ago.  m 24-39: one fragment read of stage s + 1 before each MFMA.  m 40-63: MFMAs only (they cover the reads' latency,
+        // so the lgkmcnt(0) at the top of the next body does not wait).
+        static_for<0, 64>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            constexpr int i = m >> 3, j = m & 7;
+            constexpr bool SPREAD = STEADY && (VAR == 4 || VAR == 5 || VAR == 6);
+            // VAR 6: as VAR 4 with the piece written out by hand — M0 (the LDS destination) stepped in the gap BEFORE the one that
+            // carries the load, so no wait state is needed between them, and nothing but those two instructions per piece
+            if constexpr (SPREAD && VAR == 6 && m % 8 == 0) {
+                constexpr int q = m / 8;
+                if constexpr (q == 0) asm volatile("s_mov_b32 m0, %0" :: "s"(lds_base + slot_wr + wave * 4096) : "memory");
+                else if constexpr (q == 4) asm volatile("s_add_u32 m0, m0, 0x3400" ::: "memory");
+                else asm volatile("s_add_u32 m0, m0, 0x400" ::: "memory");
+            }
+            if constexpr (SPREAD && VAR == 6 && m % 8 == 1) {
+                constexpr int q = m / 8;
+                if constexpr (q < 4) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" :: "v"(offA[q & 3]), "s"(rA), "s"(kb) : "memory");
+                else asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" :: "v"(offW[q & 3]), "s"(rW), "s"(kb) : "memory");
+            }
+            if constexpr (!SPREAD && m < 24 && m % 3 == 0) {
+                if (VAR != 1 && dma) piece(m / 3, kb, slot_wr);
+            }
+            // VAR 4: the pieces spread over the whole stage, one before every eighth MFMA; VAR 5: the same, and wave w two MFMAs
+            // (32 cycles, two pieces' worth of texture-path time) behind wave w - 1, so that the four waves' pieces never queue
+            if constexpr (SPREAD && VAR == 4 && m % 8 == 0) piece(m / 8, kb, slot_wr);
+            if constexpr (SPREAD && VAR == 5 && m % 2 == 0 && (m & 7) < 8) {
+                if (wave == ((m & 7) >> 1)) piece(m / 8, kb, slot_wr);
+            }
+            if constexpr (m >= 24 && m < 40) {
+                constexpr int q = m - 24;
+                if (VAR != 2 && rd) {
+                    if constexpr (q < 8) fwn[q] = *(lds_fptr)(ring + slot_nx + constW + q * 1024);
+                    else fan[q - 8] = *(lds_fptr)(ring + slot_nx + constA + (q - 8) * 1024);
+                }
+            }
+            QUAD_MFMA(acc[i][j], fwc[j], fac[i]);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (m == 23) {
+                if (SPREAD) asm volatile("s_waitcnt vmcnt(19)" ::: "memory");       // stages s+2, s+3 and the three pieces of s+4 issued so far
+                else if (STEADY) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+                else wait_vmcnt8(max(0, min(3, ns - 2 - s)));
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        });
+        slot_wr = slot_wr == 4 * RING_STAGE_BYTES ? 0 : slot_wr + RING_STAGE_BYTES;
+        slot_nx = slot_nx == 4 * RING_STAGE_BYTES ? 0 : slot_nx + RING_STAGE_BYTES;
+    };
+    int s = 0;
+    for (; s + 5 < ns; s += 2) {
+        body(s, fa0, fw0, fa1, fw1, std::true_type{});
+        body(s + 1, fa1, fw1, fa0, fw0, std::true_type{});
+    }
+    for (; s < ns; s += 2) {
+        body(s, fa0, fw0, fa1, fw1, std::false_type{});
+        if (s + 1 < ns) body(s + 1, fa1, fw1, fa0, fw0, std::false_type{});
+    }
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");    // the last MFMAs' results (inline asm: no hazard tracking by the compiler)
+    __syncthreads();                           // every wave is done with the ring before it becomes the output image
+    epilogue_staged<256, 256, 4, 8, 8>(acc, ep, C, ldc, M, N, m0, n0, wm * 128, wn * 128, wave, lane, smem);
+}
+
+// ------------------------------------------------------------------------------------------------
+// "duo" kernel (experiment, select 50): TWO workgroups per CU instead of one with two wave groups.  A workgroup is 4 waves (one per
+// SIMD) on a 128 x 256 tile, 128 x 64 per wave (the same 128 accumulators and the same fragment traffic per MFMA as the ping-pong
+// kernels), with a 3-slot ring of 24 KiB stages (A 128 x 32 | W 256 x 32) = 72 KiB, so two workgroups share a CU.  The two waves
+// of a SIMD belong to DIFFERENT workgroups: nothing synchronises them, one's load phase, pipeline fill and — the point — its
+// whole epilogue run beside the other's MFMAs (a K = 1280 tile of the ping-pong kernels spends 25 % of its time in fill +
+// epilogue with the matrix pipe idle).  Price: a W stage is shared by 128 rows instead of 256: +50 % operand traffic from L2.
+// Same K order and rounding: bit-identical results.
+// ------------------------------------------------------------------------------------------------
+#define DUO_STAGES 3
+#define DUO_STAGE_BYTES 24576
+__global__ __launch_bounds__(256, 2)
+void gemm_bf16_duo_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw,
+                     void* __restrict__ C, int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n, GemmEpi ep, int group) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // [3 stages][A 8 KiB | W 16 KiB]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // = wn: columns 64 wave ... of the tile
+    int tm, tn;
+    tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn, group);
+    const int m0 = tm * 128, n0 = tn * 256;
+    const int ns = K / 32;                                           // >= 3
+
+    // DMA: wave w stages A rows [32w, 32w + 32) (2 pieces) and W rows [64w, 64w + 64) (4 pieces) of every stage
+    const bf16_t* srcA[2];
+    const bf16_t* srcW[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = wave * 32 + i * 16 + (lane >> 2);
+        const int chunk = (lane & 3) ^ (((row >> 2) & 1) << 1);
+        srcA[i] = A + (int64_t)min(m0 + row, M - 1) * lda + chunk * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = wave * 64 + i * 16 + (lane >> 2);
+        const int chunk = (lane & 3) ^ (((row >> 2) & 1) << 1);
+        srcW[i] = W + (int64_t)min(n0 + row, N - 1) * ldw + chunk * 8;
+    }
+    auto issue = [&](int slot_bytes) {
+        char* sa = smem + slot_bytes + wave * 2048;
+        char* sw = smem + slot_bytes + 8192 + wave * 4096;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcA[i],
+                                             (__attribute__((address_space(3))) void*)(sa + i * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcW[i],
+                                             (__attribute__((address_space(3))) void*)(sw + i * 1024), 16, 0, 0);
+    };
+    auto advance = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) srcA[i] += 32;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) srcW[i] += 32;
+    };
+
+    floatx4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    typedef const __attribute__((address_space(3))) char* lds_cptr;
+    typedef const __attribute__((address_space(3))) bf16x8* lds_fptr;
+    const lds_cptr ring = (lds_cptr)smem;
+    const int fo = ring_off(lane & 15, lane >> 4);
+    const int constA = fo, constW = 8192 + wave * 4096 + fo;
+    bf16x8 fa[8], fw[4];
+
+    issue(0); advance(); issue(DUO_STAGE_BYTES); advance();
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");         // my pieces of stage 0 have landed
+    __builtin_amdgcn_s_barrier();                            // stage 0 published
+
+    int slot_rd = 0, slot_wr = 2 * DUO_STAGE_BYTES;
+    lds_cptr rdA = ring + constA, rdW = ring + constW;
+    auto stage = [&](int s, auto steady_c) {
+        constexpr bool STEADY = decltype(steady_c)::value;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fw[j] = *(lds_fptr)(rdW + j * 16 * 64);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fa[i] = *(lds_fptr)(rdA + i * 16 * 64);
+        __builtin_amdgcn_sched_barrier(0);
+        if (STEADY) {
+            issue(slot_wr);                                  // stage s + 2 into the slot stage s - 1 used (its readers passed the last barrier)
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // retires my pieces of stage s + 1
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();                        // stage s + 1 published; every wave holds its fragments of stage s
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        slot_wr = slot_rd;
+        slot_rd = slot_rd == 2 * DUO_STAGE_BYTES ? 0 : slot_rd + DUO_STAGE_BYTES;
+        rdA = ring + (constA + slot_rd);
+        rdW = ring + (constW + slot_rd);
+        if (STEADY) advance();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    int s = 0;
+    for (; s + 2 < ns; ++s) stage(s, std::true_type{});
+    for (; s < ns; ++s) stage(s, std::false_type{});
+    __syncthreads();                           // every wave is done with the ring before it becomes the output image
+    epilogue_staged<128, 256, 4, 8, 4>(acc, ep, C, ldc, M, N, m0, n0, 0, wave * 64, wave, lane, smem);
+}
+
+// ------------------------------------------------------------------------------------------------
+// "pair" kernel: the ping-pong schedule with TWO 32-deep K stages per phase.
+//
+// Measured on the ping-pong kernel (tools/gemm_segments.py, s_memtime stamps, cycles per wave and stage): LOAD phase 600
+// (12 fragment reads 236 — the LDS port, 4 waves x 12 KiB; 4 DMA pieces 152; counted vmcnt 108; lgkmcnt 68; barrier 36),
+// COMPUTE phase 600 (32 MFMAs), second barrier 320: 1536 per stage against 1024 if the matrix pipe never waited.  Each
+// phase is about as long as the partner's, so every barrier costs its skew, and there are two per 32 K.  With two stages
+// per phase the load phase (~950) fits under the partner's 64 MFMAs (~1200) and the barrier count per K halves — the
+// 256 x 256 x 64 geometry of the vendor library's kernels, on the same five 32 KiB ring slots:
+//   * interval H(2P): leaders read pair P (stages 2P, 2P+1) while trailers run the MFMAs of pair P-1; H(2P+1): the reverse;
+//   * BOTH groups issue the DMA of stages 2P+3 and 2P+4 during H(2P) — the leaders at the head of their load phase, the
+//     trailers at the head of their compute phase — into the slots of pair P-1, which nobody reads any more; both retire
+//     pair P+1 (counted vmcnt(4): stage 2P+4 stays in flight) before the barrier that ends H(2P+1), two intervals after the
+//     issue, and the leaders first read pair P+1 after that barrier.
+// Same tile, same K order, same epilogue: bit-identical to the ping-pong kernel.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2)
+void gemm_bf16_pair_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw,
+                      void* __restrict__ C, int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n, GemmEpi ep, int group) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // [5 stages][A 16 KiB | W 16 KiB]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;                         // waves 0-3 lead, 4-7 trail by one interval
+    int tm, tn;
+    tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn, group);
+    const int m0 = tm * 256, n0 = tn * 256;
+    const bf16_t* srcA[2];
+    const bf16_t* srcW[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = wave * 32 + i * 16 + (lane >> 2);
+        const int chunk = (lane & 3) ^ (((row >> 2) & 1) << 1);
+        srcA[i] = A + (int64_t)min(m0 + row, M - 1) * lda + chunk * 8;
+        srcW[i] = W + (int64_t)min(n0 + row, N - 1) * ldw + chunk * 8;
+    }
+    const int ns = K / 32, npair = ns >> 1;                  // K % 64 == 0 and K >= 128: npair >= 2
+    auto issue = [&](int s) {
+        char* sa = smem + (s % RING_STAGES) * RING_STAGE_BYTES + wave * 32 * 64;
+        char* sw = sa + 16384;
+        const int64_t koff = (int64_t)s * 32;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + koff),
+                                             (__attribute__((address_space(3))) void*)(sa + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[i] + koff),
+                                             (__attribute__((address_space(3))) void*)(sw + i * 1024), 16, 0, 0);
+        }
+    };
+    floatx4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    const int fo = ring_off(lane & 15, lane >> 4);
+    bf16x8 fa0[8], fw0[4], fa1[8], fw1[4];
+    auto read_stage = [&](int s, bf16x8 (&fa)[8], bf16x8 (&fw)[4]) {
+        const char* sa = smem + (s % RING_STAGES) * RING_STAGE_BYTES + (wm * 128) * 64 + fo;
+        const char* sw = smem + (s % RING_STAGES) * RING_STAGE_BYTES + 16384 + (wn * 64) * 64 + fo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fw[j] = *reinterpret_cast<const bf16x8*>(sw + j * 16 * 64);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 64);
+    };
+    auto mma = [&](bf16x8 (&fa)[8], bf16x8 (&fw)[4]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
+    };
+    // DMA of the two stages that become free when pair P is the one being read: 2P+3 and 2P+4 (P = 0: stage 3 went out in the prologue)
+    auto issue_for = [&](int P) {
+        if (P > 0 && 2 * P + 3 < ns) issue(2 * P + 3);
+        if (2 * P + 4 < ns) issue(2 * P + 4);
+    };
+    // all but stage 2P+4 (if it exists) retired: pair P+1 has landed
+    auto retire_next = [&](int P) { wait_vmcnt(2 * P + 4 < ns ? 4 : 0); };
+
+    issue(0); issue(1); issue(2); issue(3);
+    wait_vmcnt(8);                                           // my pieces of pair 0 have landed
+    __builtin_amdgcn_s_barrier();                            // pair 0 published
+    if (wm == 1) { issue_for(0); __builtin_amdgcn_s_barrier(); }     // trailers: the H(0) issue, then start one interval later
+
+    for (int P = 0; P < npair; ++P) {
+        // ---- LOAD phase (partner computes)
+        read_stage(2 * P, fa0, fw0);
+        read_stage(2 * P + 1, fa1, fw1);
+        if (wm == 0) issue_for(P);                           // leaders: H(2P)
+        else if (P + 1 < npair) retire_next(P);              // trailers: pair P+1 must be in before the barrier that ends H(2P+1)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- COMPUTE phase (partner loads)
+        __builtin_amdgcn_sched_barrier(0);
+        if (wm == 1) issue_for(P + 1);                       // trailers: H(2P+2) = the leaders' load phase of pair P+1
+        __builtin_amdgcn_s_setprio(1);
+        mma(fa0, fw0);
+        mma(fa1, fw1);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (wm == 0 && P + 1 < npair) retire_next(P);        // leaders: the same deadline, the end of H(2P+1)
+        __builtin_amdgcn_s_barrier();
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();               // leading group: match the barrier count
+    epilogue_staged<256, 256, 8, 8, 4>(acc, ep, C, ldc, M, N, m0, n0, wm * 128, wn * 64, wave, lane, smem);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Persistent ping-pong kernel: one workgroup per CU walks its share of the tile grid.  Between two tiles the
+// LDS-DMA of the NEXT tile's first three K-stages is issued into ring slots 0-2 BEFORE the current tile's
+// epilogue runs, so the pipeline fill (~2-3 us of DMA latency per tile) hides under the epilogue instead of
+// following a workgroup relaunch; the epilogue's output image then lives in the two remaining slots (64 KiB)
+// and is produced in four 64-row passes.  Same main loop, same math, same results as gemm_bf16_pingpong_k.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2)
+void gemm_bf16_persist_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw,
+                         void* __restrict__ C, int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n, GemmEpi ep,
+                         int stagger_sleeps) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // [5 stages][A 16 KiB | W 16 KiB]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int ntiles = tiles_m * tiles_n;
+    // Equal tiles keep all 256 CUs in lockstep: every CU reaches its epilogue at once, the chip alternates
+    // between a pure-MFMA phase and a pure HBM-write burst (measured ~7-10 us per 256x256 tile).  Start the
+    // 8 XCD groups (workgroups b, b+8, ... share an XCD and keep sharing operand slices through their L2)
+    // an eighth of a tile apart so one group's write burst lands under the other groups' MFMAs.
+    for (int i = 0, n = (blockIdx.x & 7) * stagger_sleeps; i < n; ++i) __builtin_amdgcn_s_sleep(64);
+    const int ns = K / 32;                                   // >= 4
+    const int fo = ring_off(lane & 15, lane >> 4);
+    char* const ybase = smem + 3 * RING_STAGE_BYTES;         // output image region: ring slots 3 and 4
+    constexpr int YS = 256 * 2 + 16;
+
+    const bf16_t* srcA[2];
+    const bf16_t* srcW[2];
+    int m0 = 0, n0 = 0;
+    auto set_tile = [&](int t) {
+        int tm, tn;
+        tile_coords(t, tiles_m, tiles_n, tm, tn);
+        m0 = tm * 256; n0 = tn * 256;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = wave * 32 + i * 16 + (lane >> 2);
+            const int chunk = (lane & 3) ^ (((row >> 2) & 1) << 1);
+            srcA[i] = A + (int64_t)min(m0 + row, M - 1) * lda + chunk * 8;
+            srcW[i] = W + (int64_t)min(n0 + row, N - 1) * ldw + chunk * 8;
+        }
+    };
+    auto issue = [&](int s) {
+        char* sa = smem + (s % RING_STAGES) * RING_STAGE_BYTES + wave * 32 * 64;
+        char* sw = sa + 16384;
+        const int64_t koff = (int64_t)s * 32;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + koff),
+                                             (__attribute__((address_space(3))) void*)(sa + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[i] + koff),
+                                             (__attribute__((address_space(3))) void*)(sw + i * 1024), 16, 0, 0);
+        }
+    };
+
+    // tile ids are dealt so that the 32 workgroups of an XCD (ids b, b+8, ...) walk a contiguous run together
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    set_tile(tile);
+    issue(0); issue(1); issue(2);
+    for (;;) {
+        const int cm0 = m0, cn0 = n0;                        // coordinates of the tile being computed
+        floatx4 acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+        bf16x8 fa[8], fw[4];
+        issue(3);
+        wait_vmcnt(12);                                      // everything older than the 12 youngest ops: stage 0 is in
+        __builtin_amdgcn_s_barrier();
+        if (wm == 1) __builtin_amdgcn_s_barrier();           // trailing group starts half a stage later
+        for (int s = 0; s < ns; ++s) {
+            {
+                const char* sa = smem + (s % RING_STAGES) * RING_STAGE_BYTES + (wm * 128) * 64 + fo;
+                const char* sw = smem + (s % RING_STAGES) * RING_STAGE_BYTES + 16384 + (wn * 64) * 64 + fo;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fw[j] = *reinterpret_cast<const bf16x8*>(sw + j * 16 * 64);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 64);
+                if (s + 4 < ns) issue(s + 4);
+                wait_vmcnt(4 * max(0, min(3, ns - 2 - s)));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        }
+        if (wm == 0) __builtin_amdgcn_s_barrier();           // leading group: match the barrier count
+
+        // ---- next tile's pipeline fill goes out before this tile's epilogue
+        const int next = tile + gridDim.x;
+        const bool more = next < ntiles;
+        if (more) { set_tile(next); issue(0); issue(1); issue(2); }
+
+        // ---- epilogue in four 64-row passes through the 64 KiB output image
+        {
+            const int cq = (lane >> 4) * 4;
+            float bv[4][4];
+            static_for<0, 4>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                const int ncol = cn0 + wn * 64 + j * 16 + cq;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bv[j][r] = (ep.bias && ncol + r < N) ? bf2f(ep.bias[ncol + r]) : 0.f;
+            });
+            static_for<0, 4>([&](auto pc) {
+                constexpr int P = decltype(pc)::value;
+                if (wm == (P >> 1)) {
+                    static_for<0, 4>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
+                        constexpr int I = 4 * (P & 1) + i;
+                        static_for<0, 4>([&](auto jc) {
+                            constexpr int j = decltype(jc)::value;
+                            uint2 u;
+                            u.x = (uint32_t)f2bf(acc[I][j][0] + bv[j][0]) | ((uint32_t)f2bf(acc[I][j][1] + bv[j][1]) << 16);
+                            u.y = (uint32_t)f2bf(acc[I][j][2] + bv[j][2]) | ((uint32_t)f2bf(acc[I][j][3] + bv[j][3]) << 16);
+                            *reinterpret_cast<uint2*>(ybase + (i * 16 + (lane & 15)) * YS + (wn * 64 + j * 16 + cq) * 2) = u;
+                        });
+                    });
+                }
+                __syncthreads();
+                epilogue_rows<64, 256, 8>(ep, C, ldc, M, N, cm0 + 64 * P, cn0, wave, lane, ybase);
+                __syncthreads();
+            });
+        }
+        if (!more) break;
+        tile = next;
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// host side: the launcher the dispatch in gemm.hip calls for a licv_gemm_select() value that names a kernel of this file
+// ------------------------------------------------------------------------------------------------
+static int g_stagger = 0;        // per-XCD start stagger of the persistent kernel: measured slower, off
+// pingpong kernel, per-XCD first-round start stagger in percent of the estimated tile time / 8 (0 = off).
+// (A rotated K traversal per tile was also tried: -3 ... -25 %, lockstep K sweeps are what makes L2 sharing work.)
+static int g_pp_stagger = 0;
+extern "C" int licv_gemm_stagger(int on) { g_stagger = on; return LICV_OK; }
+extern "C" int licv_gemm_exp_knob(int knob, int value) { if (knob == 0) g_pp_stagger = value; return LICV_OK; }
+extern "C" int licv_gemm_exp_debug_timestamps(void* dev_buffer) { return set_dbg_ts(dev_buffer); }
+
+// returns 1 if a kernel was launched, 0 if `which` is not an experiment of this file (or the shape is outside what it takes)
+extern "C" int licv_gemm_exp_launch(int which, const GemmArgs* g) {
+    const bf16_t* A = (const bf16_t*)g->A; const bf16_t* W = (const bf16_t*)g->W;
+    void* C = g->C;
+    const int64_t lda = g->lda, ldw = g->ldw, ldc = g->ldc;
+    const int M = g->M, N = g->N, K = g->K;
+    const GemmEpi ep = g->ep;
+    hipStream_t stream = g->stream;
+    if (K % BK != 0) return 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        const int ring = RING_STAGES * RING_STAGE_BYTES;
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_persist_k, hipFuncAttributeMaxDynamicSharedMemorySize, ring);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_pingpong_k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, ring);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_pingpong_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, ring);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_pingpong_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, ring);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_pingpong_k<3>, hipFuncAttributeMaxDynamicSharedMemorySize, ring);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_pingpong_k<4>, hipFuncAttributeMaxDynamicSharedMemorySize, ring);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_pingpong_k<6>, hipFuncAttributeMaxDynamicSharedMemorySize, ring);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_ring_k, hipFuncAttributeMaxDynamicSharedMemorySize, ring);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_pair_k, hipFuncAttributeMaxDynamicSharedMemorySize, ring);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_tile256_k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, T256_LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_tile256_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, T256_LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_tile256_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, T256_LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_duo_k, hipFuncAttributeMaxDynamicSharedMemorySize, DUO_STAGES * DUO_STAGE_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_quad_k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, ring);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_quad_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, ring);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_quad_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, ring);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_quad_k<3>, hipFuncAttributeMaxDynamicSharedMemorySize, ring);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_quad_k<4>, hipFuncAttributeMaxDynamicSharedMemorySize, ring);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_quad_k<5>, hipFuncAttributeMaxDynamicSharedMemorySize, ring);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_quad_k<6>, hipFuncAttributeMaxDynamicSharedMemorySize, ring);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_quad_k<7>, hipFuncAttributeMaxDynamicSharedMemorySize, ring);
+        attr_set = true;
+    }
+    const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256;
+    const dim3 grid(tiles_m * tiles_n), block(512);
+    const int pp_group = g->pp_group > 0 ? g->pp_group : (tiles_n <= 6 ? 2 : 8);
+    const bool lean_ok = lda * 510 < (1ll << 31) && ldw * 510 < (1ll << 31);     // 32-bit lane offsets of the DMA sources
+    // estimated tile time: K/32 stages x ~0.85 us + ~15 us of fill/epilogue, in 10 ns ticks; an eighth of it per XCD
+    const int pp_ticks = (g_pp_stagger > 0 && tiles_m * tiles_n >= 2 * g->num_cus)
+                             ? (int)(((K / 32) * 85 + 1500) / 8 * g_pp_stagger / 100) : 0;
+    const int ring = RING_STAGES * RING_STAGE_BYTES;
+#define LAUNCH256(ABL) gemm_bf16_tile256_k<ABL><<<grid, block, T256_LDS, stream>>>(A, lda, W, ldw, C, ldc, M, N, K, tiles_m, tiles_n, ep)
+#define PP(X) gemm_bf16_pingpong_k<X><<<grid, block, ring, stream>>>(A, lda, W, ldw, C, ldc, M, N, K, tiles_m, tiles_n, ep, pp_ticks, pp_group)
+#define QUAD(V) gemm_bf16_quad_k<V><<<grid, dim3(256), ring, stream>>>(A, lda, W, ldw, C, ldc, M, N, K, tiles_m, tiles_n, ep, pp_group)
+    if (which == 2) LAUNCH256(0);
+    else if (which == 3) LAUNCH256(1);
+    else if (which == 4) LAUNCH256(2);
+    else if (K < 128) return 0;
+    else if (which == 5) gemm_bf16_ring_k<<<grid, block, ring, stream>>>(A, lda, W, ldw, C, ldc, M, N, K, tiles_m, tiles_n, ep);
+    else if (which == 6) PP(0);
+    else if (which == 7) PP(1);
+    else if (which == 10) PP(2);          // timing-only ablations of the main loop (wrong results)
+    else if (which == 11) PP(3);
+    else if (which == 12) PP(4);
+    else if (which == 13) PP(6);          // diagnostic build with per-segment s_memtime stamps
+    else if (which == 8)                  // measured: no faster than relaunching (kept for A/B)
+        gemm_bf16_persist_k<<<dim3(min(tiles_m * tiles_n, g->num_cus)), block, ring, stream>>>(A, lda, W, ldw, C, ldc, M, N, K, tiles_m, tiles_n, ep,
+            // one tile ~ K/32 stages x ~1300 cycles; s_sleep 64 = 4096 cycles; an eighth of a tile per XCD group
+            (tiles_m * tiles_n > g->num_cus && g_stagger) ? (int)((K / 32) * 1300 / 8 / 4096 + 1) : 0);
+    else if (which == 21) gemm_bf16_pair_k<<<grid, block, ring, stream>>>(A, lda, W, ldw, C, ldc, M, N, K, tiles_m, tiles_n, ep, pp_group);
+    else if (which == 50) {
+        const int tm128 = (M + 127) / 128;
+        gemm_bf16_duo_k<<<dim3(tm128 * tiles_n), dim3(256), DUO_STAGES * DUO_STAGE_BYTES, stream>>>(A, lda, W, ldw, C, ldc, M, N, K, tm128, tiles_n, ep, 2 * pp_group);
+    }
+    else if (which >= 30 && which <= 37 && lean_ok) {
+        switch (which) { case 30: QUAD(0); break; case 31: QUAD(1); break; case 32: QUAD(2); break; case 33: QUAD(3); break;
+                         case 34: QUAD(4); break; case 35: QUAD(5); break; case 36: QUAD(6); break; default: QUAD(7); }
+    }
+    else return 0;
+#undef LAUNCH256
+#undef PP
+#undef QUAD
+    return 1;
+}
+
+// split-K producer on the round-1 ping-pong kernel (select 6 only: A/B against gemm_bf16_lean_k<1>)
+extern "C" int licv_gemm_exp_splitk_producer(const GemmArgs* g, void* workspace, int t256m, int t256n, int splits, int per32) {
+    static bool attr5 = false;
+    if (!attr5) { (void)hipFuncSetAttribute((const void*)gemm_bf16_pingpong_k<5>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES); attr5 = true; }
+    gemm_bf16_pingpong_k<5><<<dim3(t256m * t256n, splits), dim3(512), RING_STAGES * RING_STAGE_BYTES, g->stream>>>(
+        (const bf16_t*)g->A, g->lda, (const bf16_t*)g->W, g->ldw, workspace, 0, g->M, g->N, g->K, t256m, t256n, g->ep, 0, per32);
+    return 1;
+}

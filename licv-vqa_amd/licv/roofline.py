@@ -40,3 +40,22 @@ def inject_bytes_per_question(a: IdeficsArch, S: int, n_hooked: int, first_strea
         return 0
     first = S * H * ((2 if first_stream_bf16 else 4) + 4)
     return first + (n_hooked - 1) * S * H * 8
+
+
+def weight_bytes(a: IdeficsArch) -> dict:
+    """bf16 bytes of the weight matrices one forward streams, per tower (the bound of the weight-streaming shapes of SURVEY.md
+    §8d: the 32-token student and the decode steps of hooked generate read every weight once per pass and reuse it over few rows)."""
+    H, I, V = a.hidden_size, a.intermediate_size, a.total_vocab
+    E = a.v_embed
+    lm = a.num_layers * (4 * H * H + 3 * H * I) + a.num_cross_layers * (2 * H * H + 3 * H * I + 2 * E * H) + H * V
+    vit = a.v_layers * (4 * E * E + 2 * E * a.v_inter) + 3 * a.v_patch * a.v_patch * E
+    perc = 0
+    if a.use_resampler:
+        inner = a.r_heads * a.r_head_dim
+        perc = a.r_depth * (4 * E * inner + 2 * E * 4 * E)
+    return dict(language=2 * lm, vision=2 * vit, perceiver=2 * perc, total=2 * (lm + vit + perc))
+
+
+def cross_kv_weight_bytes(a: IdeficsArch) -> int:
+    """The cross-attention K|V projections (image side): computed at the prefill only, the decode steps reuse their output."""
+    return 2 * a.num_cross_layers * 2 * a.v_embed * a.hidden_size

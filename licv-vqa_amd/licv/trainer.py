@@ -56,6 +56,7 @@ class ICVTrainer:
             module.global_step = 0
         self.layers = list(module.icv_model.intervention_layers)
         self._kl_sum = torch.zeros((), device=dev)
+        self.allreduce_events = None      # a list: optimizer_step appends a HIP event pair around the collective (bench.py reads it)
         self.vision_cache = None          # licv.feature_cache.VisionFeatureCache (enable_caches)
         self.teacher_cache = None         # licv.feature_cache.TeacherLogitCache
 
@@ -186,7 +187,13 @@ class ICVTrainer:
         enc = m.icv_encoder
         ga = enc.alpha.grad if enc.alpha.grad is not None else torch.zeros_like(enc.alpha)
         flat_g = torch.cat([ga.reshape(-1), enc.icv.grad.reshape(-1), self._kl_sum.reshape(1)]).to(torch.float32).contiguous()
+        if self.allreduce_events is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         allreduce_mean_(flat_g, self.group)                                # the ONE collective of the step
+        if self.allreduce_events is not None:
+            e1.record()
+            self.allreduce_events.append((e0, e1))
         kl = float(flat_g[-1])
         g = flat_g[:-1].contiguous()
         norm = float(g.norm())

@@ -58,3 +58,26 @@ def test_two_rank_trainer_matches_single_process_union_batch(tmp_path):
         assert abs(a["kl_loss"] - b["kl_loss"]) <= 1e-3 * abs(b["kl_loss"]) + 1e-6       # mean of rank means == union mean
         assert abs(a["grad_norm"] - b["grad_norm"]) <= 2e-2 * b["grad_norm"] + 1e-8
     assert r0["logs"][0]["kl_loss"] == r1["logs"][0]["kl_loss"]
+
+
+@pytest.mark.parametrize("workload", ["idefics_mid_debug", "idefics_mid_train_debug"])
+def test_bench_two_ranks_reports_what_the_process_group_saw(workload):
+    """`python bench.py --gpus 2` starts its own two ranks (a child torch.distributed.run, before the parent touches the GPU) and its
+    JSON line proves what ran: n_gpus, the backend the process group reports, the world size IT saw and one device name per rank;
+    the training workload also times its one collective.  gloo here (both ranks share this box's one GPU); RCCL on a real node."""
+    import json
+    root = HERE.parent
+    cmd = [sys.executable, str(root / "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--steps", "2", "--warmup", "0",
+           "--no-cpu-baseline", "--no-gpu-baseline", "--workload", workload]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), MASTER_ADDR="127.0.0.1")
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(root))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints ONE JSON line"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["world_size_seen"] == 2 and d["dist_backend"] == "gloo"
+    assert len(d["devices"]) == 2 and d["devices"][0].startswith("rank0:") and d["devices"][1].startswith("rank1:")
+    assert d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak" and d["value"] > 0
+    if "train" in workload:
+        ar = d["allreduce"]
+        assert ar["optimizer_steps_timed"] >= 1 and ar["per_optimizer_step_ms_median"] > 0 and ar["bytes"] > 0
