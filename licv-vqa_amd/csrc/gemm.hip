@@ -722,6 +722,342 @@ void gemm_bf16_flow_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* _
 }
 
 // ------------------------------------------------------------------------------------------------
+// "flow64" kernel (round 3): the four-wave quad64 main loop made PERSISTENT, with the register-direct asynchronous epilogue of
+// the flow kernel — and with the operand stream CONTINUOUS across output tiles.
+//
+// Why four waves on 64-deep K tiles: a wave owns 128 x 128 of the tile in 256 accumulator registers (the vendor library's
+// geometry), reads a third less LDS per flop than the 128 x 64 waves of the ping-pong pair, and its LDS-DMA pieces are 8 rows x
+// 128 B — whole cache lines.  With 32-deep stages a piece is 16 rows x 64 B: every 128-byte line is requested twice, half a line
+// per stage, a stage apart (the 32 KiB vector L1 has long dropped it), which doubles the L2 -> CU requests of the operand
+// stream; that request path is what the main loop of the 8-wave kernels runs into.  The quad64 main loop in
+// its branch-free form measured +7 % over the lean kernel (geometric mean of the headline shapes, staged epilogue on both); what
+// it still paid per tile — pipeline fill, staged epilogue, launch tail — is what this kernel removes:
+//   * the K-tile stream never drains: the ring (ten 16 KiB units, four per K tile, see gemm_bf16_quad64_k) is addressed by a
+//     running K-tile count over the workgroup's whole tile sequence, so during the LAST two K tiles of an output tile the pieces
+//     issued are the FIRST two K tiles of the next one and the last step already reads the next tile's first fragments — the
+//     barrier / counted-vmcnt protocol is the steady state's, unchanged, across the seam;
+//   * a tile's first 64 MFMAs take the constant 0 as their C operand (no accumulator clearing);
+//   * the epilogue runs between two K tiles of that stream, from the accumulators: bf16(acc + bias) [activation | SwiGLU
+//     pairing], two v_permlane16_swap per 16 x 32 block so a lane owns 8 consecutive columns, one 16-byte buffer store per block
+//     (rows past M fall outside the descriptor and are dropped: every store instruction issues, the count NST is exact); bias
+//     through the scalar cache.  No LDS image, no barrier.  The stores retire in issue order behind the pieces already in flight,
+//     so the one counted wait that would otherwise cover them — step (0, 1) of the next tile — leaves them in flight as well:
+//     s_waitcnt vmcnt(8 + NST).
+// Same tiles, same per-tile K order (32-deep MFMA steps, ascending), same rounding points as every other kernel: bit-identical
+// results (tests/test_ops_gpu.py kernels-agree test).  Needs K % 64 == 0, K >= 256, N % 128 == 0 (a wave is all in or all out).
+// ------------------------------------------------------------------------------------------------
+template <int EPI>      // 0 plain/bias, 1 GELU(erf), 2 GELU(tanh), 3 ReLU, 4 SwiGLU (N/2 output columns), 5 bias + bf16 residual (may alias C)
+__global__ __launch_bounds__(256)
+void gemm_bf16_flow64_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw,
+                        bf16_t* C, int ldc, int M, int N, int K, int tiles_m, int tiles_n, const bf16_t* __restrict__ bias, int group,
+                        const bf16_t* res = nullptr, int ld_res = 0) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // 10 units x 16 KiB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntiles = tiles_m * tiles_n;
+    const int nt = K / 64;                                           // >= 4, host-guaranteed
+    constexpr int NST = (EPI == 4) ? 16 : 32;                        // epilogue store instructions per wave and tile
+    // ... of which this many can still be in flight when the epilogue ends (EPI 5 waits for its residual loads block by block, and
+    // vector-memory operations retire in order: only the stores issued after the last such wait remain)
+    constexpr int NSTF = (EPI == 5) ? 8 : NST;
+    const auto crs = __builtin_amdgcn_make_buffer_rsrc((void*)C, 0, (int)((int64_t)M * ldc * 2), 0x00020000);
+    // EPI 5: the residual rows through a descriptor of their own (rows past M read as zero and are never stored)
+    const auto rrs = __builtin_amdgcn_make_buffer_rsrc((void*)(EPI == 5 ? res : C), 0, (int)((int64_t)M * (EPI == 5 ? ld_res : ldc) * 2), 0x00020000);
+    // Bias: each lane's 8 x 4 values (accumulator block j covers columns colbase + 16 j + 4 (lane / 16) ...) arrive by eight 8-byte
+    // buffer loads issued ONE TILE AHEAD — in the prologue for the first tile, at the end of an epilogue for the next tile — so no
+    // epilogue waits for them (through the scalar cache, as the 8-wave kernel does it, a tile paid four dependent scalar-load
+    // latencies with nothing on the CU to hide them: -15 % on the ViT QKV shape).  The loads are inline asm: invisible to the
+    // compiler's own wait insertion (which would drain the LDS-DMA pieces in flight at the first use), counted by hand like the
+    // pieces.  No bias: a descriptor of zero records, every load returns 0 without touching memory, same counts.
+    constexpr int NB = (EPI == 4) ? 0 : 8;                           // bias loads per wave and tile
+    const auto brs = __builtin_amdgcn_make_buffer_rsrc((void*)(bias ? bias : C), 0, bias ? N * 2 : 0, 0x00020000);
+    unsigned long long braw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define F64_BIAS1(J, VOFF) asm volatile("s_nop 4\n\tbuffer_load_dwordx2 %0, %1, %2, 0 offen offset:%c3" : "=v"(braw[J]) : "v"(VOFF), "s"(brs), "i"((J) * 32) : "memory")
+#define F64_LOAD_BIAS(N_TILE) do { if constexpr (EPI != 4) { const int voff_ = ((N_TILE) + wn * 128 + 4 * (lane >> 4)) * 2; \
+        F64_BIAS1(0, voff_); F64_BIAS1(1, voff_); F64_BIAS1(2, voff_); F64_BIAS1(3, voff_); \
+        F64_BIAS1(4, voff_); F64_BIAS1(5, voff_); F64_BIAS1(6, voff_); F64_BIAS1(7, voff_); } } while (0)
+    typedef __attribute__((address_space(3))) char* lds_ptr;
+    typedef const __attribute__((address_space(3))) char* lds_cptr;
+    typedef const __attribute__((address_space(3))) bf16x8* lds_fptr;
+    const lds_ptr ring_w = (lds_ptr)smem;
+    const lds_cptr ring = (lds_cptr)smem;
+    auto wrap = [](int u) { return u >= 10 ? u - 10 : u; };
+
+    // ONE set of operand sources: those of the output tile whose K tiles are being ISSUED (mP, nP: its corner; per-lane byte offsets
+    // of the wave's 8 + 8 pieces).  It moves on to the workgroup's next output tile two K tiles before the multiplication does.
+    // piece (half, q): rows half * 128 + 32 * wave + 8 q + lane / 8 of the tile; LDS position lane % 8 holds source chunk
+    // (lane % 8) ^ (row % 8); rows past M / N re-read the last valid row (those outputs are never stored)
+    int offA[2][4], offW[2][4];
+    int mP = 0, nP = 0;
+    auto set_sources = [&](int t) {
+        int tm, tn;
+        tile_coords(t, tiles_m, tiles_n, tm, tn, group);
+        mP = tm * 256; nP = tn * 256;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = h * 128 + wave * 32 + q * 8 + (lane >> 3);
+                const int chunk = (lane & 7) ^ (row & 7);
+                offA[h][q] = min(row, M - 1 - mP) * (int)lda * 2 + chunk * 16;
+                offW[h][q] = min(row, N - 1 - nP) * (int)ldw * 2 + chunk * 16;
+            }
+    };
+    // one 1-KiB piece: IS_A: A units (else W units), p = 4 * half + q, kb = byte offset of the K tile in a row, u0 = ring slot of the
+    // first of the two units
+    auto piece = [&](auto isa_c, auto p_c, int kb, int u0) {
+        constexpr bool IS_A = decltype(isa_c)::value;
+        constexpr int p = decltype(p_c)::value, h = p >> 2, q = p & 3;
+        const int slot = wrap(u0 + h);
+        const lds_ptr dst = ring_w + slot * Q64_UNIT + wave * 4096 + q * 1024;
+        if (IS_A) {
+            const auto r = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (int64_t)mP * lda), 0, 0xFFFFFFFF, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 16, offA[h][q], kb, 0, 0);
+        } else {
+            const auto r = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (int64_t)nP * ldw), 0, 0xFFFFFFFF, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 16, offW[h][q], kb, 0, 0);
+        }
+    };
+
+    // The 256 accumulators are NOT C++ values: accumulator (i, j) is a[4 (8 i + j) : 4 (8 i + j) + 3], named literally in the MFMA
+    // and in the epilogue's reads.  As values under this loop (a conditional epilogue that reads and clears them inside the K-tile
+    // loop) the register allocator kept part of them in arch VGPRs, moved them with v_accvgpr_write ahead of every MFMA and spilled
+    // to scratch (scratch traffic would also break the counted vmcnt waits).  The clearing statement below declares all of
+    // a[0:255] clobbered, which reserves that half of the register file; the compiler itself never touches it as long as its own
+    // values fit the 256 arch VGPRs (checked by licv_gemm_flow_available: no private segment; tests: kernels agree bit for bit).
+#include "gemm_acc256_clear.inc"
+    // fragment (row i * 16 + lane % 16 of the unit, K chunk kk * 4 + lane / 16): the swizzle term is (lane % 16) % 8 = lane % 8 for every i
+    const int fo0 = (lane & 15) * 128 + ((((lane >> 4)) ^ (lane & 7)) << 4);
+    const int fo1 = (lane & 15) * 128 + ((((lane >> 4) + 4) ^ (lane & 7)) << 4);
+    bf16x8 fa0[8], fw0[8], fa1[8], fw1[8];
+    // accumulator (i, j) += W fragment j (x) A fragment i; M = 8 i + j is a compile-time constant at every call
+#define F64_MFMA(M, w, a) asm volatile("v_mfma_f32_16x16x32_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" :: "v"(w), "v"(a), "i"(4 * (M)), "i"(4 * (M) + 3))
+    // read accumulator (i, j) into four floats and clear it (the next tile's first MFMA then accumulates onto zero)
+    auto take = [&](auto m_c, float (&v)[4]) {
+        constexpr int R = 4 * decltype(m_c)::value;
+        asm volatile("v_accvgpr_read_b32 %0, a[%c4]\n\tv_accvgpr_read_b32 %1, a[%c5]\n\tv_accvgpr_read_b32 %2, a[%c6]\n\tv_accvgpr_read_b32 %3, a[%c7]\n\t"
+                     "v_accvgpr_write_b32 a[%c4], 0\n\tv_accvgpr_write_b32 a[%c5], 0\n\tv_accvgpr_write_b32 a[%c6], 0\n\tv_accvgpr_write_b32 a[%c7], 0"
+                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "i"(R), "i"(R + 1), "i"(R + 2), "i"(R + 3));
+    };
+
+    int tile = blockIdx.x;                                   // the output tile being multiplied
+    if (tile >= ntiles) return;
+    set_sources(tile);
+    int mC = mP, nC = nP;                                    // its corner (the epilogue's addresses)
+
+    F64_LOAD_BIAS(nC);                                       // older than every piece: retired by the first counted wait
+    // prologue: K tiles 0 and 1 of the first output tile (units 0-7)
+    static_for<0, 8>([&](auto pc) { piece(std::false_type{}, pc, 0, 0); });
+    static_for<0, 8>([&](auto pc) { piece(std::true_type{}, pc, 0, 2); });
+    static_for<0, 8>([&](auto pc) { piece(std::false_type{}, pc, 128, 4); });
+    static_for<0, 8>([&](auto pc) { piece(std::true_type{}, pc, 128, 6); });
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");        // my pieces of K tile 0 have landed
+    __builtin_amdgcn_s_barrier();                            // K tile 0 published
+#pragma unroll
+    for (int j = 0; j < 8; ++j) fw0[j] = *(lds_fptr)(ring + wn * Q64_UNIT + fo0 + j * 2048);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fa0[i] = *(lds_fptr)(ring + (2 + wm) * Q64_UNIT + fo0 + i * 2048);
+
+    int ub = 0;                                              // ring slot of unit 4 g (W rows 0-127 of the K tile being multiplied)
+    int extra = 0;                                           // what this wave's last epilogue left queued: its stores (NSTF, if it was inside N) + the NB bias loads
+    // One body for every K tile of the workgroup's stream (g-th of the stream, t-th of its output tile): nothing in it depends on
+    // where in a tile it is except (a) which tile the pieces it issues belong to — a change of DATA (set_sources at t == nt - 2), not
+    // of code — and (b) the one counted wait that has the previous epilogue's stores in its queue (t == 0).  After the last tile's
+    // K tile nt - 2 there is nothing left to fetch: the same pieces are issued once more (K tiles 0 and 1 of the last tile again, into
+    // ring slots that are free by the protocol and never read), so every count stays what it is in the steady state.
+    for (int t = 0;; ++t) {
+        if (t == nt - 2 && tile + (int)gridDim.x < ntiles) set_sources(tile + gridDim.x);
+        const int kb = (t + 2 >= nt ? t + 2 - nt : t + 2) * 128;
+        const int ubn = wrap(ub + 4);                        // slot of unit 4 (g + 1)
+        const int u8 = wrap(ub + 8);                         // slot of unit 4 (g + 2): its W units (free since the barrier of K tile g - 1)
+        // ---- step 0: MFMAs on set 0; reads of (g, second half) into set 1; pieces of the W units of K tile g + 2
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const lds_cptr pw = ring + wrap(ub + wn) * Q64_UNIT + fo1;
+            const lds_cptr pa = ring + wrap(ub + 2 + wm) * Q64_UNIT + fo1;
+            static_for<0, 64>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                constexpr int i = m >> 3, j = m & 7;
+                if constexpr (m < 16) {
+                    if constexpr (m < 8) fw1[m] = *(lds_fptr)(pw + m * 2048);
+                    else fa1[m - 8] = *(lds_fptr)(pa + (m - 8) * 2048);
+                }
+                if constexpr (m >= 16 && m < 40 && (m - 16) % 3 == 0)
+                    piece(std::false_type{}, std::integral_constant<int, (m - 16) / 3>{}, kb, u8);
+                F64_MFMA(m, fw0[j], fa0[i]);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+        // ---- step 1: MFMAs on set 1; rendezvous; reads of (g + 1, first half) into set 0; pieces of the A units of K tile g + 2
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const lds_cptr pw = ring + wrap(ubn + wn) * Q64_UNIT + fo0;
+            const lds_cptr pa = ring + wrap(ubn + 2 + wm) * Q64_UNIT + fo0;
+            const int u10 = ub;                              // slots of units 4 g, 4 g + 1 = units 4 (g + 2) + 2, + 3: freed by this step's barrier
+            static_for<0, 64>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                constexpr int i = m >> 3, j = m & 7;
+                if constexpr (m >= 8 && m < 24) {
+                    constexpr int r = m - 8;
+                    if constexpr (r < 8) fw0[r] = *(lds_fptr)(pw + r * 2048);
+                    else fa0[r - 8] = *(lds_fptr)(pa + (r - 8) * 2048);
+                }
+                if constexpr (m >= 24 && m < 48 && (m - 24) % 3 == 0)
+                    piece(std::true_type{}, std::integral_constant<int, (m - 24) / 3>{}, kb, u10);
+                F64_MFMA(m, fw1[j], fa1[i]);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (m == 7) {
+                    // in flight, oldest first: W(g+1), A(g+1), [the previous epilogue's stores,] W(g+2): retire K tile g + 1
+                    if (t == 0 && extra != 0) {
+                        if (extra == NB) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(8 + NB) : "memory");
+                        else asm volatile("s_waitcnt vmcnt(%0)" :: "i"(8 + NSTF + NB) : "memory");
+                    } else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+        }
+        ub = ubn;
+        if (t + 1 < nt) continue;
+
+        // ==== the output tile is complete: register-direct epilogue of tile (mC, nC); the next tile's K tiles 0 and 1 are in flight
+        // or landed meanwhile, its first fragments are being read into set 0.  Every accumulator is cleared as it is read.
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");    // the last MFMAs' results (inline asm: no hazard tracking by the compiler)
+        __builtin_amdgcn_sched_barrier(0);
+        const int colbase = nC + wn * 128;                   // wave-uniform; N % 128 == 0 -> a wave is all in or all out
+        const bool inside = colbase < N;
+        if (inside) {                                        // one wave-uniform branch around the whole epilogue: every load / store below
+                                                             // always issues, so the counted waits (mine and the compiler's) are exact
+            const int fr = lane & 15, fq = lane >> 4;
+            if constexpr (EPI != 4) {
+                float bv[8][4];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    asm volatile("" : "+v"(braw[j]));            // loaded a tile ago (retired in order ahead of pieces long since waited for)
+                    const uint32_t lo = (uint32_t)braw[j], hi = (uint32_t)(braw[j] >> 32);
+                    bv[j][0] = __uint_as_float(lo << 16); bv[j][1] = __uint_as_float(lo & 0xffff0000u);
+                    bv[j][2] = __uint_as_float(hi << 16); bv[j][3] = __uint_as_float(hi & 0xffff0000u);
+                }
+                const uint32_t off0 = (uint32_t)(((mC + wm * 128 + fr) * ldc + colbase + (fq & 1) * 16 + (fq >> 1) * 8) * 2);
+                // EPI 5: out = bf16(residual + y0), y0 = bf16(acc + bias) (the rounding points of epilogue_rows_res).  The residual of
+                // block b = 4 i + p (16 rows x 32 columns per wave-instruction, 16 B per lane, the addresses the store will use) is in
+                // flight 8 blocks ahead, in 32 registers: issued at the start for blocks 0-7, then the load of block b + 8 right after
+                // the store of block b.  One counted wait per block: the operations younger than the load of block b are the 7 loads
+                // after it, or — from block 7 on — the 7 store / load pairs issued since (14), and at the end the stores alone.
+                u32x4 rres[8];
+                const uint32_t roff0 = EPI == 5 ? (uint32_t)(((mC + wm * 128 + fr) * ld_res + colbase + (fq & 1) * 16 + (fq >> 1) * 8) * 2) : 0u;
+                if constexpr (EPI == 5) {
+                    static_for<0, 8>([&](auto bc) {
+                        constexpr int bb = decltype(bc)::value;
+                        rres[bb] = __builtin_amdgcn_raw_buffer_load_b128(rrs, roff0 + (uint32_t)((bb >> 2) * 16 * ld_res * 2 + (bb & 3) * 64), 0, 0);
+                    });
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                static_for<0, 8>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    static_for<0, 4>([&](auto pc) {
+                        constexpr int p = decltype(pc)::value;
+                        float y[2][4], c[2][4];
+                        take(std::integral_constant<int, 8 * i + 2 * p>{}, c[0]);
+                        take(std::integral_constant<int, 8 * i + 2 * p + 1>{}, c[1]);
+                        if constexpr (EPI == 1) {                       // erf GELU, two values per packed instruction
+    #pragma unroll
+                            for (int h = 0; h < 2; ++h)
+    #pragma unroll
+                                for (int r = 0; r < 4; r += 2) {
+                                    const f32x2 g2 = gelu_erf_fast2(f32x2{rbf(c[h][r] + bv[2 * p + h][r]), rbf(c[h][r + 1] + bv[2 * p + h][r + 1])});
+                                    y[h][r] = g2[0]; y[h][r + 1] = g2[1];
+                                }
+                        } else {
+    #pragma unroll
+                            for (int h = 0; h < 2; ++h)
+    #pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const float v = c[h][r] + bv[2 * p + h][r];
+                                    y[h][r] = (EPI == 0 || EPI == 5) ? v : act_apply(rbf(v), EPI);
+                                }
+                        }
+                        uint32_t a0 = pack_bf2(y[0][0], y[0][1]), a1 = pack_bf2(y[0][2], y[0][3]);
+                        uint32_t b0 = pack_bf2(y[1][0], y[1][1]), b1 = pack_bf2(y[1][2], y[1][3]);
+                        swap16(a0, b0);
+                        swap16(a1, b1);
+                        u32x4 outv = u32x4{a0, a1, b0, b1};         // 8 consecutive columns of y0 = bf16(acc + bias)
+                        if constexpr (EPI == 5) {
+                            constexpr int bb = 4 * i + p;
+                            constexpr int younger = bb < 7 ? 7 + bb : (bb <= 24 ? 14 : 7 + (31 - bb));
+                            __builtin_amdgcn_sched_barrier(0);
+                            asm volatile("s_waitcnt vmcnt(%0)" :: "i"(younger) : "memory");
+                            __builtin_amdgcn_sched_barrier(0);
+                            float q[8], tt[8], z[8];
+                            unpack8(rres[bb & 7], q);
+                            unpack8(outv, tt);
+    #pragma unroll
+                            for (int e = 0; e < 8; ++e) z[e] = q[e] + tt[e];
+                            outv = pack8(z);
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b128(outv, crs, off0 + (uint32_t)(i * 16 * ldc * 2 + p * 64), 0, 0);
+                        if constexpr (EPI == 5 && 4 * i + p + 8 < 32) {
+                            constexpr int nb = 4 * i + p + 8;
+                            __builtin_amdgcn_sched_barrier(0);
+                            rres[nb & 7] = __builtin_amdgcn_raw_buffer_load_b128(rrs, roff0 + (uint32_t)((nb >> 2) * 16 * ld_res * 2 + (nb & 3) * 64), 0, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                });
+            } else {
+                // packed column blocks of 16: acc[.][4q] gate / acc[.][4q+1] up of output block 2q, acc[.][4q+2] / acc[.][4q+3] of 2q+1
+                const uint32_t off0 = (uint32_t)(((mC + wm * 128 + fr) * ldc + (colbase >> 1) + (fq & 1) * 16 + (fq >> 1) * 8) * 2);
+                static_for<0, 8>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    static_for<0, 2>([&](auto qc) {
+                        constexpr int q = decltype(qc)::value;
+                        float y[2][4], c[4][4];
+                        take(std::integral_constant<int, 8 * i + 4 * q>{}, c[0]);
+                        take(std::integral_constant<int, 8 * i + 4 * q + 1>{}, c[1]);
+                        take(std::integral_constant<int, 8 * i + 4 * q + 2>{}, c[2]);
+                        take(std::integral_constant<int, 8 * i + 4 * q + 3>{}, c[3]);
+    #pragma unroll
+                        for (int h = 0; h < 2; ++h)
+    #pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                y[h][r] = rbf(silu_fast(rbf(c[2 * h][r]))) * rbf(c[2 * h + 1][r]);
+                        uint32_t a0 = pack_bf2(y[0][0], y[0][1]), a1 = pack_bf2(y[0][2], y[0][3]);
+                        uint32_t b0 = pack_bf2(y[1][0], y[1][1]), b1 = pack_bf2(y[1][2], y[1][3]);
+                        swap16(a0, b0);
+                        swap16(a1, b1);
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{a0, a1, b0, b1}, crs, off0 + (uint32_t)(i * 16 * ldc * 2 + q * 64), 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                });
+            }
+        } else {
+            // a wave past N (the last tile column when N % 256 == 128): nothing to store, but its accumulators start the next tile too
+            static_for<0, 64>([&](auto mc) {
+                constexpr int R = 4 * decltype(mc)::value;
+                asm volatile("v_accvgpr_write_b32 a[%c0], 0\n\tv_accvgpr_write_b32 a[%c1], 0\n\tv_accvgpr_write_b32 a[%c2], 0\n\tv_accvgpr_write_b32 a[%c3], 0"
+                             :: "i"(R), "i"(R + 1), "i"(R + 2), "i"(R + 3));
+            });
+        }
+        asm volatile("s_nop 1" ::: "memory");                // accumulator writes (v_accvgpr_write) ahead of the next inline-asm MFMA
+        __builtin_amdgcn_sched_barrier(0);
+        if (tile + (int)gridDim.x >= ntiles) break;
+        tile += gridDim.x;
+        mC = mP; nC = nP;
+        F64_LOAD_BIAS(nC);                                   // behind this epilogue's stores, ahead of the next K tile's pieces
+        __builtin_amdgcn_sched_barrier(0);
+        extra = (inside ? NSTF : 0) + NB;
+        t = -1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the spare pieces issued after the last tile's K tile nt - 2 land in LDS: not after the workgroup is gone
+#undef F64_MFMA
+#undef F64_BIAS1
+#undef F64_LOAD_BIAS
+}
+
+// ------------------------------------------------------------------------------------------------
 // 128 x 128 x 64, 4 waves, register staged (general shapes)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2)
@@ -1121,7 +1457,23 @@ static bool flow_scratch_free() {
     return ok == 1;
 }
 
-extern "C" int licv_gemm_flow_available(void) { return flow_scratch_free() ? 1 : 0; }
+static bool flow64_scratch_free() {
+    static int ok = -1;
+    if (ok < 0) {
+        ok = 1;
+        const void* fns[6] = {(const void*)gemm_bf16_flow64_k<0>, (const void*)gemm_bf16_flow64_k<1>, (const void*)gemm_bf16_flow64_k<2>,
+                              (const void*)gemm_bf16_flow64_k<3>, (const void*)gemm_bf16_flow64_k<4>, (const void*)gemm_bf16_flow64_k<5>};
+        for (const void* f : fns) {
+            hipFuncAttributes at;
+            if (hipFuncGetAttributes(&at, f) != hipSuccess || at.localSizeBytes != 0) ok = 0;
+            (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 10 * Q64_UNIT);
+        }
+    }
+    return ok == 1;
+}
+
+// 1: the 8-wave flow kernel is usable; 2: the 4-wave flow64 kernel as well (bit 1)
+extern "C" int licv_gemm_flow_available(void) { return (flow_scratch_free() ? 1 : 0) | (flow64_scratch_free() ? 2 : 0); }
 
 extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
                               int64_t M, int64_t N, int64_t K, const licv_gemm_epilogue* e, void* stream) {
@@ -1190,7 +1542,22 @@ extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
                          (!e->bias_bf16 || ((uintptr_t)e->bias_bf16 & 3) == 0);
     const bool use256 = fk == 1 ? false : (fk == 0 ? big : can256);
     const bool flow_auto = g_flow_default != 0;
-    if (use256 && flow_ok && flow_scratch_free() && (fk == 20 || (fk == 0 && flow_auto))) {
+    // flow64: the same epilogue families without the residual one, waves of 128 columns, at least four 64-deep K tiles
+    const bool flow64_ok = flow_ok && N % 128 == 0 && K >= 256;
+    if (use256 && flow64_ok && (fk == 60 || (fk == 0 && flow_auto)) && flow64_scratch_free()) {
+        const dim3 grid(min(tiles_m * tiles_n, g_num_cus)), block(256);
+#define FLOW64(E) gemm_bf16_flow64_k<E><<<grid, block, 10 * Q64_UNIT, (hipStream_t)stream>>>( \
+            (const bf16_t*)A, lda, (const bf16_t*)W, ldw, (bf16_t*)C, (int)ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep.bias, pp_group)
+        if (e->residual)
+            gemm_bf16_flow64_k<5><<<grid, block, 10 * Q64_UNIT, (hipStream_t)stream>>>(
+                (const bf16_t*)A, lda, (const bf16_t*)W, ldw, (bf16_t*)C, (int)ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep.bias, pp_group,
+                (const bf16_t*)e->residual, (int)e->ld_res);
+        else if (e->swiglu) FLOW64(4); else if (e->act == 1) FLOW64(1); else if (e->act == 2) FLOW64(2); else if (e->act == 3) FLOW64(3); else FLOW64(0);
+#undef FLOW64
+        LICV_LAUNCH_CHECK();
+        return LICV_OK;
+    }
+    if (use256 && flow_ok && flow_scratch_free() && (fk == 20 || fk == 60 || (fk == 0 && flow_auto))) {
         const dim3 grid(min(tiles_m * tiles_n, g_num_cus)), block(512);
         const int ring = RING_STAGES * RING_STAGE_BYTES;
 #define FLOW(E) gemm_bf16_flow_k<E><<<grid, block, ring, (hipStream_t)stream>>>( \
@@ -1209,8 +1576,9 @@ extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
 #define LEAN(V) gemm_bf16_lean_k<0, V><<<grid, block, ring, (hipStream_t)stream>>>( \
             (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, pp_group)
         if (fk == 40) QUAD64(0); else if (fk == 41) QUAD64(1); else if (fk == 42) QUAD64(2);
-        else if (fk == 23) LEAN(1); else if (fk == 24) LEAN(2); else if (fk == 25) LEAN(9); else if (fk == 26) LEAN(8); else if (fk == 27) LEAN(7);
-        else LEAN(0);
+        else if (fk == 22) LEAN(0); else if (fk == 23) LEAN(1); else if (fk == 24) LEAN(2); else if (fk == 25) LEAN(9); else if (fk == 26) LEAN(8);
+        else if (fk == 27) LEAN(7);
+        else QUAD64(0);            // the staged-epilogue default (fp32 output / residual, row gate, tanh-gate scale, N % 64 != 0): +7 % over lean
 #undef QUAD64
 #undef LEAN
     } else {

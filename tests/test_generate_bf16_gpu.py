@@ -7,6 +7,10 @@ as a near-tie of the REFERENCE: tools/make_golden.py re-ran the reference's deco
 +1 bf16 ulp at random (two bf16 implementations differ by one ulp on a few logits; bf16 logits tie exactly on several rows) and
 stored the fraction of re-runs that reproduced the row.  Rows with stability 1.0 — no comparison of the search within two ulp
 — must match bit for bit, and at least 85 % of all rows must match outright.
+
+Fixtures g15 / g16 are the sharp form of the north-star's "token ids bit-exact": the same reference set-up on prompts chosen so
+that EVERY row has stability 1.0 (72 jittered re-runs of the reference reproduce all 96 rows per model); there the native
+engine must return every id of every row, no floor, no exemption.  g11 / g12 stay as the near-tie study.
 """
 import pytest
 import torch
@@ -39,12 +43,14 @@ def _run(w, icv, batch, z, side, stats):
     return torch.cat(same)
 
 
-def test_idefics_generate_ids_match_reference_bf16_decode(golden):
+@pytest.mark.parametrize("fixture", ["g11_generate_bf16", "g15_generate_bf16_stable"])
+def test_idefics_generate_ids_match_reference_bf16_decode(golden, fixture):
     from icv_src.icv_model.icv_intervention import LearnableICVInterventionLMM
     from lmm_icl_interface import IdeficsInterface
-    z = golden("g11_generate_bf16")
+    z = golden(fixture)
+    strict = "stable" in fixture
     arch = IDEFICS_TINY.with_(additional_vocab_size=0)
-    sd = synth_idefics_weights(arch, seed=121, dtype=torch.float32)
+    sd = synth_idefics_weights(arch, seed=int(z["weights_seed"]) if strict else 121, dtype=torch.float32)
     sd["model.embed_tokens.weight"] *= float(z["embed_scale"])
     sd["lm_head.weight"] *= float(z["head_scale"])
     iface = IdeficsInterface(state_dict=sd, arch=arch, device=DEV)
@@ -56,15 +62,19 @@ def test_idefics_generate_ids_match_reference_bf16_decode(golden):
         same.append(_run(w, icv, batch, z, side, stats))
     print("\n  " + "\n  ".join(f"{s}/{t}: {a}/{n} rows identical ({b} decided by more than bf16 noise)" for s, t, a, b, n in stats))
     frac = float(torch.cat(same).float().mean())
+    if strict:
+        assert frac == 1.0, f"{fixture}: {int(round((1 - frac) * 96))} of 96 rows differ from the reference's bf16 decode (every row is decided by more than bf16 noise)"
     assert frac >= 0.85, f"only {frac:.2f} of the 96 decoded rows equal the reference's bf16 decode"
 
 
-def test_idefics2_generate_ids_match_reference_bf16_autocast_decode(golden):
+@pytest.mark.parametrize("fixture", ["g12_generate_idefics2_bf16", "g16_generate_idefics2_bf16_stable"])
+def test_idefics2_generate_ids_match_reference_bf16_autocast_decode(golden, fixture):
     from icv_src.icv_model.icv_intervention import LearnableICVInterventionLMM
     from lmm_icl_interface import Idefics2Interface
-    z = golden("g12_generate_idefics2_bf16")
+    z = golden(fixture)
+    strict = "stable" in fixture
     arch = IDEFICS2_TINY
-    sd = synth_idefics2_weights(arch, seed=181, dtype=torch.float32)
+    sd = synth_idefics2_weights(arch, seed=int(z["weights_seed"]) if strict else 181, dtype=torch.float32)
     sd["model.text_model.embed_tokens.weight"] *= float(z["embed_scale"])
     sd["lm_head.weight"] *= float(z["head_scale"])
     for l in range(arch.num_layers):
@@ -78,4 +88,6 @@ def test_idefics2_generate_ids_match_reference_bf16_autocast_decode(golden):
         same.append(_run(w, icv, batch, z, side, stats))
     print("\n  " + "\n  ".join(f"{s}/{t}: {a}/{n} rows identical ({b} decided by more than bf16 noise)" for s, t, a, b, n in stats))
     frac = float(torch.cat(same).float().mean())
+    if strict:
+        assert frac == 1.0, f"{fixture}: {int(round((1 - frac) * 96))} of 96 rows differ from the reference's bf16 decode (every row is decided by more than bf16 noise)"
     assert frac >= 0.85, f"only {frac:.2f} of the 96 decoded rows equal the reference's bf16 decode"
