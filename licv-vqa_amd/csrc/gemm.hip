@@ -784,16 +784,20 @@ void gemm_bf16_flow64_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t*
     const lds_cptr ring = (lds_cptr)smem;
     auto wrap = [](int u) { return u >= 10 ? u - 10 : u; };
 
-    // ONE set of operand sources: those of the output tile whose K tiles are being ISSUED (mP, nP: its corner; per-lane byte offsets
-    // of the wave's 8 + 8 pieces).  It moves on to the workgroup's next output tile two K tiles before the multiplication does.
-    // piece (half, q): rows half * 128 + 32 * wave + 8 q + lane / 8 of the tile; LDS position lane % 8 holds source chunk
-    // (lane % 8) ^ (row % 8); rows past M / N re-read the last valid row (those outputs are never stored)
+    // ONE set of operand sources: those of the output tile whose K tiles are being ISSUED (its corner in two buffer descriptors,
+    // per-lane byte offsets of the wave's 8 + 8 pieces).  It moves on to the workgroup's next output tile two K tiles before the
+    // multiplication does.  piece (half, q): rows half * 128 + 32 * wave + 8 q + lane / 8 of the tile; LDS position lane % 8 holds
+    // source chunk (lane % 8) ^ (row % 8); rows past M / N re-read the last valid row (those outputs are never stored)
     int offA[2][4], offW[2][4];
     int mP = 0, nP = 0;
+    auto rA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0xFFFFFFFF, 0x00020000);
+    auto rW = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, 0xFFFFFFFF, 0x00020000);
     auto set_sources = [&](int t) {
         int tm, tn;
         tile_coords(t, tiles_m, tiles_n, tm, tn, group);
         mP = tm * 256; nP = tn * 256;
+        rA = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (int64_t)mP * lda), 0, 0xFFFFFFFF, 0x00020000);
+        rW = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (int64_t)nP * ldw), 0, 0xFFFFFFFF, 0x00020000);
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -804,20 +808,29 @@ void gemm_bf16_flow64_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t*
                 offW[h][q] = min(row, N - 1 - nP) * (int)ldw * 2 + chunk * 16;
             }
     };
-    // one 1-KiB piece: IS_A: A units (else W units), p = 4 * half + q, kb = byte offset of the K tile in a row, u0 = ring slot of the
-    // first of the two units
-    auto piece = [&](auto isa_c, auto p_c, int kb, int u0) {
-        constexpr bool IS_A = decltype(isa_c)::value;
-        constexpr int p = decltype(p_c)::value, h = p >> 2, q = p & 3;
-        const int slot = wrap(u0 + h);
-        const lds_ptr dst = ring_w + slot * Q64_UNIT + wave * 4096 + q * 1024;
-        if (IS_A) {
-            const auto r = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (int64_t)mP * lda), 0, 0xFFFFFFFF, 0x00020000);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 16, offA[h][q], kb, 0, 0);
-        } else {
-            const auto r = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (int64_t)nP * ldw), 0, 0xFFFFFFFF, 0x00020000);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 16, offW[h][q], kb, 0, 0);
-        }
+    // The ring as five PAIRS of units (32 KiB each: W rows 0-127 | W rows 128-255, or the two A units): K tile g has its W pair at
+    // position 2 g mod 5 and its A pair at 2 g + 1 mod 5.  A pair is filled by the wave's 8 pieces at consecutive KiB of its own 4 KiB
+    // of each unit: the LDS destination (M0) starts at pair + 4096 wave and steps by 1 KiB, + 13 KiB from unit 0 to unit 1.
+    // (s_add_u32 writes SCC: declared, or the compiler keeps a loop condition in it across the statement.)
+    // A piece is two instructions, as the vendor library issues it: the load, then the M0 step for the NEXT piece (so no wait state
+    // sits between an M0 write and the load that uses it); M0 is set one MFMA before a pair's first piece.  The compiler has no LDS-DMA
+    // of its own in this kernel, so nothing else writes M0 between these statements.
+    const int lds_base = __builtin_amdgcn_readfirstlane((int)(uintptr_t)ring_w) + wave * 4096;
+    auto nx = [](int pair) { const int n = pair + 32768; return n >= 163840 ? n - 163840 : n; };
+#define F64_M0(ADDR) asm volatile("s_mov_b32 m0, %0" :: "s"(ADDR) : "memory")
+#define F64_PIECE(VOFF, RSRC, KB, STEP) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds\n\ts_add_u32 m0, m0, %3" :: "v"(VOFF), "s"(RSRC), "s"(KB), "i"(STEP) : "memory", "scc")
+    // the p-th piece (0-7) of the pair being filled: W or A rows, this K tile's byte offset in a row
+    auto piece_w = [&](auto p_c, int kb) {
+        constexpr int p = decltype(p_c)::value;
+        const int vo = offW[p >> 2][p & 3];                  // (locals: an asm operand alone does not capture in a generic lambda)
+        const auto r = rW;
+        F64_PIECE(vo, r, kb, (p == 3 ? 13312 : 1024));
+    };
+    auto piece_a = [&](auto p_c, int kb) {
+        constexpr int p = decltype(p_c)::value;
+        const int vo = offA[p >> 2][p & 3];
+        const auto r = rA;
+        F64_PIECE(vo, r, kb, (p == 3 ? 13312 : 1024));
     };
 
     // The 256 accumulators are NOT C++ values: accumulator (i, j) is a[4 (8 i + j) : 4 (8 i + j) + 3], named literally in the MFMA
@@ -847,36 +860,44 @@ void gemm_bf16_flow64_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t*
     int mC = mP, nC = nP;                                    // its corner (the epilogue's addresses)
 
     F64_LOAD_BIAS(nC);                                       // older than every piece: retired by the first counted wait
-    // prologue: K tiles 0 and 1 of the first output tile (units 0-7)
-    static_for<0, 8>([&](auto pc) { piece(std::false_type{}, pc, 0, 0); });
-    static_for<0, 8>([&](auto pc) { piece(std::true_type{}, pc, 0, 2); });
-    static_for<0, 8>([&](auto pc) { piece(std::false_type{}, pc, 128, 4); });
-    static_for<0, 8>([&](auto pc) { piece(std::true_type{}, pc, 128, 6); });
+    // prologue: K tiles 0 and 1 of the first output tile (pairs 0-3)
+    F64_M0(lds_base);
+    asm volatile("s_nop 0" ::: "memory");
+    static_for<0, 8>([&](auto pc) { piece_w(pc, 0); });
+    F64_M0(lds_base + 32768);
+    asm volatile("s_nop 0" ::: "memory");
+    static_for<0, 8>([&](auto pc) { piece_a(pc, 0); });
+    F64_M0(lds_base + 65536);
+    asm volatile("s_nop 0" ::: "memory");
+    static_for<0, 8>([&](auto pc) { piece_w(pc, 128); });
+    F64_M0(lds_base + 98304);
+    asm volatile("s_nop 0" ::: "memory");
+    static_for<0, 8>([&](auto pc) { piece_a(pc, 128); });
     asm volatile("s_waitcnt vmcnt(16)" ::: "memory");        // my pieces of K tile 0 have landed
     __builtin_amdgcn_s_barrier();                            // K tile 0 published
+    const int rdW0 = fo0 + wn * Q64_UNIT, rdW1 = fo1 + wn * Q64_UNIT;      // fragment-read offsets inside a pair, both K halves
+    const int rdA0 = fo0 + wm * Q64_UNIT, rdA1 = fo1 + wm * Q64_UNIT;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) fw0[j] = *(lds_fptr)(ring + wn * Q64_UNIT + fo0 + j * 2048);
+    for (int j = 0; j < 8; ++j) fw0[j] = *(lds_fptr)(ring + rdW0 + j * 2048);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) fa0[i] = *(lds_fptr)(ring + (2 + wm) * Q64_UNIT + fo0 + i * 2048);
+    for (int i = 0; i < 8; ++i) fa0[i] = *(lds_fptr)(ring + 32768 + rdA0 + i * 2048);
 
-    int ub = 0;                                              // ring slot of unit 4 g (W rows 0-127 of the K tile being multiplied)
+    int pW = 0;                                              // ring position (bytes) of the W pair of the K tile being multiplied
     int extra = 0;                                           // what this wave's last epilogue left queued: its stores (NSTF, if it was inside N) + the NB bias loads
-    // One body for every K tile of the workgroup's stream (g-th of the stream, t-th of its output tile): nothing in it depends on
-    // where in a tile it is except (a) which tile the pieces it issues belong to — a change of DATA (set_sources at t == nt - 2), not
-    // of code — and (b) the one counted wait that has the previous epilogue's stores in its queue (t == 0).  After the last tile's
-    // K tile nt - 2 there is nothing left to fetch: the same pieces are issued once more (K tiles 0 and 1 of the last tile again, into
-    // ring slots that are free by the protocol and never read), so every count stays what it is in the steady state.
-    for (int t = 0;; ++t) {
-        if (t == nt - 2 && tile + (int)gridDim.x < ntiles) set_sources(tile + gridDim.x);
-        const int kb = (t + 2 >= nt ? t + 2 - nt : t + 2) * 128;
-        const int ubn = wrap(ub + 4);                        // slot of unit 4 (g + 1)
-        const int u8 = wrap(ub + 8);                         // slot of unit 4 (g + 2): its W units (free since the barrier of K tile g - 1)
-        // ---- step 0: MFMAs on set 0; reads of (g, second half) into set 1; pieces of the W units of K tile g + 2
+    // One K tile of the workgroup's stream (g-th of the stream).  Nothing in it depends on where in an output tile it is except the
+    // DATA of the pieces it issues (set_sources two K tiles before a seam; kb) and, for a tile's first K tile (FIRST), the counted wait
+    // that has the previous epilogue's stores and bias loads in its queue.  After the last tile's K tile nt - 2 there is nothing left
+    // to fetch: the same pieces are issued once more (K tiles 0 and 1 of the last tile again, into pairs that are free by the
+    // protocol and never read), so every count stays what it is in the steady state.
+    auto ktile = [&](auto first_c, int kb) {
+        constexpr bool FIRST = decltype(first_c)::value;
+        const int pA = nx(pW), pW1 = nx(pA), pA1 = nx(pW1), pW2 = nx(pA1);     // pairs of g (A), g + 1 (W, A), g + 2 (W; its A pair is pW)
+        // ---- step 0: MFMAs on set 0; reads of (g, second half) into set 1; pieces of the W pair of K tile g + 2
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         {
-            const lds_cptr pw = ring + wrap(ub + wn) * Q64_UNIT + fo1;
-            const lds_cptr pa = ring + wrap(ub + 2 + wm) * Q64_UNIT + fo1;
+            const lds_cptr pw = ring + pW + rdW1;
+            const lds_cptr pa = ring + pA + rdA1;
             static_for<0, 64>([&](auto mc) {
                 constexpr int m = decltype(mc)::value;
                 constexpr int i = m >> 3, j = m & 7;
@@ -884,19 +905,18 @@ void gemm_bf16_flow64_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t*
                     if constexpr (m < 8) fw1[m] = *(lds_fptr)(pw + m * 2048);
                     else fa1[m - 8] = *(lds_fptr)(pa + (m - 8) * 2048);
                 }
-                if constexpr (m >= 16 && m < 40 && (m - 16) % 3 == 0)
-                    piece(std::false_type{}, std::integral_constant<int, (m - 16) / 3>{}, kb, u8);
+                if constexpr (m == 15) F64_M0(lds_base + pW2);
+                if constexpr (m >= 16 && m < 40 && (m - 16) % 3 == 0) piece_w(std::integral_constant<int, (m - 16) / 3>{}, kb);
                 F64_MFMA(m, fw0[j], fa0[i]);
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
-        // ---- step 1: MFMAs on set 1; rendezvous; reads of (g + 1, first half) into set 0; pieces of the A units of K tile g + 2
+        // ---- step 1: MFMAs on set 1; rendezvous; reads of (g + 1, first half) into set 0; pieces of the A pair of K tile g + 2
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         {
-            const lds_cptr pw = ring + wrap(ubn + wn) * Q64_UNIT + fo0;
-            const lds_cptr pa = ring + wrap(ubn + 2 + wm) * Q64_UNIT + fo0;
-            const int u10 = ub;                              // slots of units 4 g, 4 g + 1 = units 4 (g + 2) + 2, + 3: freed by this step's barrier
+            const lds_cptr pw = ring + pW1 + rdW0;
+            const lds_cptr pa = ring + pA1 + rdA0;
             static_for<0, 64>([&](auto mc) {
                 constexpr int m = decltype(mc)::value;
                 constexpr int i = m >> 3, j = m & 7;
@@ -905,14 +925,15 @@ void gemm_bf16_flow64_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t*
                     if constexpr (r < 8) fw0[r] = *(lds_fptr)(pw + r * 2048);
                     else fa0[r - 8] = *(lds_fptr)(pa + (r - 8) * 2048);
                 }
-                if constexpr (m >= 24 && m < 48 && (m - 24) % 3 == 0)
-                    piece(std::true_type{}, std::integral_constant<int, (m - 24) / 3>{}, kb, u10);
+                if constexpr (m == 23) F64_M0(lds_base + pW);        // the pair of K tile g's W units, freed by this step's barrier
+                if constexpr (m >= 24 && m < 48 && (m - 24) % 3 == 0) piece_a(std::integral_constant<int, (m - 24) / 3>{}, kb);
                 F64_MFMA(m, fw1[j], fa1[i]);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (m == 7) {
-                    // in flight, oldest first: W(g+1), A(g+1), [the previous epilogue's stores,] W(g+2): retire K tile g + 1
-                    if (t == 0 && extra != 0) {
-                        if (extra == NB) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(8 + NB) : "memory");
+                    // in flight, oldest first: W(g+1), A(g+1), [the previous epilogue's stores and bias loads,] W(g+2): retire K tile g + 1
+                    if constexpr (FIRST) {
+                        if (extra == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                        else if (extra == NB) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(8 + NB) : "memory");
                         else asm volatile("s_waitcnt vmcnt(%0)" :: "i"(8 + NSTF + NB) : "memory");
                     } else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
@@ -920,8 +941,14 @@ void gemm_bf16_flow64_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t*
                 }
             });
         }
-        ub = ubn;
-        if (t + 1 < nt) continue;
+        pW = pW1;
+    };
+    for (;;) {
+        ktile(std::true_type{}, 256);
+        for (int t = 1; t + 2 < nt; ++t) ktile(std::false_type{}, (t + 2) * 128);
+        if (tile + (int)gridDim.x < ntiles) set_sources(tile + gridDim.x);
+        ktile(std::false_type{}, 0);
+        ktile(std::false_type{}, 128);
 
         // ==== the output tile is complete: register-direct epilogue of tile (mC, nC); the next tile's K tiles 0 and 1 are in flight
         // or landed meanwhile, its first fragments are being read into set 0.  Every accumulator is cleared as it is read.
@@ -1049,10 +1076,11 @@ void gemm_bf16_flow64_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t*
         F64_LOAD_BIAS(nC);                                   // behind this epilogue's stores, ahead of the next K tile's pieces
         __builtin_amdgcn_sched_barrier(0);
         extra = (inside ? NSTF : 0) + NB;
-        t = -1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the spare pieces issued after the last tile's K tile nt - 2 land in LDS: not after the workgroup is gone
 #undef F64_MFMA
+#undef F64_M0
+#undef F64_PIECE
 #undef F64_BIAS1
 #undef F64_LOAD_BIAS
 }
