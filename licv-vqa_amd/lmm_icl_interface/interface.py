@@ -105,30 +105,35 @@ class IdeficsInterface(LMMInterface):
         self.image_token_id = self._resolve_image_token_id(self.tokenizer, arch)
 
     @staticmethod
-    def _resolve_image_token_id(tokenizer, arch) -> int:
-        """`<image>` id: the tokenizer's, when it really knows the token (not None, not its unk id, inside the embedding
-        table); otherwise the additional-vocabulary slot the released checkpoints use.  A silently wrong id would give an
-        all-zero image_attention_mask, i.e. no cross-attention at all, without any error."""
-        n_embed = arch.vocab_size + getattr(arch, "additional_vocab_size", 0)
-        fallback = arch.vocab_size + (1 if getattr(arch, "additional_vocab_size", 0) > 1 else 0)
+    def _resolve_image_token_id(tokenizer, arch):
+        """`<image>` id: the tokenizer's, when it really knows the token (not None, not its unk id); otherwise the
+        additional-vocabulary slot the released checkpoints use.  An id outside the embedding table coming from a tokenizer
+        is an error (tokenizer and model do not belong together); a model without additional vocabulary and without a
+        tokenizer simply has no `<image>` token: None, and building an image_attention_mask from input_ids then raises.
+        A silently wrong id would give an all-zero mask, i.e. no cross-attention at all, without any error."""
+        extra = getattr(arch, "additional_vocab_size", 0)
+        n_embed = arch.vocab_size + extra
+        fallback = arch.vocab_size + (1 if extra > 1 else 0) if extra > 0 else None
         conv = getattr(tokenizer, "convert_tokens_to_ids", None)
         if conv is None:
-            tid = fallback
-        else:
-            tid = conv("<image>")
-            unk = getattr(tokenizer, "unk_token_id", None)
-            if tid is None or (unk is not None and tid == unk) or not isinstance(tid, int):
-                tid = fallback
-        if not 0 <= int(tid) < max(n_embed, 1):
+            return fallback
+        tid = conv("<image>")
+        unk = getattr(tokenizer, "unk_token_id", None)
+        if tid is None or (unk is not None and tid == unk) or not isinstance(tid, int):
+            return fallback
+        if not 0 <= tid < max(n_embed, 1):
             raise ValueError(f"`<image>` token id {tid} is outside the embedding table of {n_embed} rows: "
                              "the tokenizer and the model configuration do not belong together")
-        return int(tid)
+        return tid
 
     def _image_mask(self, input_ids, pixel_values, image_attention_mask):
         """image_attention_mask as processor.prepare_input builds it (hf:idefics/processing_idefics.py:89-133) when the caller
         did not pass one: from input_ids, on the device (licv.frontend, csrc/frontend.hip)."""
         if image_attention_mask is not None:
             return image_attention_mask.to(self._device)
+        if self.image_token_id is None:
+            raise ValueError("no image_attention_mask was passed and this model has no `<image>` token to build one from "
+                             "(no additional vocabulary, no tokenizer that knows the token)")
         from licv import frontend
         return frontend.idefics_image_attention_mask(input_ids.to(self._device), self.image_token_id,
                                                      getattr(self.tokenizer, "eos_token_id", self.arch.eos_token_id), pixel_values.shape[1])

@@ -12,6 +12,8 @@ accumulation, head_dim 80 at 257 keys, the 32002-wide head, S = 800 tiling or th
   W3  BASELINE configs[0], the plumbing run: Idefics-9B at FULL depth, bs = 1, 1-shot (teacher S = 56 with 2 images, student
       = the bare query with 1 image), driven through icv_src.icv_module.VQAICVModule.forward; teacher logits, hooked student
       logits and the KL loss against the oracle on the host cores (wall times printed).
+  W4  BASELINE configs[1], the headline: Idefics-9B at FULL depth, one 32-shot question (S = 800, 33 images, hooks on 32 layers)
+      against the oracle in bf16 and fp32; and, split-K off, that question inside the batch of 8 == alone, bit for bit.
 
 Bar: the engine may be no less accurate than the reference's own bf16 path, measured against the fp32 oracle:
   (ii)  max|hip - f32_gold| <= 1.5 * max|bf16_gold - f32_gold| + 1e-3 * scale            (as tests/test_engine_gpu.py);
@@ -233,3 +235,67 @@ def test_w3_configs0_idefics9b_full_depth_one_shot_through_icv_module():
     print(f"  W3 KL(teacher || hooked student): native {kl:.5f}  oracle bf16 {k16:.5f}  oracle fp32 {k32:.5f}")
     assert abs(kl - k32) <= 1.5 * abs(k16 - k32) + 0.05 * abs(k32) + 1e-3
     assert set(loss_dict) == {"kl_loss", "loss"}
+
+
+def test_w4_configs1_idefics9b_full_depth_32shot_question_vs_oracle():
+    """BASELINE.json configs[1] pinned to the oracle: Idefics-9B at FULL depth (32 ViT layers, 6 perceiver blocks, 32 decoder + 8
+    gated cross-attention layers), ONE 32-shot question (S = 800, 33 images), hooks on all 32 layers — the HIP engine against the
+    CPU oracle in bf16 and in fp32, same three-part bar as W1-W3, wall times printed.  Then the step from B = 1 to the headline's
+    B = 8: with the split-K path off (the one dispatch decision that depends on the row count), the question's logits inside the
+    headline batch of 8 are bit for bit those of the question alone — so the bench configuration itself sits on the oracle."""
+    from licv import ops
+    from licv.idefics_engine import IdeficsEngine, IdeficsWeights
+    torch.set_num_threads(max(torch.get_num_threads(), 8))
+    arch = IDEFICS_9B
+    t0 = time.perf_counter()
+    sd = trained_like_(synth_idefics_weights(arch, seed=426, dtype=torch.bfloat16, device=DEV), arch.num_layers)
+    eng = IdeficsEngine(IdeficsWeights(sd, arch, DEV))
+    batch8 = synth_vqa_batch(arch, 8, 800, 33, seed=426, min_len=720, dtype=torch.bfloat16)
+    one = {k: v[:1].clone() for k, v in batch8.items()}
+    layers = list(range(arch.num_layers))
+    icv = torch.randn(1, arch.num_layers, arch.hidden_size, generator=torch.Generator().manual_seed(431)) * 0.05
+    to = lambda d: {k: v.to(DEV) for k, v in d.items()}
+    t1 = time.perf_counter()
+    lg = eng.forward(**to(one), icv=icv.to(DEV), hook_layers=layers)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    # B = 1 -> B = 8, split-K off for both runs
+    ops.set_splitk(False)
+    try:
+        alone = eng.forward(**to(one), icv=icv.to(DEV), hook_layers=layers)
+        inb = eng.forward(**to(batch8), icv=icv.to(DEV), hook_layers=layers)[:1]
+        torch.cuda.synchronize()
+        assert torch.equal(alone, inb), "row 0 of the headline batch differs from the question run alone (split-K off)"
+    finally:
+        ops.set_splitk(True)
+    d = (lg.float() - alone.float())
+    print(f"\n  W4 split-K on vs off, one question: relative L2 {float(d.norm() / alone.float().norm()):.2e}")
+    del inb
+    sdc = _cpu(sd, torch.bfloat16)
+    del sd, eng
+    torch.cuda.empty_cache()
+    t3 = time.perf_counter()
+    gold, tm = {}, {}
+    for name, dt in (("bf16", torch.bfloat16), ("f32", torch.float32)):
+        s_ = sdc if dt == torch.bfloat16 else {k: v.float() for k, v in sdc.items()}
+        kw = {k: (v.to(dt) if v.is_floating_point() else v) for k, v in one.items()}
+        ta = time.perf_counter()
+        with torch.no_grad():
+            gold[name] = R.forward(s_, arch, **kw, icv=icv, hook_layers=layers).float()
+        tm[name] = time.perf_counter() - ta
+        del s_
+    print(f"  W4 weights {t1 - t0:.1f}s, native forward (cold) {t2 - t1:.2f}s, CPU oracle ({torch.get_num_threads()} threads): "
+          f"bf16 {tm['bf16']:.1f}s, fp32 {tm['f32']:.1f}s per question")
+    rep = []
+    valid = one["attention_mask"][0].bool()
+    _check(lg[0][valid.to(lg.device)], gold["bf16"][0][valid], gold["f32"][0][valid], "logits, full depth, 32-shot question (real positions)", rep)
+    _check(alone[0][valid.to(lg.device)], gold["bf16"][0][valid], gold["f32"][0][valid], "the same, split-K off (= row 0 of the batch of 8, bit for bit)", rep)
+    print("  W4 " + "\n  W4 ".join(rep))
+    # argmax agrees with the bf16 oracle wherever the oracle's own top-2 margin exceeds its bf16-vs-fp32 spread
+    g16 = gold["bf16"][0]
+    top2 = g16.topk(2, dim=-1).values
+    spread = float((g16 - gold["f32"][0]).abs().max())
+    sure = ((top2[..., 0] - top2[..., 1]) > 2 * spread) & valid
+    if int(sure.sum()) > 0:
+        assert torch.equal(lg[0].float().cpu().argmax(-1)[sure], g16.argmax(-1)[sure])
+    print(f"  W4 positions whose argmax is decided by more than the reference's own bf16 noise: {int(sure.sum())} of {int(valid.sum())}")

@@ -72,3 +72,4 @@ def test_image_token_id_resolution():
     bad = types.SimpleNamespace(convert_tokens_to_ids=lambda t: 10 ** 6, unk_token_id=0)  # outside the embedding table
     with pytest.raises(ValueError):
         res(bad, arch)
+    assert res(types.SimpleNamespace(), arch.with_(additional_vocab_size=0)) is None                  # no such token at all
