@@ -1086,6 +1086,175 @@ void gemm_bf16_flow64_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t*
 }
 
 // ------------------------------------------------------------------------------------------------
+// "mid" kernel (round 3): 128 x 128 tiles for the row counts between the weight-streaming kernel (M <= 32) and the 256-tile
+// kernels (M >= 512) — the 32-token student of training, the prefill of hooked generate (M = B S = 256), the vision tower on a
+// handful of images (M = 8 x 257) — and the producer of their split-K partials.  It is the quad64 main loop at half scale:
+//   * 4 waves as 2 x 2, 64 x 64 per wave (16 accumulators), 64-deep K tiles;
+//   * LDS = a ring of five PAIRS of 8 KiB units (a unit = 64 rows x 64 K of one operand, 128-byte rows, 16-byte chunk c of row r
+//     at position c ^ (r & 7)): K tile g has its W pair at position 2 g mod 5, its A pair at 2 g + 1 mod 5; 80 KiB, so TWO
+//     workgroups share a CU and cover each other's waits;
+//   * LDS-DMA pieces of 8 rows x 128 B (whole cache lines), issued as `load; M0 step`, four per wave and pair, two K tiles ahead;
+//     one barrier per K tile, counted vmcnt;
+//   * staged epilogue (every epilogue family), or — SPLITK — fp32 partial tiles into [split][M_pad][N_pad] for
+//     skinny_finalize_k (row-major, 4 columns per thread).
+// Against the register-staged 128-tile kernel it replaces for K % 64 == 0: no VGPR round trip and no ds_write for the operands,
+// two K tiles in flight instead of one, half the barriers.  Same K order and rounding points: bit-identical.
+// ------------------------------------------------------------------------------------------------
+#define MID_PAIR 16384
+#define MID_LDS (5 * MID_PAIR)
+template <int SPLITK>
+__global__ __launch_bounds__(256, 2)
+void gemm_bf16_mid_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw,
+                     void* __restrict__ C, int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n, GemmEpi ep, int per) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // 5 pairs x 16 KiB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int tm, tn;
+    tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * 128, n0 = tn * 128;
+    const int kt0 = SPLITK ? (int)blockIdx.y * per : 0;                       // first 64-deep K tile of this workgroup
+    const int nt = SPLITK ? min(per, K / 64 - kt0) : K / 64;                  // >= 2, host-guaranteed
+    typedef __attribute__((address_space(3))) char* lds_ptr;
+    typedef const __attribute__((address_space(3))) char* lds_cptr;
+    typedef const __attribute__((address_space(3))) bf16x8* lds_fptr;
+    const lds_ptr ring_w = (lds_ptr)smem;
+    const lds_cptr ring = (lds_cptr)smem;
+
+    // piece q (0-3) of a pair: rows 32 wave + 8 q + lane / 8 of the operand's 128; LDS position lane % 8 holds source chunk
+    // (lane % 8) ^ (row % 8); rows past M / N re-read the last valid row (those outputs are never stored)
+    const auto rA = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (int64_t)m0 * lda + (int64_t)kt0 * 64), 0, 0xFFFFFFFF, 0x00020000);
+    const auto rW = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (int64_t)n0 * ldw + (int64_t)kt0 * 64), 0, 0xFFFFFFFF, 0x00020000);
+    int offA[4], offW[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = wave * 32 + q * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ (row & 7);
+        offA[q] = min(row, M - 1 - m0) * (int)lda * 2 + chunk * 16;
+        offW[q] = min(row, N - 1 - n0) * (int)ldw * 2 + chunk * 16;
+    }
+    const int lds_base = __builtin_amdgcn_readfirstlane((int)(uintptr_t)ring_w) + wave * 4096;
+    auto nx = [](int pair) { const int n = pair + MID_PAIR; return n >= MID_LDS ? n - MID_LDS : n; };
+#define MID_M0(ADDR) asm volatile("s_mov_b32 m0, %0" :: "s"(ADDR) : "memory")
+#define MID_PIECE(VOFF, RSRC, KB) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds\n\ts_add_u32 m0, m0, 0x400" :: "v"(VOFF), "s"(RSRC), "s"(KB) : "memory", "scc")
+
+    floatx4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    // fragment (row i * 16 + lane % 16 of the unit, K chunk kk * 4 + lane / 16): the swizzle term is (lane % 16) % 8 = lane % 8 for every i
+    const int fo0 = (lane & 15) * 128 + ((((lane >> 4)) ^ (lane & 7)) << 4);
+    const int fo1 = (lane & 15) * 128 + ((((lane >> 4) + 4) ^ (lane & 7)) << 4);
+    const int rdW0 = fo0 + wn * 8192, rdW1 = fo1 + wn * 8192, rdA0 = fo0 + wm * 8192, rdA1 = fo1 + wm * 8192;
+    bf16x8 fa0[4], fw0[4], fa1[4], fw1[4];
+
+    // prologue: K tiles 0 and 1 (pairs 0-3)
+    MID_M0(lds_base);
+    asm volatile("s_nop 0" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < 4; ++q) MID_PIECE(offW[q], rW, 0);
+    MID_M0(lds_base + MID_PAIR);
+    asm volatile("s_nop 0" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < 4; ++q) MID_PIECE(offA[q], rA, 0);
+    MID_M0(lds_base + 2 * MID_PAIR);
+    asm volatile("s_nop 0" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < 4; ++q) MID_PIECE(offW[q], rW, 128);
+    MID_M0(lds_base + 3 * MID_PAIR);
+    asm volatile("s_nop 0" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < 4; ++q) MID_PIECE(offA[q], rA, 128);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");         // my pieces of K tile 0 have landed
+    __builtin_amdgcn_s_barrier();                            // K tile 0 published
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fw0[j] = *(lds_fptr)(ring + rdW0 + j * 2048);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa0[i] = *(lds_fptr)(ring + MID_PAIR + rdA0 + i * 2048);
+
+    int pW = 0;                                              // ring position of the W pair of the K tile being multiplied
+    // One K tile.  STEADY (t + 2 < nt): pieces of K tile t + 2 and reads of K tile t + 1 exist: one straight instruction stream.
+    auto ktile = [&](int t, auto steady_c) {
+        constexpr bool STEADY = decltype(steady_c)::value;
+        const bool more1 = STEADY || t + 1 < nt, more2 = STEADY || t + 2 < nt;
+        const int kb = (t + 2) * 128;
+        const int pA = nx(pW), pW1 = nx(pA), pA1 = nx(pW1), pW2 = nx(pA1);     // pairs of t (A), t + 1 (W, A), t + 2 (W; its A pair is pW)
+        // ---- step 0: MFMAs on set 0; reads of (t, second half) into set 1; pieces of the W pair of K tile t + 2
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const lds_cptr pw = ring + pW + rdW1;
+            const lds_cptr pa = ring + pA + rdA1;
+            if (more2) MID_M0(lds_base + pW2);
+            static_for<0, 16>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                constexpr int i = m >> 2, j = m & 3;
+                if constexpr (m < 8) {
+                    if constexpr (m < 4) fw1[m] = *(lds_fptr)(pw + m * 2048);
+                    else fa1[m - 4] = *(lds_fptr)(pa + (m - 4) * 2048);
+                }
+                if constexpr (m >= 8 && m < 16 && (m & 1) == 0) {
+                    if (more2) MID_PIECE(offW[(m - 8) >> 1], rW, kb);
+                }
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw0[j], fa0[i], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+        // ---- step 1: MFMAs on set 1; rendezvous; reads of (t + 1, first half) into set 0; pieces of the A pair of K tile t + 2
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const lds_cptr pw = ring + pW1 + rdW0;
+            const lds_cptr pa = ring + pA1 + rdA0;
+            static_for<0, 16>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                constexpr int i = m >> 2, j = m & 3;
+                if constexpr (m >= 2 && m < 10) {
+                    constexpr int r = m - 2;
+                    if (more1) {
+                        if constexpr (r < 4) fw0[r] = *(lds_fptr)(pw + r * 2048);
+                        else fa0[r - 4] = *(lds_fptr)(pa + (r - 4) * 2048);
+                    }
+                }
+                if constexpr (m == 7) { if (more2) MID_M0(lds_base + pW); }      // the pair of K tile t's W units, freed by this step's barrier
+                if constexpr (m >= 8 && m < 16 && (m & 1) == 0) {
+                    if (more2) MID_PIECE(offA[(m - 8) >> 1], rA, kb);
+                }
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw1[j], fa1[i], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (m == 1) {
+                    // in flight, oldest first: W(t+1), A(t+1), W(t+2) [if it exists]: retire K tile t + 1
+                    if (more2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+        }
+        pW = pW1;
+    };
+    int t = 0;
+    for (; t + 2 < nt; ++t) ktile(t, std::true_type{});
+    for (; t < nt; ++t) ktile(t, std::false_type{});
+#undef MID_M0
+#undef MID_PIECE
+    if (SPLITK) {                                            // fp32 partial tile -> this split's workspace slice ([split][M_pad][N_pad], pads of 128)
+        const int64_t np = (int64_t)tiles_n * 128;
+        float* slice = reinterpret_cast<float*>(C) + (int64_t)blockIdx.y * ((int64_t)tiles_m * 128) * np;
+        const int rl = m0 + wm * 64 + (lane & 15), c0 = n0 + wn * 64 + (lane >> 4) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<floatx4*>(slice + (int64_t)(rl + i * 16) * np + c0 + j * 16) = acc[i][j];
+        return;
+    }
+    __syncthreads();                           // every wave is done with the ring before it becomes the output image
+    epilogue_staged<128, 128, 4, 4, 4>(acc, ep, C, ldc, M, N, m0, n0, wm * 64, wn * 64, wave, lane, smem);
+}
+
+// ------------------------------------------------------------------------------------------------
 // 128 x 128 x 64, 4 waves, register staged (general shapes)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2)
@@ -1264,7 +1433,7 @@ void gemm_bf16_splitk_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t*
 //     eight loads in flight per wave before the first is consumed;
 //   * the few activation rows of the K range are staged once per workgroup in LDS (row stride + 16 B: conflict-free
 //     ds_read_b128 fragments), zero-padded to 16 / 32 rows;
-//   * fp32 partials go to the caller's workspace as [split][32 rows][N padded to 128] and gemm_splitk_finalize_k adds them
+//   * fp32 partials go to the caller's workspace as [split][32 rows][N padded to 128] and skinny_finalize_k adds them
 //     in order and runs the usual epilogue (deterministic, no atomics).
 // ------------------------------------------------------------------------------------------------
 #define SKINNY_KR_MAX 1024          // K elements per split: 32 rows x 1024 x 2 B + padding = 66 KB of LDS
@@ -1304,6 +1473,7 @@ void gemm_bf16_skinny_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t*
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int k = kbase + (s + u) * 32 + fq * 8;
+            // (non-temporal loads measured here: 33 -> 40 us at (24, 12288, 4096) replayed back to back, generate unchanged: not taken)
             wf[u] = k < K ? *reinterpret_cast<const u32x4*>(wp + (s + u) * 32) : u32x4{0u, 0u, 0u, 0u};
         }
 #pragma unroll
@@ -1338,17 +1508,19 @@ void gemm_bf16_skinny_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t*
 // activation; SwiGLU pairing; row gate; gate scale; residual in the stream dtype) — the general finalize kernel walks
 // 128 x 128 tiles through an LDS image, 17 us per call for 24 rows; this one is a few microseconds.
 __global__ __launch_bounds__(256)
-void skinny_finalize_k(const float* __restrict__ ws, void* __restrict__ C, int64_t ldc, int M, int N, int64_t np, int splits, GemmEpi ep) {
+void skinny_finalize_k(const float* __restrict__ ws, void* __restrict__ C, int64_t ldc, int M, int N, int64_t np, int splits, GemmEpi ep,
+                       int slice_rows) {              // rows a split's slice holds: 32 (weight-streaming kernel) or M padded to 128 (128-tile route)
     const int n_out = ep.swiglu ? N >> 1 : N;
     const int groups = (n_out + 3) >> 2;
     const int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (item >= (int64_t)M * groups) return;
     const int m = (int)(item / groups), c = (int)(item - (int64_t)m * groups) * 4;
     const int nv = min(4, n_out - c);
-    const int64_t slice = 32 * np;
+    const int64_t slice = (int64_t)slice_rows * np;
     auto sum4 = [&](int col) -> floatx4 {
         const float* p = ws + (int64_t)m * np + col;
         floatx4 v = *reinterpret_cast<const floatx4*>(p);
+#pragma unroll 4
         for (int sp = 1; sp < splits; ++sp) v += *reinterpret_cast<const floatx4*>(p + sp * slice);         // fixed order
         return v;
     };
@@ -1395,33 +1567,6 @@ void skinny_finalize_k(const float* __restrict__ ws, void* __restrict__ C, int64
     }
 }
 
-__global__ __launch_bounds__(256, 2)
-void gemm_splitk_finalize_k(const float* __restrict__ ws, void* __restrict__ C, int64_t ldc, int M, int N, int tiles_m, int tiles_n,
-                            int splits, GemmEpi ep, int slice_rows) {      // slice_rows: rows a slice holds (0: tiles_m * 128)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
-    const int m0 = tm * 128, n0 = tn * 128;
-    const int rows = slice_rows > 0 ? slice_rows : tiles_m * 128;
-    const int64_t np = (int64_t)tiles_n * 128, slice = (int64_t)rows * np;
-    const int rl = m0 + wm * 64 + (lane & 15), c0 = n0 + wn * 64 + (lane >> 4) * 4;
-    floatx4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            floatx4 v = floatx4{0.f, 0.f, 0.f, 0.f};
-            if (rl + i * 16 < rows) {                              // rows past the slice height were never produced (skinny slices: 32 rows)
-                const float* p = ws + (int64_t)(rl + i * 16) * np + c0 + j * 16;
-                v = *reinterpret_cast<const floatx4*>(p);
-                for (int sp = 1; sp < splits; ++sp) v += *reinterpret_cast<const floatx4*>(p + sp * slice);  // fixed order
-            }
-            acc[i][j] = v;
-        }
-    epilogue_staged<128, 128, 4, 4, 4>(acc, ep, C, ldc, M, N, m0, n0, wm * 64, wn * 64, wave, lane, smem);
-}
-
 // gate/up rows interleaved in blocks of 16: packed[32b + i] = gate[16b + i], packed[32b + 16 + i] = up[16b + i]
 __global__ __launch_bounds__(256)
 void pack_gate_up_k(const bf16_t* __restrict__ g, const bf16_t* __restrict__ u, bf16_t* __restrict__ out, int64_t inter, int64_t K) {
@@ -1449,6 +1594,8 @@ extern "C" int licv_gemm_debug_timestamps(void* dev_buffer) {
 
 static int g_pp_group = 0;      // experiment knob: tile-rows per XCD patch group (0 = heuristic)
 static int g_splitk_enabled = 1;
+static int g_big_tiles = 160;   // knob 6: fewest 256 x 256 tiles for which the 256-tile kernels are taken (see route_256)
+static int g_force_splits = 0;  // knob 5 (A/B timing only): split count of the 128-tile route, 0 = the plan's own choice
 static int g_flow_default = 1;  // auto mode takes the flow kernels where they are eligible (knob 2 of licv_gemm_experiment; 0 = staged epilogues only)
 // A/B timing knobs:
 //   knob 0: (experiments' ping-pong kernel) per-XCD first-round start stagger, percent of an eighth of the estimated tile time
@@ -1459,12 +1606,15 @@ extern "C" int licv_gemm_experiment(int knob, int value) {
     if (knob == 0) return licv_gemm_exp_knob(0, value);
     else if (knob == 1) g_pp_group = value; else if (knob == 2) g_flow_default = value;
     else if (knob == 4) g_splitk_enabled = value;
+    else if (knob == 5) g_force_splits = value;
+    else if (knob == 6) g_big_tiles = value;
     else return licv_set_error(LICV_E_BADARG, "gemm_experiment: unknown knob %d", knob);
     return LICV_OK;
 }
 static int g_num_cus = 256;        // persistent grid size (queried once)
 // 0 auto; 1 tile128; 20 the 8-wave flow kernel where eligible (else lean); 22-27 lean variants; 40-42 quad64 variants (staged
-// epilogue); 60 the 4-wave flow64 kernel where eligible; every other value names a kernel of gemm_experiments.hip
+// epilogue); 60 the 4-wave flow64 kernel where eligible; 70 the 128-tile mid kernel at any M; every other value names a kernel of
+// gemm_experiments.hip
 static int g_force_kernel = 0;
 extern "C" int licv_gemm_select(int which) { g_force_kernel = which; return LICV_OK; }
 
@@ -1502,6 +1652,16 @@ static bool flow64_scratch_free() {
 
 // 1: the 8-wave flow kernel is usable; 2: the 4-wave flow64 kernel as well (bit 1)
 extern "C" int licv_gemm_flow_available(void) { return (flow_scratch_free() ? 1 : 0) | (flow64_scratch_free() ? 2 : 0); }
+
+// Which tile size a dense GEMM takes.  The 256 x 256 kernels (flow64 / quad64) need enough tiles to fill the 256 CUs: below
+// g_big_tiles of them (the vision tower on a few images: 2056 rows = 9 tile rows; Idefics2's 1-shot text stack) the 128 x 128
+// route — the mid kernel, two workgroups per CU, split-K where the tiles are still too few — is faster.  knob 6 moves the bar.
+static bool route_256(int64_t M, int64_t N, int64_t K) {
+    if (K % BK != 0 || K < 128 || M < 512 || N < 256) return false;
+    const int64_t t = ((M + 255) / 256) * ((N + 255) / 256);
+    // ... and those tiles must fill whole rounds of 256 reasonably (288 tiles = 1.13 rounds run as two: the 128-tile route wins)
+    return t >= g_big_tiles && (t >= 768 || 20 * t >= 13 * ((t + 255) / 256 * 256));
+}
 
 extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
                               int64_t M, int64_t N, int64_t K, const licv_gemm_epilogue* e, void* stream) {
@@ -1549,14 +1709,14 @@ extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
     }
     const int fk = g_force_kernel;
     const bool can256 = (K % BK == 0) && K >= 128;
-    const bool big = can256 && M >= 512 && N >= 256;
+    const bool big = route_256(M, N, K);
     const bool lean_ok = lda * 510 < (1ll << 31) && ldw * 510 < (1ll << 31);     // 32-bit lane offsets of the DMA sources
     const int tiles_m = (int)((M + 255) / 256), tiles_n = (int)((N + 255) / 256);
     // tile-rows per XCD patch: 8 (a 32-CU XCD then works on an 8 x 4 patch); with <= 6 tile-columns an 8-row group is 40-48
     // tiles and the patch straddles two groups -> 2-row groups keep it compact (measured +6 % at N = 1280, K = 5120)
     const int pp_group = g_pp_group > 0 ? g_pp_group : (tiles_n <= 6 ? 2 : 8);
     // a kernel of gemm_experiments.hip, by number
-    const bool product_sel = fk == 0 || fk == 1 || fk == 20 || (fk >= 22 && fk <= 27) || (fk >= 40 && fk <= 42) || fk == 60;
+    const bool product_sel = fk == 0 || fk == 1 || fk == 20 || (fk >= 22 && fk <= 27) || (fk >= 40 && fk <= 42) || fk == 60 || fk == 70;
     if (!product_sel && K % BK == 0) {
         GemmArgs ga{A, lda, W, ldw, C, ldc, (int)M, (int)N, (int)K, ep, (hipStream_t)stream, g_pp_group, g_num_cus};
         if (licv_gemm_exp_launch(fk, &ga) == 1) { LICV_LAUNCH_CHECK(); return LICV_OK; }
@@ -1568,7 +1728,7 @@ extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
     const bool flow_ok = can256 && M >= 512 && N >= 256 && N % 64 == 0 && e->out_dtype == LICV_BF16 && (!e->residual || flow_res) && !e->row_gate &&
                          !e->use_scale && (int64_t)(M + 256) * ldc * 2 < (1ll << 31) && ldc % 8 == 0 && lean_ok &&
                          (!e->bias_bf16 || ((uintptr_t)e->bias_bf16 & 3) == 0);
-    const bool use256 = fk == 1 ? false : (fk == 0 ? big : can256);
+    const bool use256 = (fk == 1 || fk == 70) ? false : (fk == 0 ? big : can256);
     const bool flow_auto = g_flow_default != 0;
     // flow64: the same epilogue families without the residual one, waves of 128 columns, at least four 64-deep K tiles
     const bool flow64_ok = flow_ok && N % 128 == 0 && K >= 256;
@@ -1611,8 +1771,15 @@ extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
 #undef LEAN
     } else {
         const int t128m = (int)((M + 127) / 128), t128n = (int)((N + 127) / 128);
-        gemm_bf16_tile128_k<<<dim3(t128m * t128n), dim3(256), 65536, (hipStream_t)stream>>>(
-            (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, t128m, t128n, ep);
+        // the LDS-DMA 128-tile kernel where its K tiling applies (select 1 / 70: the register-staged general kernel / the mid kernel, forced)
+        if (fk != 1 && K % 64 == 0 && K >= 128 && lean_ok) {
+            static bool amid = false;
+            if (!amid) { (void)hipFuncSetAttribute((const void*)gemm_bf16_mid_k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, MID_LDS); amid = true; }
+            gemm_bf16_mid_k<0><<<dim3(t128m * t128n), dim3(256), MID_LDS, (hipStream_t)stream>>>(
+                (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, t128m, t128n, ep, 0);
+        } else
+            gemm_bf16_tile128_k<<<dim3(t128m * t128n), dim3(256), 65536, (hipStream_t)stream>>>(
+                (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, t128m, t128n, ep);
     }
     LICV_LAUNCH_CHECK();
     return LICV_OK;
@@ -1623,20 +1790,6 @@ extern "C" int licv_gemm_splitk_plan(int64_t M, int64_t N, int64_t K, int* split
     LICV_CHECK_ARG(splits && workspace_bytes, "gemm_splitk_plan: null pointer");
     *splits = 1; *workspace_bytes = 0;
     if (!g_splitk_enabled) return LICV_OK;
-    if (M > 256) {
-        // few 256 x 256 tiles and a long K (Idefics2 1-shot down-projection: 1376 x 4096 x 14336 = 96 tiles on 256 CUs, 257 us):
-        // the ping-pong kernel itself produces the partials (workspace padded to 256)
-        const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256);
-        if (M >= 512 && N >= 256 && K >= 8192 && K % 64 == 0 && t256 <= 128) {
-            int64_t sp = 320 / t256;
-            if (sp > 4) sp = 4;
-            if (sp >= 2) {
-                *splits = (int)sp;
-                *workspace_bytes = sp * ((M + 255) / 256 * 256) * ((N + 255) / 256 * 256) * 4;
-            }
-        }
-        return LICV_OK;
-    }
     if (M > 0 && M <= 32 && N >= 256 && K >= 256 && K % 8 == 0) {    // weight-streaming kernel (gemm_bf16_skinny_k)
         const int64_t nblocks = (N + 63) / 64, nsteps = (K + 31) / 32;
         int64_t sp = (nsteps + SKINNY_KR_MAX / 32 - 1) / (SKINNY_KR_MAX / 32);
@@ -1651,14 +1804,31 @@ extern "C" int licv_gemm_splitk_plan(int64_t M, int64_t N, int64_t K, int* split
             return LICV_OK;
         }
     }
-    // measured (round 1): worth it from K ~ 8192 up (K = 11008: 132 -> 69 us at M = 256); at K = 4096 the extra
-    // fp32 round trip through the workspace and the second launch cancel the gain
-    if (M <= 0 || M > 256 || K < 8192 || K % 8 != 0 || N < 128) return LICV_OK;
+    if (M <= 0 || N < 128 || K % 8 != 0 || route_256(M, N, K)) return LICV_OK;
+    // 128-tile route.  Two workgroups fit a CU (512 slots); a K tile is 64 deep.
     const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
     const int64_t nkt = (K + BK - 1) / BK;
-    int64_t sp = (512 + tiles - 1) / tiles;                       // aim at ~512 workgroups
-    if (sp > nkt / 4) sp = nkt / 4;                               // at least 4 K-tiles (256 K) per split
-    if (sp > 16) sp = 16;
+    int64_t sp = 1;
+    if (g_force_splits > 0) sp = g_force_splits;
+    else if (K % BK == 0) {
+        // The smallest estimated time wins: rounds of workgroups x K tiles per workgroup x time per K tile (the operand stream of a
+        // CU is shared by its two workgroups: ~0.5 us per 32 KiB K tile alone, ~0.9 us each in pairs), plus — for sp > 1 — the fp32
+        // partials written once and read once at ~3 TB/s and a second launch.  Constants from tools/mid_bench.py sweeps.
+        double best = 1e30;
+        for (int64_t c : {1, 2, 3, 4, 6, 8, 12, 16}) {
+            if (c > 1 && nkt / c < 4) break;                      // at least 4 K tiles per split
+            const int64_t wgs = tiles * c, per = (nkt + c - 1) / c;
+            const double rounds = (double)((wgs + 511) / 512);
+            const double tk = wgs <= 256 ? 0.5 : 0.9;
+            double t = rounds * (per * tk + 4.0);
+            if (c > 1) t += (double)(c + 1) * M * N * 4.0 / 3.0e6 + 5.0;
+            if (t < best) { best = t; sp = c; }
+        }
+    } else if (M <= 256 && K >= 8192) {                           // ragged K: the register-staged producer, the round-1 rule
+        sp = (512 + tiles - 1) / tiles;
+        if (sp > nkt / 4) sp = nkt / 4;
+        if (sp > 16) sp = 16;
+    }
     if (sp < 2) return LICV_OK;
     *splits = (int)sp;
     *workspace_bytes = sp * ((M + 127) / 128 * 128) * ((N + 127) / 128 * 128) * 4;
@@ -1700,8 +1870,7 @@ extern "C" int licv_gemm_bf16_splitk(const void* A, int64_t lda, const void* W, 
         if (!sattr) {
             (void)hipFuncSetAttribute((const void*)gemm_bf16_skinny_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 32 * (SKINNY_KR_MAX * 2 + 16));
             (void)hipFuncSetAttribute((const void*)gemm_bf16_skinny_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 32 * (SKINNY_KR_MAX * 2 + 16));
-            (void)hipFuncSetAttribute((const void*)gemm_splitk_finalize_k, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-            sattr = true;
+                sattr = true;
         }
         hipStream_t sst = (hipStream_t)stream;
         const dim3 grid((unsigned)((N + 63) / 64), (unsigned)splits);
@@ -1711,17 +1880,14 @@ extern "C" int licv_gemm_bf16_splitk(const void* A, int64_t lda, const void* W, 
         else         gemm_bf16_skinny_k<2><<<grid, 256, lds, sst>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, (float*)workspace, (int)M, (int)N, (int)K, per, np);
         const int n_out = e->swiglu ? (int)(N / 2) : (int)N;
         const int64_t items = (int64_t)M * ((n_out + 3) / 4);
-        skinny_finalize_k<<<dim3((unsigned)((items + 255) / 256)), dim3(256), 0, sst>>>((const float*)workspace, C, ldc, (int)M, (int)N, np, splits, eps);
+        skinny_finalize_k<<<dim3((unsigned)((items + 255) / 256)), dim3(256), 0, sst>>>((const float*)workspace, C, ldc, (int)M, (int)N, np, splits, eps, 32);
         LICV_LAUNCH_CHECK();
         return LICV_OK;
     }
-    const bool big = M > 256;                                  // partials from the 256 x 256 ping-pong kernel
-    const int pad = big ? 256 : 128;
     const int tiles_m = (int)((M + 127) / 128), tiles_n = (int)((N + 127) / 128);
-    const int64_t mp = (M + pad - 1) / pad * pad, npad = (N + pad - 1) / pad * pad;
+    const int64_t mp = (int64_t)tiles_m * 128, npad = (int64_t)tiles_n * 128;
     const int64_t need = (int64_t)splits * mp * npad * 4;
     LICV_CHECK_ARG(workspace_bytes >= need, "gemm_bf16_splitk: workspace %lld B < %lld B", (long long)workspace_bytes, (long long)need);
-    LICV_CHECK_ARG(!big || (K % 64 == 0 && (K / 32) / splits >= 8), "gemm_bf16_splitk: K too short for %d splits of the 256-tile kernel", splits);
     const int nkt = (int)((K + BK - 1) / BK);
     const int per = (nkt + splits - 1) / splits;
     GemmEpi ep;
@@ -1732,32 +1898,23 @@ extern "C" int licv_gemm_bf16_splitk(const void* A, int64_t lda, const void* W, 
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)gemm_bf16_splitk_k, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        (void)hipFuncSetAttribute((const void*)gemm_splitk_finalize_k, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_mid_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, MID_LDS);
         attr = true;
     }
     hipStream_t st = (hipStream_t)stream;
-    if (big) {
-        static bool attr5 = false;
-        if (!attr5) { (void)hipFuncSetAttribute((const void*)gemm_bf16_lean_k<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES); attr5 = true; }
-        const int t256m = (int)(mp / 256), t256n = (int)(npad / 256);
-        const int stages = (int)(K / 32), per32 = (stages + splits - 1) / splits;
-        LICV_CHECK_ARG(lda * 510 < (1ll << 31) && ldw * 510 < (1ll << 31), "gemm_bf16_splitk: leading dimensions too large for the 256-tile producer");
-        if (g_force_kernel != 6)
-            gemm_bf16_lean_k<1, 0><<<dim3(t256m * t256n, splits), dim3(512), RING_STAGES * RING_STAGE_BYTES, st>>>(
-                (const bf16_t*)A, lda, (const bf16_t*)W, ldw, workspace, 0, (int)M, (int)N, (int)K, t256m, t256n, ep, per32);
-        else {                                                 // A/B only: the round-1 ping-pong kernel as the producer
-            GemmArgs ga{A, lda, W, ldw, C, ldc, (int)M, (int)N, (int)K, ep, st, g_pp_group, g_num_cus};
-            licv_gemm_exp_splitk_producer(&ga, workspace, t256m, t256n, splits, per32);
-        }
-        // the finalize kernel walks 128 x 128 tiles of the same [split][M_pad][N_pad] workspace
-        gemm_splitk_finalize_k<<<dim3((int)(mp / 128) * (int)(npad / 128)), dim3(256), 65536, st>>>((const float*)workspace, C, ldc, (int)M, (int)N,
-            (int)(mp / 128), (int)(npad / 128), splits, ep, 0);
+    if (g_force_kernel != 1 && K % 64 == 0 && nkt - (splits - 1) * per >= 2 && lda * 510 < (1ll << 31) && ldw * 510 < (1ll << 31)) {
+        // the mid kernel as the producer (every split at least two K tiles deep)
+        gemm_bf16_mid_k<1><<<dim3(tiles_m * tiles_n, splits), dim3(256), MID_LDS, st>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw,
+            workspace, 0, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, per);
     } else {
         gemm_bf16_splitk_k<<<dim3(tiles_m * tiles_n, splits), dim3(256), 65536, st>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw,
             (float*)workspace, (int)M, (int)N, (int)K, tiles_m, tiles_n, per);
-        gemm_splitk_finalize_k<<<dim3(tiles_m * tiles_n), dim3(256), 65536, st>>>((const float*)workspace, C, ldc, (int)M, (int)N,
-            tiles_m, tiles_n, splits, ep, 0);
     }
+    // the row-major finalize (4 consecutive columns per thread: coalesced 16-byte reads of every slice, same rounding points as the
+    // staged epilogue); the first version walked the partials in the accumulator layout through an LDS image: ~8 us per extra split
+    const int n_out = e->swiglu ? (int)(N / 2) : (int)N;
+    const int64_t items = (int64_t)M * ((n_out + 3) / 4);
+    skinny_finalize_k<<<dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st>>>((const float*)workspace, C, ldc, (int)M, (int)N, npad, splits, ep, (int)mp);
     LICV_LAUNCH_CHECK();
     return LICV_OK;
 }
