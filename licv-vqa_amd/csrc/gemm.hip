@@ -1450,6 +1450,21 @@ void gemm_bf16_skinny_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t*
     const int ns = s1 - s0;
     const int kbase = s0 * 32, kr = ns * 32;
     const int xstr = kr * 2 + 16;                                    // LDS row stride in bytes
+    const int n = blockIdx.x * 64 + wave * 16 + fr;
+    const bf16_t* wp = W + (int64_t)min(n, N - 1) * ldw + kbase + fq * 8;
+    // The weight stream is software-pipelined in two register sets of UN fragments: set (s + UN) is requested before set s is
+    // multiplied, and the FIRST set before the activations are staged (it does not depend on them) — the first version loaded a
+    // set, waited, multiplied, and only then asked for the next, and began streaming after the staging barrier: 3.0 TB/s.
+    constexpr int UN = 8;
+    u32x4 wf[2][UN];
+    auto loadw = [&](int s, u32x4 (&dst)[UN]) {
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int k = kbase + (s + u) * 32 + fq * 8;
+            dst[u] = (s + u < ns && k < K) ? *reinterpret_cast<const u32x4*>(wp + (s + u) * 32) : u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+    loadw(0, wf[0]);
     // ---- activations of this K range -> LDS (zero rows past M, zero columns past K)
     const int chunks = kr / 8;
     for (int c = tid; c < MB * 16 * chunks; c += 256) {
@@ -1460,38 +1475,27 @@ void gemm_bf16_skinny_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t*
         *reinterpret_cast<u32x4*>(smem + row * xstr + ch * 16) = v;
     }
     __syncthreads();
-    const int n = blockIdx.x * 64 + wave * 16 + fr;
-    const bf16_t* wp = W + (int64_t)min(n, N - 1) * ldw + kbase + fq * 8;
     const char* xp = smem + fr * xstr + fq * 16;
     floatx4 acc[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) acc[mb] = floatx4{0.f, 0.f, 0.f, 0.f};
-    constexpr int UN = 8;
-    int s = 0;
-    for (; s + UN <= ns; s += UN) {
-        u32x4 wf[UN];
+    auto mul = [&](int s, const u32x4 (&src)[UN]) {
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            const int k = kbase + (s + u) * 32 + fq * 8;
-            // (non-temporal loads measured here: 33 -> 40 us at (24, 12288, 4096) replayed back to back, generate unchanged: not taken)
-            wf[u] = k < K ? *reinterpret_cast<const u32x4*>(wp + (s + u) * 32) : u32x4{0u, 0u, 0u, 0u};
-        }
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
+            const int so = s + u < ns ? (s + u) * 64 : 0;           // steps past the range carry zero weights: any in-range activations do
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
-                const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xp + mb * 16 * xstr + (s + u) * 64);
-                acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&wf[u]), xf, acc[mb], 0, 0, 0);
+                const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xp + mb * 16 * xstr + so);
+                acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&src[u]), xf, acc[mb], 0, 0, 0);
             }
         }
-    }
-    for (; s < ns; ++s) {
-        const int k = kbase + s * 32 + fq * 8;
-        const u32x4 w1 = k < K ? *reinterpret_cast<const u32x4*>(wp + s * 32) : u32x4{0u, 0u, 0u, 0u};
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-            const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xp + mb * 16 * xstr + s * 64);
-            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&w1), xf, acc[mb], 0, 0, 0);
+    };
+    for (int s = 0; s < ns; s += 2 * UN) {
+        if (s + UN < ns) loadw(s + UN, wf[1]);
+        mul(s, wf[0]);
+        if (s + UN < ns) {
+            if (s + 2 * UN < ns) loadw(s + 2 * UN, wf[0]);
+            mul(s + UN, wf[1]);
         }
     }
     // lane holds rows m = mb*16 + fr, columns n0 + fq*4 .. +3  (W was the A operand)

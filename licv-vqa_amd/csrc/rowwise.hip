@@ -44,26 +44,40 @@ void inject_renorm_fwd_k(const void* __restrict__ h, const float* __restrict__ i
     if (row >= rows) return;
     const float a = alpha ? *alpha : 1.0f;
     const int64_t base = row * hidden;
-    floatx4 x[NCH];
+    // Every load of a phase is issued before the first value is used: chunk indices past the row are clamped to the row's first
+    // chunk and their values discarded by a select, not skipped by a branch.  (A guard `if (i < hidden) { load; use; }` per chunk
+    // made each chunk its own basic block with a full vmcnt(0) wait: 16 dependent round trips per row — 11 us of the 12 a 24-row
+    // call took in a decode step, and fewer bytes in flight per wave at every size.)
+    // The optional operands (`pre`, `res`) are wave-uniform: their loads are issued unconditionally from a stand-in address inside
+    // `h` when absent and dropped by a select — no branch per chunk either.
+    floatx4 x[NCH], hvv[NCH], bvv[NCH], vvv[NCH];
     float ss = 0.f, hh = 0.f;
+    const bool has_pre = pre != nullptr;
+    const void* pre_p = has_pre ? (const void*)pre : h;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int i = (c * 64 + lane) * 4, ii = i < hidden ? i : 0;
+        hvv[c] = RowIO<DT>::load4(h, base + ii);
+        bvv[c] = RowIO<LICV_BF16>::load4(pre_p, base + ii);
+        vvv[c] = *reinterpret_cast<const floatx4*>(icv + ii);
+    }
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int i = (c * 64 + lane) * 4;
-        if (i < hidden) {
-            floatx4 hv = RowIO<DT>::load4(h, base + i);
-            if (pre) {      // the layer's last residual add, h + branch in the stream's dtype, folded in (it was the down projection's epilogue)
-                const floatx4 bv = RowIO<LICV_BF16>::load4(pre, base + i);
+        const bool ok = i < hidden;
+        floatx4 hv = hvv[c];
+        // the layer's last residual add, h + branch in the stream's dtype, folded in (it was the down projection's epilogue)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) hv[j] = (DT == LICV_BF16) ? rbf(hv[j] + bv[j]) : hv[j] + bv[j];
-            }
-            const floatx4 vv = *reinterpret_cast<const floatx4*>(icv + i);
+        for (int j = 0; j < 4; ++j) {
+            const float sum = (DT == LICV_BF16) ? rbf(hv[j] + bvv[c][j]) : hv[j] + bvv[c][j];
+            hv[j] = has_pre ? sum : hv[j];
+        }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float s = hv[j] + a * vv[j];
-                hh += hv[j] * hv[j];
-                ss += s * s;
-                x[c][j] = s;
-            }
+        for (int j = 0; j < 4; ++j) {
+            const float s = hv[j] + a * vvv[c][j];
+            hh += ok ? hv[j] * hv[j] : 0.f;
+            ss += ok ? s * s : 0.f;
+            x[c][j] = s;
         }
     }
     ss = wave_sum(ss);
@@ -73,21 +87,42 @@ void inject_renorm_fwd_k(const void* __restrict__ h, const float* __restrict__ i
     const float ns = sqrtf(ss);
     const float nh = (DT == LICV_BF16) ? rbf(sqrtf(hh)) : sqrtf(hh);
     float q2 = 0.f;
+    floatx4 rvv[NCH], wvv[NCH];
+    const bool has_res = res != nullptr;                 // hooked BRANCH output (Idefics2 `.mlp`): stream = residual + edited branch
+    const bool res32 = has_res && res_dt == LICV_F32;
+    const void* res_p = has_res ? res : h;
+    if (res32) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int i = (c * 64 + lane) * 4, ii = i < hidden ? i : 0;
+            rvv[c] = RowIO<LICV_F32>::load4(res_p, base + ii);
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int i = (c * 64 + lane) * 4, ii = i < hidden ? i : 0;
+            rvv[c] = RowIO<LICV_BF16>::load4(res_p, base + ii);
+        }
+    }
+    if (FUSE_NORM) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int i = (c * 64 + lane) * 4, ii = i < hidden ? i : 0;
+            wvv[c] = RowIO<LICV_BF16>::load4(norm_w, ii);
+        }
+    }
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int i = (c * 64 + lane) * 4;
-        if (i < hidden) {
+        const bool ok = i < hidden;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) x[c][j] = x[c][j] / ns * nh;
-            if (res) {                                   // hooked BRANCH output (Idefics2 `.mlp`): stream = residual + edited branch
-                const floatx4 rv = res_dt == LICV_F32 ? RowIO<LICV_F32>::load4(res, base + i) : RowIO<LICV_BF16>::load4(res, base + i);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) x[c][j] = rv[j] + x[c][j];
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) q2 += x[c][j] * x[c][j];
-            *reinterpret_cast<floatx4*>(out + base + i) = x[c];
+        for (int j = 0; j < 4; ++j) {
+            const float e = x[c][j] / ns * nh;
+            x[c][j] = has_res ? rvv[c][j] + e : e;
         }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) q2 += ok ? x[c][j] * x[c][j] : 0.f;
+        if (ok) *reinterpret_cast<floatx4*>(out + base + i) = x[c];
     }
     if (FUSE_NORM) {
         q2 = wave_sum(q2);
@@ -96,10 +131,9 @@ void inject_renorm_fwd_k(const void* __restrict__ h, const float* __restrict__ i
         for (int c = 0; c < NCH; ++c) {
             const int i = (c * 64 + lane) * 4;
             if (i < hidden) {
-                const floatx4 w = RowIO<LICV_BF16>::load4(norm_w, i);
                 floatx4 y;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) y[j] = w[j] * (norm_flavour == 1 ? x[c][j] * rs : rbf(x[c][j] * rs));
+                for (int j = 0; j < 4; ++j) y[j] = wvv[c][j] * (norm_flavour == 1 ? x[c][j] * rs : rbf(x[c][j] * rs));
                 store4_bf16(xn, base + i, y);
             }
         }
@@ -179,16 +213,19 @@ void rmsnorm_fwd_k(const void* __restrict__ x, const bf16_t* __restrict__ w, bf1
     if (row >= rows) return;
     const int64_t ro = row / inner, ri = row % inner;
     const int64_t xb = ro * ld_x + ri * dim, ob = ro * ld_out + ri * dim;
-    floatx4 v[NCH];
+    floatx4 v[NCH], wv[NCH];                                      // all loads first, no per-chunk branch (see inject_renorm_fwd_k)
     float ss = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        const int i = (c * 64 + lane) * 4;
-        if (i < dim) {
-            v[c] = RowIO<DT>::load4(x, xb + i);
+        const int i = (c * 64 + lane) * 4, ii = i < dim ? i : 0;
+        v[c] = RowIO<DT>::load4(x, xb + ii);
+        wv[c] = RowIO<LICV_BF16>::load4(w, ii);
+    }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) ss += v[c][j] * v[c][j];
-        }
+    for (int c = 0; c < NCH; ++c) {
+        const bool ok = (c * 64 + lane) * 4 < dim;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ss += ok ? v[c][j] * v[c][j] : 0.f;
     }
     ss = wave_sum(ss);
     const float rs = rsqrtf(ss / (float)dim + eps);
@@ -197,12 +234,11 @@ void rmsnorm_fwd_k(const void* __restrict__ x, const bf16_t* __restrict__ w, bf1
     for (int c = 0; c < NCH; ++c) {
         const int i = (c * 64 + lane) * 4;
         if (i < dim) {
-            const floatx4 wv = RowIO<LICV_BF16>::load4(w, i);
             floatx4 y;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float n = v[c][j] * rs;
-                y[j] = wv[j] * (single_round ? n : rbf(n));
+                y[j] = wv[c][j] * (single_round ? n : rbf(n));
             }
             store4_bf16(out, ob + i, y);
         }
@@ -220,24 +256,31 @@ void add_rmsnorm_fwd_k(void* __restrict__ h, const bf16_t* __restrict__ branch, 
     if (row >= rows) return;
     const int64_t base = row * dim;
     const bool closed = row_gate && row_gate[row] == 0.0f;           // gated cross-attention: a token that attends no image adds nothing
-    floatx4 v[NCH];
+    floatx4 v[NCH], bvv[NCH], wv[NCH];                             // all loads first, no per-chunk branch (see inject_renorm_fwd_k)
     float ss = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
+        const int i = (c * 64 + lane) * 4, ii = i < dim ? i : 0;
+        v[c] = RowIO<DT>::load4(h, base + ii);
+        bvv[c] = RowIO<LICV_BF16>::load4(branch, base + ii);
+        wv[c] = RowIO<LICV_BF16>::load4(w, ii);
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
         const int i = (c * 64 + lane) * 4;
-        if (i < dim) {
-            v[c] = RowIO<DT>::load4(h, base + i);
-            floatx4 bv = RowIO<LICV_BF16>::load4(branch, base + i);
-            if (closed) bv = floatx4{0.f, 0.f, 0.f, 0.f};
-            if (use_scale) {                                          // tanh(alpha) gate, rounded to bf16 as the GEMM epilogue does
+        const bool ok = i < dim;
+        floatx4 bv = bvv[c];
+        if (closed) bv = floatx4{0.f, 0.f, 0.f, 0.f};
+        if (use_scale) {                                          // tanh(alpha) gate, rounded to bf16 as the GEMM epilogue does
 #pragma unroll
-                for (int j = 0; j < 4; ++j) bv[j] = rbf(scale * bv[j]);
-            }
+            for (int j = 0; j < 4; ++j) bv[j] = rbf(scale * bv[j]);
+        }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                v[c][j] = (DT == LICV_BF16) ? rbf(v[c][j] + bv[j]) : v[c][j] + bv[j];
-                ss += v[c][j] * v[c][j];
-            }
+        for (int j = 0; j < 4; ++j) {
+            v[c][j] = (DT == LICV_BF16) ? rbf(v[c][j] + bv[j]) : v[c][j] + bv[j];
+            ss += ok ? v[c][j] * v[c][j] : 0.f;
+        }
+        if (ok) {
             if (DT == LICV_BF16) store4_bf16(h, base + i, v[c]);
             else *reinterpret_cast<floatx4*>(reinterpret_cast<float*>(h) + base + i) = v[c];
         }
@@ -249,12 +292,11 @@ void add_rmsnorm_fwd_k(void* __restrict__ h, const bf16_t* __restrict__ branch, 
     for (int c = 0; c < NCH; ++c) {
         const int i = (c * 64 + lane) * 4;
         if (i < dim) {
-            const floatx4 wv = RowIO<LICV_BF16>::load4(w, i);
             floatx4 y;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float n = v[c][j] * rs;
-                y[j] = wv[j] * (single_round ? n : rbf(n));
+                y[j] = wv[c][j] * (single_round ? n : rbf(n));
             }
             store4_bf16(out, base + i, y);
         }
