@@ -33,6 +33,10 @@ WORKLOADS = {
     # name: (arch preset, B, S, n_img, min_len)
     "idefics9b_32shot_bs8": ("idefics-9b", 8, 800, 33, 720),
     "idefics9b_student_bs8": ("idefics-9b", 8, 32, 1, 24),
+    # the image input pipeline (uint8 on the host -> pinned staging -> H2D on a side stream -> normalise kernel)
+    # beside the headline forward: images/s of the feeder alone and with the forward running, and the headline step when every
+    # step's pixel_values come from host bytes instead of a device-resident tensor
+    "frontend_images_bs8": ("idefics-9b", 8, 800, 33, 720),
     "idefics_mid_debug": ("idefics-mid", 4, 96, 5, 80),
     # ref:inference.py:300-321 shape: hooked generate on the query-only prompt, 3 beams, 5 new tokens (ref:config/inference.yaml:26-30)
     "idefics9b_generate_bs8": ("idefics-9b", 8, 32, 1, 32),
@@ -154,6 +158,77 @@ def cpu_baseline_generate(arch, S, n_img):
                        f"decoder layers: " + ", ".join(f"{k} {v:.2f}s" for k, v in tm.items())
                        + f"; per-4-layer difference scaled to {arch.num_layers} layers + {arch.v_layers - 1} more ViT layers "
                        f"({one['vit_layer']:.2f}s each) + {arch.r_depth - 1} more perceiver blocks = {full:.1f} s/question")}
+
+
+def frontend_bench(args, eng, arch, batch, hooks, B, n_img, dev):
+    """Workload frontend_images_bs8 (one GPU): see WORKLOADS."""
+    import numpy as np
+    from licv.image_feeder import ImageFeeder
+    side = arch.v_image
+    n = B * n_img
+    rng = np.random.default_rng(426)
+    host = [rng.integers(0, 256, (n, side, side, 3), dtype=np.uint8) for _ in range(2)]
+    feeder = ImageFeeder(dev, n, side, side)
+    kw = {k: v for k, v in batch.items() if k != "pixel_values"}
+
+    def timed(fn, iters):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn(iters)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    # (1) the feeder alone
+    def alone(iters):
+        for i in range(iters):
+            feeder.get(feeder.submit(host[i & 1]))
+    alone(4)
+    t_alone = timed(alone, 40)
+    # (2) headline forward on device-resident pixel_values (the bench's own configuration)
+    def resident(iters):
+        for _ in range(iters):
+            eng.forward(**batch, **hooks)
+    resident(args.warmup)
+    t_res = timed(resident, args.steps)
+    # (3) every step's images come from host bytes: batch i + 1 is submitted (packed, copied, normalised on the side stream) while
+    # the forward of batch i runs
+    def fed(iters):
+        t = feeder.submit(host[0])
+        for i in range(iters):
+            pv, _ = feeder.get(t, B, n_img)
+            nxt = feeder.submit(host[(i + 1) & 1])
+            eng.forward(**kw, pixel_values=pv, **hooks)
+            feeder.release(t)
+            t = nxt
+    fed(args.warmup)
+    t_fed = timed(fed, args.steps)
+    # (4) the feeder at full tilt beside the forward: `k` extra batches per step on the side stream
+    k = 8
+    def beside(iters):                                    # (submit only: a get() would make the main stream a consumer of every batch)
+        for i in range(iters):
+            eng.forward(**batch, **hooks)
+            for j in range(k):
+                feeder.submit(host[j & 1])
+    beside(2)
+    t_beside = timed(beside, args.steps)
+    res = {
+        "metric": "frontend images/s: uint8 host -> pinned staging -> H2D -> normalised bf16 on the device (licv.image_feeder), headline forward running concurrently",
+        "value": args.steps * k * n / t_beside, "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * t_beside / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8 -> bf16",
+        "data": "synthetic (seeded uint8 images, random-init idefics-9b weights)",
+        "config": {"workload": args.workload, "images_per_batch": n, "image": f"{side}x{side}x3 uint8", "extra_batches_per_step": k,
+                   "questions_per_gpu": B, "images_per_question": n_img},
+        "alone_images_per_s": 40 * n / t_alone, "alone_ms_per_batch": 1e3 * t_alone / 40,
+        "headline_resident": {"questions_per_s": B * args.steps / t_res, "ms_per_step": 1e3 * t_res / args.steps},
+        "headline_fed_from_host_uint8": {"questions_per_s": B * args.steps / t_fed, "ms_per_step": 1e3 * t_fed / args.steps,
+                                         "images_per_s": n * args.steps / t_fed},
+        "forward_ms_per_step_with_feeder_at_full_tilt": 1e3 * t_beside / args.steps,
+        "bytes": {"per_image_over_pcie": side * side * 3, "per_image_written_bf16": side * side * 3 * 2,
+                  "note": "the reference ships float32 pixel_values (4x the bytes) produced by the HF image processor on the host"},
+        "roofline": {"bound": "hbm", "kernel": "image_preprocess_k", "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": None,
+                     "note": "451 KB of device traffic per image: 10 k images/s is 4.5 GB/s, nowhere near a device bound; the pipeline is host-side (packing into pinned memory) and PCIe"},
+    }
+    print(json.dumps(res), flush=True)
 
 
 def gemm_src_sha16() -> str:
@@ -361,6 +436,10 @@ def main():
     layers = list(range(arch.num_layers))
     hooks = {} if args.no_hooks else dict(icv=icv, alpha=alpha, hook_layers=layers)
 
+    if args.workload.startswith("frontend_images"):
+        assert world == 1, "the image-input workload is a one-GPU measurement"
+        frontend_bench(args, eng, arch, batch, hooks, B, n_img, dev)
+        return
     generating = "generate" in args.workload
     if generating:
         from licv.generation import generate as native_generate

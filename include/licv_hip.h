@@ -300,6 +300,13 @@ int licv_idefics2_patch_front(const void* pixel_values_bf16, const void* pixel_a
 int licv_merge_image_rows(void* h_bf16, const int64_t* input_ids, const void* image_rows_bf16, int32_t* rank_scratch,
                           int32_t* count_out, int64_t M, int64_t dim, int64_t n_image_rows, int64_t image_token_id, void* stream);
 
+/* Image input (ref:icv_src/icv_datamodule.py:80-124 -> processor.prepare_input -> hf:image_transforms.py rescale :118-122, normalize
+ * :437; hf:idefics2 image processor's padding + pixel_attention_mask): src (n, H, W, 3) uint8 on the device -> dst (n, 3, H, W) bf16 =
+ * bf16(((float)(u8 * rescale) - mean[c]) / std[c]); valid_hw (n, 2) int32 (optional): real height / width of each image inside the
+ * padded H x W (pixels outside are 0, mask 0); mask (n, H, W) uint8 (optional).  mean3 / std3 are HOST pointers. */
+int licv_preprocess_images(const void* src_u8, const int32_t* valid_hw, void* dst_bf16, void* mask_u8, int64_t n_images,
+                           int64_t H, int64_t W, double rescale, const float* mean3, const float* std3, void* stream);
+
 /* ---- loss + optimiser (ref:icv_src/icv_module.py:121-134, :171-209) ---- */
 /* per-row KL(teacher||student) with eps inside the log, rows gathered by index; out_rows fp32 (n_rows). */
 int licv_kl_rows_fwd(const void* stu_logits, const void* tea_logits, int dtype,

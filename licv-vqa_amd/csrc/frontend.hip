@@ -7,6 +7,7 @@
 //                (hf:idefics2/modeling_idefics2.py:831-855, :136-170);
 //   * Idefics2 : inputs_merger (hf:idefics2/modeling_idefics2.py:789-815) as rank-of-<image>-token + row copy, no nonzero().
 // All of it is byte/integer work bounded by HBM bandwidth: coalesced 16-byte loads, one wave (or workgroup) per row / image.
+#include <cstring>
 #include "common.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -195,6 +196,63 @@ extern "C" int licv_merge_image_rows(void* h_bf16, const int64_t* input_ids, con
     hipStream_t st = (hipStream_t)stream;
     image_token_rank_k<<<1, 1024, 0, st>>>(input_ids, rank_scratch, M, image_token_id, count_out);
     merge_rows_by_rank_k<<<(unsigned)((M + 3) / 4), 256, 0, st>>>((bf16_t*)h_bf16, rank_scratch, (const bf16_t*)image_rows_bf16, M, (int)dim, n_image_rows);
+    LICV_LAUNCH_CHECK();
+    return LICV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Image input: uint8 HWC -> normalised bf16 CHW (+ Idefics2's pixel_attention_mask), what the HF image processors do to an image on
+// the host before `processor.prepare_input` returns it (ref:icv_src/icv_datamodule.py:80-124; hf:image_transforms.py rescale :118-122
+// = f32(f64(u8) * f64 scale), normalize :437 = (x - f32 mean) / f32 std, channels first; hf:idefics2 pads to the batch maximum with
+// zeros and marks real pixels).  A byte has 256 values: the 3 x 256 table of final bf16 values is computed on the HOST with exactly
+// those IEEE operations (so the result is the reference's float rounded once to bf16, bit for bit; the device's float division is
+// not the host's), handed to the kernel by value (1.5 KB of kernel arguments), copied to LDS, and the pixel loop is a table
+// look-up and a layout change: 3 bytes in, 3 bf16 planes out, consecutive lanes on consecutive pixels.
+// ------------------------------------------------------------------------------------------------
+struct ImageTable { bf16_t v[3][256]; };
+
+__global__ __launch_bounds__(256)
+void image_preprocess_k(const unsigned char* __restrict__ src, const int32_t* __restrict__ hw, bf16_t* __restrict__ dst,
+                        unsigned char* __restrict__ mask, int64_t n, int H, int W, ImageTable tb) {
+    __shared__ bf16_t table[3][256];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) table[c][threadIdx.x] = tb.v[c][threadIdx.x];      // 256 threads: one byte value each
+    __syncthreads();
+    const int64_t plane = (int64_t)H * W;
+    const int64_t img = blockIdx.y;
+    const int h = hw ? hw[2 * img] : H, w = hw ? hw[2 * img + 1] : W;
+    const unsigned char* s = src + img * plane * 3;
+    bf16_t* d = dst + img * plane * 3;
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < plane; p += (int64_t)gridDim.x * 256) {
+        const int y = (int)(p / W), x = (int)(p - (int64_t)y * W);
+        const bool real = y < h && x < w;
+        const unsigned char r = s[3 * p], g = s[3 * p + 1], b = s[3 * p + 2];
+        d[p] = real ? table[0][r] : (bf16_t)0;
+        d[plane + p] = real ? table[1][g] : (bf16_t)0;
+        d[2 * plane + p] = real ? table[2][b] : (bf16_t)0;
+        if (mask) mask[img * plane + p] = real ? 1 : 0;
+    }
+}
+
+extern "C" int licv_preprocess_images(const void* src_u8, const int32_t* valid_hw, void* dst_bf16, void* mask_u8, int64_t n_images,
+                                      int64_t H, int64_t W, double rescale, const float* mean3, const float* std3, void* stream) {
+    LICV_CHECK_ARG(src_u8 && dst_bf16 && mean3 && std3, "preprocess_images: null pointer");
+    LICV_CHECK_ARG(n_images >= 0 && H > 0 && W > 0 && H * W < (1ll << 31), "preprocess_images: bad shape");
+    LICV_CHECK_ARG(std3[0] != 0.f && std3[1] != 0.f && std3[2] != 0.f, "preprocess_images: zero std");
+    if (n_images == 0) return LICV_OK;
+    ImageTable tb;
+    for (int v = 0; v < 256; ++v) {
+        const volatile float x = (float)((double)v * rescale);        // hf:image_transforms.py:118-122 (volatile: one rounding per step,
+        for (int c = 0; c < 3; ++c) {                                 //  no wider intermediate, whatever the host compiler's flags)
+            const volatile float d = x - mean3[c];
+            const volatile float q = d / std3[c];                     // :437
+            uint32_t u; float qf = q; memcpy(&u, &qf, 4);
+            tb.v[c][v] = (bf16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);      // round to nearest even (finite values only)
+        }
+    }
+    int64_t bx = (H * W + 255) / 256; bx = bx > 64 ? 64 : bx;
+    image_preprocess_k<<<dim3((unsigned)bx, (unsigned)n_images), 256, 0, (hipStream_t)stream>>>(
+        (const unsigned char*)src_u8, valid_hw, (bf16_t*)dst_bf16, (unsigned char*)mask_u8, n_images, (int)H, (int)W, tb);
     LICV_LAUNCH_CHECK();
     return LICV_OK;
 }

@@ -85,6 +85,7 @@ def lib() -> C.CDLL:
             "licv_idefics_image_attention_mask": [P, P, I64, I64, I64, I64, I64, P],
             "licv_idefics2_patch_front": [P, P, P, P, P, P, I64, I64, I64, I64, I64, P],
             "licv_merge_image_rows": [P, P, P, P, P, I64, I64, I64, I64, P],
+            "licv_preprocess_images": [P, P, P, P, I64, I64, I64, C.c_double, P, P, P],
             "licv_gemm_flow_available": [],
             "licv_gemm_select": [I],
             "licv_gemm_stagger": [I],

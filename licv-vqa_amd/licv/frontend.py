@@ -72,3 +72,33 @@ def merge_image_rows_(h: torch.Tensor, input_ids: torch.Tensor, image_rows: torc
     check(_lib.lib().licv_merge_image_rows(_p(h), _p(ids), _p(image_rows), _p(scratch), C.c_void_p(scratch.data_ptr() + 4 * M), M, dim,
                                            image_rows.shape[0], int(image_token_id), _stream(h)))
     return scratch[M:]
+
+
+# ------------------------------------------------------------------------------------------ image input (uint8 -> normalised bf16)
+IDEFICS_MEAN = (0.48145466, 0.4578275, 0.40821073)        # hf:idefics/image_processing_idefics.py IDEFICS_STANDARD_MEAN / _STD
+IDEFICS_STD = (0.26862954, 0.26130258, 0.27577711)
+IDEFICS2_MEAN = IDEFICS2_STD = (0.5, 0.5, 0.5)              # hf:idefics2 image processor (IMAGENET_STANDARD_MEAN / _STD)
+
+
+def preprocess_images(u8: torch.Tensor, mean=IDEFICS_MEAN, std=IDEFICS_STD, rescale: float = 1 / 255,
+                      valid_hw: Optional[torch.Tensor] = None, want_mask: bool = False, out: Optional[torch.Tensor] = None,
+                      mask_out: Optional[torch.Tensor] = None):
+    """u8 (n, H, W, 3) uint8 on the GPU -> (pixel_values (n, 3, H, W) bf16, pixel_attention_mask (n, H, W) bool or None): the
+    rescale + normalise + channels-first of the HF image processors (and, with `valid_hw` (n, 2) int32 = real height / width of each
+    image inside its padded H x W, Idefics2's zero padding and mask), as one HIP kernel (csrc/frontend.hip).  Resizing stays where
+    the reference has it: on the host, in the dataset workers."""
+    assert u8.is_cuda and u8.dtype == torch.uint8 and u8.dim() == 4 and u8.shape[-1] == 3 and u8.is_contiguous()
+    n, H, W, _ = u8.shape
+    dev = u8.device
+    if out is None:
+        out = torch.empty((n, 3, H, W), dtype=torch.bfloat16, device=dev)
+    m = None
+    if want_mask or mask_out is not None:
+        m = mask_out if mask_out is not None else torch.empty((n, H, W), dtype=torch.uint8, device=dev)
+    hw = None
+    if valid_hw is not None:
+        hw = valid_hw.to(device=dev, dtype=torch.int32).contiguous()
+        assert hw.shape == (n, 2)
+    mean3, std3 = (C.c_float * 3)(*[float(x) for x in mean]), (C.c_float * 3)(*[float(x) for x in std])
+    check(_lib.lib().licv_preprocess_images(_p(u8), _p(hw), _p(out), _p(m), n, H, W, C.c_double(float(rescale)), mean3, std3, _stream(u8)))
+    return out, (m.view(torch.bool) if m is not None else None)

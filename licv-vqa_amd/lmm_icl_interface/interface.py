@@ -126,6 +126,20 @@ class IdeficsInterface(LMMInterface):
                              "the tokenizer and the model configuration do not belong together")
         return tid
 
+    # ------------------------------------------------------------------ device-side image input
+    image_norm = ("IDEFICS_MEAN", "IDEFICS_STD")             # names in licv.frontend; Idefics2Interface overrides
+
+    def image_feeder(self, max_images: int, height: Optional[int] = None, width: Optional[int] = None, with_mask: bool = False):
+        """The pinned, double-buffered uint8 -> normalised-bf16 image path for this model (licv.image_feeder.ImageFeeder): what
+        `processor.prepare_input` + `.to(device)` do for the image half of a batch (ref:icv_src/icv_datamodule.py:80-124,
+        ref:inference.py:277-278), with the bytes crossing PCIe as uint8 and the normalisation done by a HIP kernel on a side
+        stream.  Default size: the vision tower's image size."""
+        from licv import frontend
+        from licv.image_feeder import ImageFeeder
+        side = getattr(self.arch, "v_image", 224)
+        return ImageFeeder(self._device, max_images, height or side, width or side, getattr(frontend, self.image_norm[0]),
+                           getattr(frontend, self.image_norm[1]), with_mask=with_mask)
+
     def _image_mask(self, input_ids, pixel_values, image_attention_mask):
         """image_attention_mask as processor.prepare_input builds it (hf:idefics/processing_idefics.py:89-133) when the caller
         did not pass one: from input_ids, on the device (licv.frontend, csrc/frontend.hip)."""
@@ -218,6 +232,7 @@ class IdeficsInterface(LMMInterface):
 class Idefics2Interface(IdeficsInterface):
     """Idefics2Interface(model_name_or_path, precision, device, prompt_manager, instruction, image_field, label_field)
     (ref:utils.py:68-78).  Hook sites are the text layers' MLP branches (ref:config/lmm/idefics2-8B-base.yaml:8)."""
+    image_norm = ("IDEFICS2_MEAN", "IDEFICS2_STD")
 
     HOOK_SITE = re.compile(r"^model\.model\.text_model\.layers\.(\d+)\.mlp$")
 

@@ -29,3 +29,19 @@ def image_attention_mask(input_ids: torch.Tensor, image_token_id: int, eod_token
     mask = torch.nn.functional.one_hot(inc, num_classes=n_images)
     mask[neg, :] = 0
     return mask
+
+
+def preprocess_images(u8, mean, std, rescale=1 / 255, valid_hw=None):
+    """uint8 (n, H, W, 3) numpy -> (float32 (n, 3, H, W), mask (n, H, W) int64): hf:image_transforms.py rescale (:118-122:
+    f32(f64(u8) * scale)) then normalize (:437: (x - f32 mean) / f32 std), channels first; pixels outside an image's valid
+    (h, w) are zero with mask 0 (hf:idefics2 image processor's padding).  Pinned by tests/golden/g17_image_preprocess.npz."""
+    import numpy as np
+    x = (u8.astype(np.float64) * rescale).astype(np.float32)
+    y = ((x - np.asarray(mean, dtype=np.float32)) / np.asarray(std, dtype=np.float32)).transpose(0, 3, 1, 2)
+    n, _, H, W = y.shape
+    mask = np.ones((n, H, W), dtype=np.int64)
+    if valid_hw is not None:
+        yy, xx = np.arange(H)[None, :, None], np.arange(W)[None, None, :]
+        mask = ((yy < valid_hw[:, 0, None, None]) & (xx < valid_hw[:, 1, None, None])).astype(np.int64)
+        y = y * mask[:, None].astype(np.float32)
+    return np.ascontiguousarray(y), mask

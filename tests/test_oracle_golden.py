@@ -376,3 +376,17 @@ def test_oracle_frontend_rules_match_hf_fixture(golden):
         pos = (bh[:, :, None] * n_side + bw[:, None, :]).reshape(pm.shape[0], -1)
         pos = torch.where(pm.view(pm.shape[0], -1), pos, torch.zeros_like(pos))
         assert torch.equal(pos, T(z[f"v_{tag}_position_ids"]))
+
+
+def test_oracle_image_preprocess_matches_hf_image_processor(golden):
+    """g17: HF's IdeficsImageProcessorPil on seeded uint8 images (resize off); transformers.image_transforms rescale / normalize with
+    the Idefics2 mean / std and padding rule.  The oracle's numpy restatement reproduces both bit for bit in float32."""
+    import numpy as np
+    from oracle import frontend_ref as F
+    z = golden("g17_image_preprocess")
+    y, m = F.preprocess_images(z["idefics_u8"], z["idefics_mean"], z["idefics_std"], float(z["idefics_rescale"]))
+    assert np.array_equal(y, z["idefics_f32"]) and int(m.min()) == 1
+    u = z["idefics2_u8"]
+    B, N, H, W = u.shape[:4]
+    y2, m2 = F.preprocess_images(u.reshape(B * N, H, W, 3), (0.5,) * 3, (0.5,) * 3, 1 / 255, z["idefics2_hw"].reshape(B * N, 2))
+    assert np.array_equal(y2.reshape(B, N, 3, H, W), z["idefics2_f32"]) and np.array_equal(m2.reshape(B, N, H, W), z["idefics2_mask"])

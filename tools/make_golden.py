@@ -677,6 +677,54 @@ def g16_generate_idefics2_bf16_stable():
     np.savez_compressed(OUT / "g16_generate_idefics2_bf16_stable.npz", **out)
 
 
+def g17_image_preprocess():
+    """f2, second half: what `processor.prepare_input` does to an image before the model sees it (ref:icv_src/icv_datamodule.py:80-124
+    through lmm_icl_interface -> the HF image processors): uint8 HWC -> rescale by 1/255 -> (x - mean) / std -> CHW float32 [-> the
+    model's bf16].  Idefics: HF's own `IdeficsImageProcessorPil` (resizing off: the dataset side resizes with PIL, a CPU step that
+    stays there) on seeded uint8 images.  Idefics2: `Idefics2ImageProcessorPil` cannot be constructed here (it asks for torchvision,
+    which is not installed: an ordinary ImportError), so the fixture uses the two numpy functions it calls,
+    `transformers.image_transforms.rescale` and `.normalize`, with its mean / std (0.5) and its padding rule (zeros to the right and
+    below up to the batch maximum, pixel_attention_mask = 1 on real pixels) restated from hf:idefics2/image_processing_pil_idefics2.py."""
+    from transformers.image_transforms import normalize, rescale
+    from transformers.models.idefics.image_processing_pil_idefics import IdeficsImageProcessorPil
+    rng = np.random.default_rng(1717)
+    out = {}
+    proc = IdeficsImageProcessorPil(do_resize=False)
+    imgs = [rng.integers(0, 256, (56, 56, 3)).astype(np.uint8) for _ in range(6)]
+    imgs[0][:] = np.arange(256, dtype=np.uint8).repeat(37)[: 56 * 56 * 3].reshape(56, 56, 3)      # every byte value in every channel
+    imgs[1][..., 0] = np.arange(56 * 56).reshape(56, 56) % 256
+    imgs[1][..., 1] = (np.arange(56 * 56).reshape(56, 56) * 7 + 3) % 256
+    imgs[1][..., 2] = 255 - imgs[1][..., 0]
+    pv = proc.preprocess(imgs, return_tensors="pt")
+    out["idefics_u8"] = np.stack(imgs)
+    out["idefics_f32"] = pv.numpy().astype(np.float32)
+    out["idefics_mean"] = np.array(proc.image_mean, dtype=np.float64)
+    out["idefics_std"] = np.array(proc.image_std, dtype=np.float64)
+    out["idefics_rescale"] = np.array(proc.rescale_factor, dtype=np.float64)
+    # Idefics2: ragged images, (B = 2, N = 2) with one missing image (an all-zero padding image with an all-zero mask)
+    mean2 = std2 = [0.5, 0.5, 0.5]
+    sizes = [[(56, 42), (28, 70)], [(42, 42), None]]
+    Hm, Wm = 56, 70
+    u8 = np.zeros((2, 2, Hm, Wm, 3), dtype=np.uint8)
+    hw = np.zeros((2, 2, 2), dtype=np.int32)
+    exp = np.zeros((2, 2, 3, Hm, Wm), dtype=np.float32)
+    mask = np.zeros((2, 2, Hm, Wm), dtype=np.int64)
+    for b in range(2):
+        for n in range(2):
+            if sizes[b][n] is None:
+                continue
+            h, w = sizes[b][n]
+            im = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+            u8[b, n, :h, :w] = im
+            hw[b, n] = (h, w)
+            x = normalize(rescale(im, 1 / 255), mean2, std2)                   # (h, w, 3) float32
+            exp[b, n, :, :h, :w] = np.transpose(x, (2, 0, 1))
+            mask[b, n, :h, :w] = 1
+    out["idefics2_u8"], out["idefics2_hw"] = u8, hw
+    out["idefics2_f32"], out["idefics2_mask"] = exp, mask
+    np.savez_compressed(OUT / "g17_image_preprocess.npz", **out)
+
+
 def g13_frontend():
     """Processor-side integer rules, produced by the HF code itself:
     (a) Idefics image_attention_mask: transformers' image_attention_mask_for_packed_input_ids_pt + incremental_to_binary_attention_mask
@@ -1018,10 +1066,10 @@ def main():
     import icv_src.icv_model.icv_intervention as _ri
     assert _ri.__file__.startswith(str(REF)), _ri.__file__
     torch.set_num_threads(4)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17"]
     fns = dict(g1=g1_encoder, g2=g2_intervention, g3=g3_idefics, g4=g4_idefics2, g5=g5_generate, g6=g6_loss, g7=g7_optim, g8=g8_generate_idefics2, g9=g9_loss_idefics2, g10=g10_hard_loss,
                g11=g11_generate_bf16, g12=g12_generate_idefics2_bf16, g13=g13_frontend, g14=g14_vqa_metric,
-               g15=g15_generate_bf16_stable, g16=g16_generate_idefics2_bf16_stable)
+               g15=g15_generate_bf16_stable, g16=g16_generate_idefics2_bf16_stable, g17=g17_image_preprocess)
     for w in which:
         print("generating", w, flush=True)
         fns[w]()
