@@ -188,8 +188,9 @@ typedef struct {
 } licv_attn_args;
 
 int licv_attn_fwd(const licv_attn_args* a, void* stream);
-/* tests / A-B timing: 1 = always the tiled kernel (never the resident-K/V variant used for short unmasked keys) */
-int licv_attn_select(int force_tiled);
+/* tests / A-B timing: bit 0 = always the tiled kernel (never the resident-K/V variant used for short unmasked keys);
+ * bit 1 = the resident variant walks its items in blockIdx order instead of grouping consecutive heads on one XCD */
+int licv_attn_select(int mode);
 
 /* ---- small data-movement kernels ---- */
 /* hf:idefics/modeling_idefics.py:230-267 IdeficsDecoupledEmbedding (ids >= vocab -> additional table) */

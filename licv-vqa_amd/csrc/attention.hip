@@ -117,6 +117,146 @@ __device__ __forceinline__ void attn_tile(const char* kt, const char* vt, const 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The key tiles of one 16-query sub-tile against K/V resident in LDS, hand-pipelined.  attn_tile above leaves the
+// order of LDS reads to the compiler, which emits  ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma  twenty times per tile: every
+// LDS latency sits on the wave's critical path (rocprofv3 on the ViT shape: waves parked 56 % of their cycles, MFMA busy 15 %,
+// ~4000 cycles per tile for ~350 cycles of MFMA; profiles/r03_attn_pmc.txt).  Here every fragment of a phase is in registers
+// before the phase starts:
+//   QK   : the 4 x DPK/32 K fragments were read ahead of the previous tile's PV               (12 ds_read_b128 at 96)
+//   V^T  : the 2 x DPV/16 x 2 transposing reads are issued before QK and land behind QK and the softmax    (20 at 80)
+//   PV   : consumes them; the next tile's K reads are already in flight.
+// Arithmetic and its order are those of attn_tile<.., 4> (same MFMA k-step order per accumulator, same sum order):
+// results are bit-identical to it.  The row max travels over v_permlane{32,16}_swap (VALU) instead of ds_bpermute (an LDS
+// round trip that would also drain the V^T reads in flight).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float max3_f32(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float max_f32(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// max over the four lanes {ql, ql + 16, ql + 32, ql + 48}, result in all of them
+__device__ __forceinline__ float max_over_groups(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto a = __builtin_amdgcn_permlane32_swap(u, u, false, false);      // a[0] = low half twice, a[1] = high half twice
+    const float h = max_f32(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const unsigned v = __float_as_uint(h);
+    const auto b = __builtin_amdgcn_permlane16_swap(v, v, false, false);      // b[0] = even rows twice, b[1] = odd rows twice
+    return max_f32(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
+// One tile of the pipelined walk: NST live 16-key sub-tiles (4 = a full tile), MASKED = keys past Sk are cut (ragged tile),
+// NEXTK = read the K fragments of the tile at `kn` for the next call while this tile's softmax / PV run.
+template <int DPK, int DPV, int NST, bool MASKED, bool NEXTK>
+__device__ __forceinline__ void attn_tile_pipe(bf16x8 (&kf)[4][DPK / 32], const char* vt, const char* kn, const bf16x8 (&qf)[DPK / 32],
+                                               floatx4 (&oacc)[DPV / 16], float& m_run, float& l_run, float sc, int g, int keys_left) {
+    constexpr int VSTR = lds_stride(DPV), KSTR = lds_stride(DPK);
+    constexpr int KS = DPK / 32, DT = DPV / 16, NS2 = (NST + 1) / 2;
+    // V^T fragments of this tile: in flight across QK and the softmax
+    bf16x4 vlo[NS2][DT], vhi[NS2][DT];
+#pragma unroll
+    for (int s2 = 0; s2 < NS2; ++s2)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            vlo[s2][dt] = lds_read_tr(vt + (s2 * 32) * VSTR + dt * 32);
+            vhi[s2][dt] = lds_read_tr(vt + (s2 * 32 + 16) * VSTR + dt * 32);
+        }
+    __builtin_amdgcn_sched_barrier(0);
+    // S^T = K.Q^T : k-step outer, so consecutive MFMAs write different accumulators
+    floatx4 s[4];
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+        s[st] = st < NST ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[st][0], qf[0], floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0)
+                         : floatx4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int ks = 1; ks < KS; ++ks)
+#pragma unroll
+        for (int st = 0; st < NST; ++st) s[st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[st][ks], qf[ks], s[st], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    // The max tree below is inline asm (fmaxf would first canonicalise each of the 16 MFMA outputs: 16 extra v_max), which the
+    // compiler's hazard recogniser does not look into: an MFMA result read by VALU needs software wait states (no interlock;
+    // without them the max read stale registers now and then - results 1 ulp off and different from run to run).
+    asm volatile("s_nop 15");
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (MASKED) {
+#pragma unroll
+        for (int st = 0; st < NST; ++st)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (st * 16 + g * 4 + r >= keys_left) s[st][r] = -INFINITY;
+    }
+    // online softmax, log2 domain
+    float tmax = max3_f32(max3_f32(s[0][0], s[0][1], s[0][2]), max3_f32(s[0][3], s[1][0], s[1][1]), max3_f32(s[1][2], s[1][3], s[2][0]));
+    tmax = max3_f32(tmax, max3_f32(s[2][1], s[2][2], s[2][3]), max3_f32(s[3][0], s[3][1], max_f32(s[3][2], s[3][3])));
+    tmax = max_over_groups(tmax);
+    const float m_new = max_f32(m_run, tmax * sc);
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+    float psum = 0.f;
+    bf16x8 pf[2];
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float p = (st < NST) ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[st][r], sc, -m_use)) : 0.f;
+            psum += p;
+            pf[st >> 1][(st & 1) * 4 + r] = (__bf16)p;
+        }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < DT; ++i) oacc[i] *= alpha;
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (NEXTK) {
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) kf[st][ks] = *reinterpret_cast<const bf16x8*>(kn + st * 16 * KSTR + ks * 64);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // O^T += V^T . P^T
+#pragma unroll
+    for (int s2 = 0; s2 < NS2; ++s2)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            bf16x8 vf;
+            vf[0] = vlo[s2][dt][0]; vf[1] = vlo[s2][dt][1]; vf[2] = vlo[s2][dt][2]; vf[3] = vlo[s2][dt][3];
+            vf[4] = vhi[s2][dt][0]; vf[5] = vhi[s2][dt][1]; vf[6] = vhi[s2][dt][2]; vf[7] = vhi[s2][dt][3];
+            oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[s2], oacc[dt], 0, 0, 0);
+        }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// All key tiles of one 16-query sub-tile: nfull full tiles, then the ragged one with `nst_last` live sub-tiles (0 = none).
+// The K fragments of a tile are read ahead of the previous tile's PV; the LDS allocation covers the read-ahead of the (possibly
+// ragged, possibly absent) tile after the last full one: rows past skp of the K region fall into the V region, never used.
+template <int DPK, int DPV>
+__device__ __forceinline__ void attn_unit_pipe(const char* sK, const char* sV, int nfull, int nst_last, int Sk, const bf16x8 (&qf)[DPK / 32],
+                                               floatx4 (&oacc)[DPV / 16], float& m_run, float& l_run, float sc, int g, int ql) {
+    constexpr int KSTR = lds_stride(DPK), VSTR = lds_stride(DPV);
+    constexpr int KS = DPK / 32;
+    const char* kp = sK + ql * KSTR + g * 16;                                                  // + (tile * 64 + st * 16) rows + ks * 64 bytes
+    const char* vp = sV + (g * 4 + (ql >> 2)) * VSTR + (ql & 3) * 8;                           // + (tile * 64 + s2 * 32 [+ 16]) rows + dt * 32 bytes
+    bf16x8 kf[4][KS];
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) kf[st][ks] = *reinterpret_cast<const bf16x8*>(kp + st * 16 * KSTR + ks * 64);
+    for (int t = 0; t < nfull; ++t)
+        attn_tile_pipe<DPK, DPV, 4, false, true>(kf, vp + t * ATT_KB * VSTR, kp + (t + 1) * ATT_KB * KSTR, qf, oacc, m_run, l_run, sc, g, 64);
+    const char* vt = vp + nfull * ATT_KB * VSTR;
+    const int left = Sk - nfull * ATT_KB;
+    if (nst_last == 1)      attn_tile_pipe<DPK, DPV, 1, true, false>(kf, vt, nullptr, qf, oacc, m_run, l_run, sc, g, left);
+    else if (nst_last == 2) attn_tile_pipe<DPK, DPV, 2, true, false>(kf, vt, nullptr, qf, oacc, m_run, l_run, sc, g, left);
+    else if (nst_last == 3) attn_tile_pipe<DPK, DPV, 3, true, false>(kf, vt, nullptr, qf, oacc, m_run, l_run, sc, g, left);
+    else if (nst_last == 4) attn_tile_pipe<DPK, DPV, 4, true, false>(kf, vt, nullptr, qf, oacc, m_run, l_run, sc, g, left);
+}
+
 template <int DPK, int DPV, typename MaskF>
 __device__ __forceinline__ void attn_tile_n(int nst, const char* kt, const char* vt, const bf16x8 (&qf)[DPK / 32],
                                             floatx4 (&oacc)[DPV / 16], float& m_run, float& l_run, float sc, int g, int ql,
@@ -351,124 +491,195 @@ void attn_fwd_k(AttnP a) {
 // of a SIMD drift apart and overlap MFMA with softmax VALU.  The tiled kernel above pays one global-load
 // latency per 64-key tile per 64-query workgroup: 487 us per ViT layer vs the ~60 us of MFMA work in it.
 // ------------------------------------------------------------------------------------------------
-template <int DPK, int DPV, int MAXI>   // MAXI: 16-byte chunks per thread per operand (>= skp * DPK/8 / 512)
+// -DLICV_ATTN_TRACE: lane 0 of every wave of workgroup 0 stamps s_memtime at the phase boundaries of its first items into
+// the buffer given to licv_attn_debug_timestamps ([wave][128] long long); tools/attn_trace.py prints the deltas.
+#ifdef LICV_ATTN_TRACE
+static __device__ long long* g_attn_ts = nullptr;
+#define ATTN_STAMP() do { if (ts && nev < 128) { ts[nev] = (long long)__builtin_readcyclecounter(); } ++nev; } while (0)
+#else
+#define ATTN_STAMP() do { } while (0)
+#endif
+
+template <int DPK, int DPV, int MAXI, bool PIPE>   // MAXI: 16-byte chunks per thread per operand (>= Sk * DPV/8 / 512); PIPE: hand-pipelined tiles
 __global__ __launch_bounds__(512, 2)
-void attn_resident_k(AttnP a, int skp, int n_items) {
+void attn_resident_k(AttnP a, int skp, int n_items, int xcd_map, int stagger) {
     constexpr int KSTR = lds_stride(DPK), VSTR = lds_stride(DPV);
-    constexpr int KCH = DPK / 8, VCH = DPV / 8;
+    constexpr int KS = DPK / 32, DT = DPV / 16;
     extern __shared__ __attribute__((aligned(16))) char rsm[];
     char* sK = rsm;
     char* sV = rsm + skp * KSTR;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform: descriptors stay in SGPRs)
     const int g = lane >> 4, ql = lane & 15;
     const float sc = a.scale * 1.4426950408889634f;
     const int nq = (a.Sq + 15) >> 4;                        // 16-query sub-tiles
     const int ntiles = (a.Sk + ATT_KB - 1) / ATT_KB;
+    const int nfull = a.Sk / ATT_KB;                        // tiles with 64 real keys: no mask, 4 live sub-tiles
+    const int nst_last = nfull < ntiles ? (a.Sk - nfull * ATT_KB + 15) >> 4 : 0;
+    const int G = (int)gridDim.x;
+#ifdef LICV_ATTN_TRACE
+    long long* ts = (g_attn_ts && blockIdx.x == 0 && lane == 0) ? g_attn_ts + wave * 128 : nullptr;
+    int nev = 0;
+#endif
 
-    // persistent over (batch, head) items: K/V of item i+1 travel global -> registers while item i is computed
-    u32x4 rk[MAXI], rv[MAXI];
-    auto fetch = [&](int item) {
-        const int hh = item % a.nh, bb = item / a.nh;
+    // Persistent over (batch, head) items: K/V of item i+1 travel global -> registers while item i is computed.  Only the real
+    // columns travel (DPV/8 16-byte chunks per row, the same (row, chunk) for K and V); the padding (K columns >= DPV, rows >= Sk)
+    // is zeroed once below and never written again.
+    //
+    // Every global access is a BUFFER access outside any branch, lanes that have nothing to move get an out-of-range offset
+    // (loads return zero, stores are dropped, no traffic).  With loads or stores inside exec-masked branches the compiler's waitcnt
+    // pass fell back to s_waitcnt vmcnt(0) - in front of the QK MFMAs of every tile and at every hand-over of Q, i.e. each unit sat
+    // out the full latency of whatever had just been issued (the next Q, the next item's K/V, the stores of the unit before).
+    constexpr int HC = DPV / 8;
+    constexpr uint32_t OOB = 0xFFFFFFFFu;
+    const int nchunk = a.Sk * HC;
+    for (int o = tid * 16; o < skp * (KSTR + VSTR); o += 512 * 16) *reinterpret_cast<u32x4*>(rsm + o) = u32x4{0u, 0u, 0u, 0u};
+    auto rsrc = [](const void* p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0xFFFFFFFF, 0x00020000); };
+    auto fetch = [&](int item, u32x4 (&rk)[MAXI], u32x4 (&rv)[MAXI]) {
+        const bool item_ok = item < n_items;
+        const int it = item_ok ? item : 0;
+        const int hh = it % a.nh, bb = it / a.nh;
         const int kvh = hh / (a.nh / a.nkv);
-        const bf16_t* kbase = a.k + (int64_t)bb * a.kv_bs + (int64_t)kvh * a.hd;
-        const bf16_t* vbase = a.v + (int64_t)bb * a.kv_bs + (int64_t)kvh * a.hd;
+        const auto rsk = rsrc(a.k + (int64_t)bb * a.kv_bs + (int64_t)kvh * a.hd);
+        const auto rsv = rsrc(a.v + (int64_t)bb * a.kv_bs + (int64_t)kvh * a.hd);
 #pragma unroll
         for (int i = 0; i < MAXI; ++i) {
             const int c = tid + i * 512;
-            const int row = c / KCH, ch = c % KCH;
-            u32x4 r = u32x4{0u, 0u, 0u, 0u};
-            if (c < skp * KCH && row < a.Sk && ch * 8 < a.hd) r = *reinterpret_cast<const u32x4*>(kbase + (int64_t)row * a.kv_rs + ch * 8);
-            rk[i] = r;
-        }
-#pragma unroll
-        for (int i = 0; i < MAXI; ++i) {
-            const int c = tid + i * 512;
-            const int row = c / VCH, ch = c % VCH;
-            u32x4 r = u32x4{0u, 0u, 0u, 0u};
-            if (c < skp * VCH && row < a.Sk && ch * 8 < a.hd) r = *reinterpret_cast<const u32x4*>(vbase + (int64_t)row * a.kv_rs + ch * 8);
-            rv[i] = r;
+            const int row = c / HC, ch = c % HC;
+            const bool ok = (int)item_ok & (int)(c < nchunk) & (int)(ch * 8 < a.hd);      // (& not &&: no branches around the loads)
+            const uint32_t off = ok ? (uint32_t)(row * (int)a.kv_rs + ch * 8) * 2u : OOB;
+            rk[i] = __builtin_amdgcn_raw_buffer_load_b128(rsk, off, 0, 0);
+            rv[i] = __builtin_amdgcn_raw_buffer_load_b128(rsv, off, 0, 0);
         }
     };
-    auto park = [&]() {
+    auto park = [&](const u32x4 (&rk)[MAXI], const u32x4 (&rv)[MAXI]) {
 #pragma unroll
         for (int i = 0; i < MAXI; ++i) {
             const int c = tid + i * 512;
-            if (c < skp * KCH) *reinterpret_cast<u32x4*>(sK + (c / KCH) * KSTR + (c % KCH) * 16) = rk[i];
-        }
-#pragma unroll
-        for (int i = 0; i < MAXI; ++i) {
-            const int c = tid + i * 512;
-            if (c < skp * VCH) *reinterpret_cast<u32x4*>(sV + (c / VCH) * VSTR + (c % VCH) * 16) = rv[i];
-        }
-    };
-
-    int item = blockIdx.x;
-    if (item < n_items) { fetch(item); park(); }
-    __syncthreads();
-    for (; item < n_items; item += gridDim.x) {
-    const int head = item % a.nh;
-    const int b = item / a.nh;
-    const int nxt = item + gridDim.x;
-    if (nxt < n_items) fetch(nxt);
-
-    // Q fragments of a unit are fetched one unit ahead (their global-load latency otherwise sits at the head of every unit)
-    auto load_q = [&](int qsub, bf16x8 (&qf)[DPK / 32]) {
-        const int qrow = qsub * 16 + ql;
-        const bf16_t* qp = a.q + (int64_t)b * a.q_bs + (int64_t)qrow * a.q_rs + (int64_t)head * a.hd;
-#pragma unroll
-        for (int ks = 0; ks < DPK / 32; ++ks) {
-            const int d = ks * 32 + g * 8;
-            u32x4 r = u32x4{0u, 0u, 0u, 0u};
-            if (qsub < nq && qrow < a.Sq && d < a.hd) r = *reinterpret_cast<const u32x4*>(qp + d);
-            qf[ks] = *reinterpret_cast<bf16x8*>(&r);
-        }
-    };
-    bf16x8 qf[DPK / 32], qf_next[DPK / 32];
-    load_q(wave, qf_next);
-    const int nfull = a.Sk / ATT_KB;                         // tiles with 64 real keys: no mask, 4 live sub-tiles
-    for (int qsub = wave; qsub < nq; qsub += 8) {
-        const int qrow = qsub * 16 + ql;
-        const bool qok = qrow < a.Sq;
-#pragma unroll
-        for (int ks = 0; ks < DPK / 32; ++ks) qf[ks] = qf_next[ks];
-        load_q(qsub + 8, qf_next);
-        floatx4 oacc[DPV / 16];
-#pragma unroll
-        for (int i = 0; i < DPV / 16; ++i) oacc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
-        float m_run = -INFINITY, l_run = 0.f;
-        auto never = [](int, int) -> bool { return true; };
-        for (int t = 0; t < nfull; ++t)
-            attn_tile<DPK, DPV, 4>(sK + t * ATT_KB * KSTR, sV + t * ATT_KB * VSTR, qf, oacc, m_run, l_run, sc, g, ql, false, never);
-        if (nfull < ntiles) {                               // ragged last tile: keys past Sk never contribute
-            const int key0 = nfull * ATT_KB;
-            auto allowed = [&](int st, int r) -> bool { return key0 + st * 16 + g * 4 + r < a.Sk; };
-            attn_tile_n<DPK, DPV>(min(4, (a.Sk - key0 + 15) >> 4), sK + key0 * KSTR, sV + key0 * VSTR, qf, oacc, m_run, l_run, sc, g, ql, true, allowed);
-        }
-        l_run += __shfl_xor(l_run, 16, 64);
-        l_run += __shfl_xor(l_run, 32, 64);
-        const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
-        if (qok) {
-            bf16_t* op = a.o + ((int64_t)b * a.Sq + qrow) * ((int64_t)a.nh * a.hd) + (int64_t)head * a.hd;
-#pragma unroll
-            for (int dt = 0; dt < DPV / 16; ++dt) {
-                const int d = dt * 16 + g * 4;
-                if (d < a.hd) {
-                    uint2 u;
-                    u.x = (uint32_t)f2bf(oacc[dt][0] * inv) | ((uint32_t)f2bf(oacc[dt][1] * inv) << 16);
-                    u.y = (uint32_t)f2bf(oacc[dt][2] * inv) | ((uint32_t)f2bf(oacc[dt][3] * inv) << 16);
-                    *reinterpret_cast<uint2*>(op + d) = u;
-                }
+            const int row = c / HC, ch = c % HC;
+            if (c < nchunk && ch * 8 < a.hd) {
+                *reinterpret_cast<u32x4*>(sK + row * KSTR + ch * 16) = rk[i];
+                *reinterpret_cast<u32x4*>(sV + row * VSTR + ch * 16) = rv[i];
             }
         }
+    };
+    // Q fragments of the 16-query sub-tile `qsub` of `item` (zeros where there is no such row / column / item)
+    auto load_q = [&](int item, int qsub, bf16x8 (&q)[KS]) {
+        const bool item_ok = item < n_items;
+        const int it = item_ok ? item : 0;
+        const int hh = it % a.nh, bb = it / a.nh;
+        const auto rsq = rsrc(a.q + (int64_t)bb * a.q_bs + (int64_t)hh * a.hd);
+        const int qrow = qsub * 16 + ql;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int d = ks * 32 + g * 8;
+            const bool ok = (int)item_ok & (int)(qrow < a.Sq) & (int)(d < a.hd);
+            const uint32_t off = ok ? (uint32_t)(qrow * (int)a.q_rs + d) * 2u : OOB;
+            const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rsq, off, 0, 0);
+            q[ks] = *reinterpret_cast<const bf16x8*>(&r);
+        }
+    };
+
+    // the heads of one image share cache lines (a head's 160-byte row piece straddles two 128-byte lines): workgroups of one XCD
+    // (blockIdx % 8, its own L2) take CONSECUTIVE items, so both halves of a line are asked of the same L2 at about the same time
+    int item = xcd_map ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
+    // A wave's units form ONE stream over all its items: (item, wave), (item, wave + 8), ..., (item + G, wave), ...; qf holds the
+    // Q fragments of the unit about to run, qf_next those of the unit after it (loaded one unit ahead - across the item boundary
+    // too: the first Q of an item is never requested behind that item's own K/V prefetch burst).
+    bf16x8 qf[KS], qf_next[KS];
+    {
+        u32x4 rk[MAXI], rv[MAXI];
+        fetch(item, rk, rv);
+        load_q(item, wave, qf);
+        const bool one = wave + 8 >= nq;
+        load_q(one ? item + G : item, one ? wave : wave + 8, qf_next);
+        __syncthreads();                        // the zero fill is complete before any real chunk lands on it
+        if (item < n_items) park(rk, rv);
+        __syncthreads();
     }
-    __syncthreads();                            // every wave is done with this item's K/V
-    if (nxt < n_items) park();
-    __syncthreads();
+    for (; item < n_items; item += G) {
+        const int head = item % a.nh;
+        const int b = item / a.nh;
+        const bool more = item + G < n_items;
+        const auto rso = rsrc(a.o + ((int64_t)b * a.Sq * a.nh + head) * a.hd);
+        ATTN_STAMP();                           // item start
+        // SIMD partners (waves w and w + 4) otherwise run their tiles in lockstep - both in the MFMA phase, then both in the softmax
+        if (stagger && wave >= 4) __builtin_amdgcn_s_sleep(8);
+        u32x4 rk[MAXI], rv[MAXI];               // (declared per item: nothing is carried from one item's prefetch into the next)
+        fetch(item + G, rk, rv);
+        int qsub = wave;                        // (nq >= 8: every wave has a unit; do-while so that the park's waits can count on one)
+        do {
+            ATTN_STAMP();                       // unit start
+            floatx4 oacc[DT];
+#pragma unroll
+            for (int i = 0; i < DT; ++i) oacc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+            float m_run = -INFINITY, l_run = 0.f;
+            if constexpr (PIPE) {
+                attn_unit_pipe<DPK, DPV>(sK, sV, nfull, nst_last, a.Sk, qf, oacc, m_run, l_run, sc, g, ql);
+            } else {
+                auto never = [](int, int) -> bool { return true; };
+                for (int t = 0; t < nfull; ++t)
+                    attn_tile<DPK, DPV, 4>(sK + t * ATT_KB * KSTR, sV + t * ATT_KB * VSTR, qf, oacc, m_run, l_run, sc, g, ql, false, never);
+                if (nst_last) {                     // ragged last tile: keys past Sk never contribute
+                    const int key0 = nfull * ATT_KB;
+                    auto allowed = [&](int st, int r) -> bool { return key0 + st * 16 + g * 4 + r < a.Sk; };
+                    attn_tile_n<DPK, DPV>(nst_last, sK + key0 * KSTR, sV + key0 * VSTR, qf, oacc, m_run, l_run, sc, g, ql, true, allowed);
+                }
+            }
+            ATTN_STAMP();                       // tiles done
+            l_run += __shfl_xor(l_run, 16, 64);
+            l_run += __shfl_xor(l_run, 32, 64);
+            const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+            const int qrow = qsub * 16 + ql;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const int d = dt * 16 + g * 4;
+                typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+                u32x2 u;
+                u.x = (uint32_t)f2bf(oacc[dt][0] * inv) | ((uint32_t)f2bf(oacc[dt][1] * inv) << 16);
+                u.y = (uint32_t)f2bf(oacc[dt][2] * inv) | ((uint32_t)f2bf(oacc[dt][3] * inv) << 16);
+                const bool ok = (int)(qrow < a.Sq) & (int)(d < a.hd);
+                const uint32_t off = ok ? (uint32_t)(qrow * (a.nh * a.hd) + d) * 2u : OOB;
+                __builtin_amdgcn_raw_buffer_store_b64(u, rso, off, 0, 0);
+            }
+            // hand over the Q of the next unit in the stream, ask for the one after it
+            int n2_q = qsub + 8, n2_item = item;                // the next unit in the stream ...
+            if (n2_q >= nq) { n2_q = wave; n2_item += G; }
+            n2_q += 8;                                          // ... and the one after it
+            if (n2_q >= nq) { n2_q = wave; n2_item += G; }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                // (a real move, here: as a plain assignment the copy is a phi, materialised at the loop's end behind the loads below,
+                //  which then land in other registers and are copied once more - after s_waitcnt vmcnt(0) on loads just issued)
+                u32x4 t = *reinterpret_cast<const u32x4*>(&qf_next[ks]), r;
+                asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
+                             : "=&v"(r.x), "=&v"(r.y), "=&v"(r.z), "=&v"(r.w) : "v"(t.x), "v"(t.y), "v"(t.z), "v"(t.w));
+                qf[ks] = *reinterpret_cast<const bf16x8*>(&r);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            load_q(n2_item, n2_q, qf_next);
+            qsub += 8;
+        } while (qsub < nq);
+        ATTN_STAMP();                           // units done
+        __syncthreads();                        // every wave is done with this item's K/V
+        ATTN_STAMP();                           // barrier passed
+        if (more) park(rk, rv);
+        ATTN_STAMP();                           // parked
+        __syncthreads();
     }
 }
 
-static int g_attn_force_tiled = 0;      // tests / A-B timing: 1 = never use the resident-K/V variant
-extern "C" int licv_attn_select(int force_tiled) { g_attn_force_tiled = force_tiled; return LICV_OK; }
+#ifdef LICV_ATTN_TRACE
+extern "C" int licv_attn_debug_timestamps(void* dev_buffer) {
+    long long* p = (long long*)dev_buffer;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_attn_ts), &p, sizeof(p)) == hipSuccess ? LICV_OK : LICV_E_HIP;
+}
+#endif
+
+static int g_attn_force_tiled = 0;      // tests / A-B timing: bit 0 = never use the resident-K/V variant
+static int g_attn_plain_items = 0;      //                     bit 1 = resident variant takes items in blockIdx order (no XCD grouping)
+static int g_attn_stagger = 1;          //                     bit 3 = no stagger of the SIMD partners (waves 4-7 start each item ~500 cycles late)
+static int g_attn_no_pipe = 0;          //                     bit 2 = resident variant leaves the LDS read schedule to the compiler (attn_tile)
+extern "C" int licv_attn_select(int mode) { g_attn_force_tiled = mode & 1; g_attn_plain_items = (mode >> 1) & 1; g_attn_no_pipe = (mode >> 2) & 1; g_attn_stagger = !((mode >> 3) & 1); return LICV_OK; }
 
 extern "C" int licv_attn_fwd(const licv_attn_args* x, void* stream) {
     LICV_CHECK_ARG(x && x->q && x->k && x->v && x->o, "attn_fwd: null pointer");
@@ -495,18 +706,25 @@ extern "C" int licv_attn_fwd(const licv_attn_args* x, void* stream) {
         const int skp = (int)((x->Sk + 15) / 16 * 16) + 16;       // the transposing V read touches one 16-row group past the last real one
         const int dpk = hd0 <= 64 ? 64 : 96, dpv = hd0 <= 64 ? 64 : (hd0 <= 80 ? 80 : 96);
         const int64_t lds = (int64_t)skp * (lds_stride(dpk) + lds_stride(dpv));
-        if (lds <= 160 * 1024 && (int64_t)skp * 12 <= 5120) {
+        const int64_t chunks = x->Sk * (dpv / 8);                 // 16-byte chunks per operand per item, 512 threads
+        // (the kernel addresses one (batch, head) slice with 32-bit byte offsets from its base)
+        const bool fits32 = x->Sq * x->q_rs * 2 < (1ll << 31) && x->Sk * x->kv_rs * 2 < (1ll << 31) && x->Sq * x->n_heads * x->head_dim * 2 < (1ll << 31);
+        if (lds <= 160 * 1024 && chunks <= 10 * 512 && fits32) {
             const int n_items = (int)(x->B * x->n_heads);
             const dim3 rgrid((unsigned)(n_items < 256 ? n_items : 256)), rblock(512);
             hipStream_t rst = (hipStream_t)stream;
-            const bool small = (int64_t)skp * (dpk / 8) <= 8 * 512;
-#define RES_LAUNCH(DK, DV, MI) do { static bool attr_##DK##_##DV##_##MI = false; \
-                if (!attr_##DK##_##DV##_##MI) { (void)hipFuncSetAttribute((const void*)attn_resident_k<DK, DV, MI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_##DK##_##DV##_##MI = true; } \
-                attn_resident_k<DK, DV, MI><<<rgrid, rblock, lds, rst>>>(p, skp, n_items); } while (0)
-            if (dpk == 64)      { if (small) RES_LAUNCH(64, 64, 8); else RES_LAUNCH(64, 64, 10); }
-            else if (dpv == 80) { if (small) RES_LAUNCH(96, 80, 8); else RES_LAUNCH(96, 80, 10); }
-            else                { if (small) RES_LAUNCH(96, 96, 8); else RES_LAUNCH(96, 96, 10); }
+            const int mi = chunks <= 6 * 512 ? 6 : (chunks <= 8 * 512 ? 8 : 10);
+            const int xcd_map = (rgrid.x % 8 == 0 && !g_attn_plain_items) ? 1 : 0;
+#define RES_LAUNCH1(DK, DV, MI, PP) do { static bool attr_##DK##_##DV##_##MI##_##PP = false; \
+                if (!attr_##DK##_##DV##_##MI##_##PP) { (void)hipFuncSetAttribute((const void*)attn_resident_k<DK, DV, MI, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_##DK##_##DV##_##MI##_##PP = true; } \
+                attn_resident_k<DK, DV, MI, PP><<<rgrid, rblock, lds, rst>>>(p, skp, n_items, xcd_map, g_attn_stagger); } while (0)
+// (the pipelined walker holds 88 more fragment registers: with 8 or 10 prefetch chunks per operand it spills at 96 columns)
+#define RES_LAUNCH(DK, DV, MI) do { if (g_attn_no_pipe || MI > (DK == 64 ? 8 : 6)) RES_LAUNCH1(DK, DV, MI, false); else RES_LAUNCH1(DK, DV, MI, true); } while (0)
+            if (dpk == 64)      { if (mi == 6) RES_LAUNCH(64, 64, 6); else if (mi == 8) RES_LAUNCH(64, 64, 8); else RES_LAUNCH(64, 64, 10); }
+            else if (dpv == 80) { if (mi == 6) RES_LAUNCH(96, 80, 6); else if (mi == 8) RES_LAUNCH(96, 80, 8); else RES_LAUNCH(96, 80, 10); }
+            else                { if (mi == 6) RES_LAUNCH(96, 96, 6); else if (mi == 8) RES_LAUNCH(96, 96, 8); else RES_LAUNCH(96, 96, 10); }
 #undef RES_LAUNCH
+#undef RES_LAUNCH1
             LICV_LAUNCH_CHECK();
             return LICV_OK;
         }

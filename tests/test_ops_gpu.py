@@ -407,12 +407,14 @@ def test_attention_self(hd, mode):
     _attn_close(out, ref)
 
 
-@pytest.mark.parametrize("hd,S,Sq", [(80, 257, 257), (96, 321, 64), (64, 200, 130)])
-def test_attention_resident_kv_variant_matches_tiled_and_reference(hd, S, Sq):
+@pytest.mark.parametrize("hd,S,Sq,B,nh", [(80, 257, 257, 3, 4), (96, 321, 64, 3, 4), (64, 200, 130, 3, 4), (80, 257, 257, 21, 16), (72, 193, 140, 5, 8),
+                                          (96, 320, 321, 2, 4), (64, 577, 577, 2, 3), (48, 128, 128, 1, 2)])
+def test_attention_resident_kv_variant_matches_tiled_and_reference(hd, S, Sq, B, nh):
     """Short unmasked key sequences (ViT 257 tokens, perceiver 64 latents over 321 keys) take the resident-K/V
-    kernel; it must agree with the tiled kernel and the fp32 reference."""
+    kernel; it must agree with the tiled kernel and the fp32 reference.  Its three schedules — hand-pipelined LDS reads (default),
+    compiler-scheduled reads (select bit 2), items in blockIdx order (bit 1) — do the same arithmetic in the same order and must
+    agree bit for bit; 21 x 16 = 336 items exercise the persistent loop (more items than workgroups, K/V prefetch, ragged last round)."""
     from licv import _lib
-    B, nh = 3, 4
     H = nh * hd
     q = torch.randn(B, Sq, H, generator=g(52)).to(torch.bfloat16)
     kv = torch.randn(B, S, 2 * H, generator=g(53)).to(torch.bfloat16)
@@ -421,14 +423,16 @@ def test_attention_resident_kv_variant_matches_tiled_and_reference(hd, S, Sq):
     dq, dkv = q.to(DEV), kv.to(DEV)
     outs = []
     try:
-        for force_tiled in (0, 1):
-            _lib.lib().licv_attn_select(force_tiled)
+        for mode in (0, 1, 2, 4, 6):
+            _lib.lib().licv_attn_select(mode)
             outs.append(ops().attention(dq, dkv, dkv.view(-1)[H:], B, Sq, S, nh, nh, hd, Sq * H, H, S * 2 * H, 2 * H, hd ** -0.5, 0).clone())
     finally:
         _lib.lib().licv_attn_select(0)
     for o in outs:
         _attn_close(o, ref)
     assert (outs[0].float() - outs[1].float()).abs().max() <= 2 ** -7 * ref.abs().max()
+    for o in outs[2:]:
+        assert torch.equal(o, outs[0])
 
 
 def test_attention_cross_image_mask_and_gqa_decode():
