@@ -502,7 +502,7 @@ static __device__ long long* g_attn_ts = nullptr;
 
 template <int DPK, int DPV, int MAXI, bool PIPE>   // MAXI: 16-byte chunks per thread per operand (>= Sk * DPV/8 / 512); PIPE: hand-pipelined tiles
 __global__ __launch_bounds__(512, 2)
-void attn_resident_k(AttnP a, int skp, int n_items, int xcd_map, int stagger) {
+void attn_resident_k(AttnP a, int skp, int n_items, int xcd_map) {
     constexpr int KSTR = lds_stride(DPK), VSTR = lds_stride(DPV);
     constexpr int KS = DPK / 32, DT = DPV / 16;
     extern __shared__ __attribute__((aligned(16))) char rsm[];
@@ -602,8 +602,6 @@ void attn_resident_k(AttnP a, int skp, int n_items, int xcd_map, int stagger) {
         const bool more = item + G < n_items;
         const auto rso = rsrc(a.o + ((int64_t)b * a.Sq * a.nh + head) * a.hd);
         ATTN_STAMP();                           // item start
-        // SIMD partners (waves w and w + 4) otherwise run their tiles in lockstep - both in the MFMA phase, then both in the softmax
-        if (stagger && wave >= 4) __builtin_amdgcn_s_sleep(8);
         u32x4 rk[MAXI], rv[MAXI];               // (declared per item: nothing is carried from one item's prefetch into the next)
         fetch(item + G, rk, rv);
         int qsub = wave;                        // (nq >= 8: every wave has a unit; do-while so that the park's waits can count on one)
@@ -677,9 +675,8 @@ extern "C" int licv_attn_debug_timestamps(void* dev_buffer) {
 
 static int g_attn_force_tiled = 0;      // tests / A-B timing: bit 0 = never use the resident-K/V variant
 static int g_attn_plain_items = 0;      //                     bit 1 = resident variant takes items in blockIdx order (no XCD grouping)
-static int g_attn_stagger = 1;          //                     bit 3 = no stagger of the SIMD partners (waves 4-7 start each item ~500 cycles late)
 static int g_attn_no_pipe = 0;          //                     bit 2 = resident variant leaves the LDS read schedule to the compiler (attn_tile)
-extern "C" int licv_attn_select(int mode) { g_attn_force_tiled = mode & 1; g_attn_plain_items = (mode >> 1) & 1; g_attn_no_pipe = (mode >> 2) & 1; g_attn_stagger = !((mode >> 3) & 1); return LICV_OK; }
+extern "C" int licv_attn_select(int mode) { g_attn_force_tiled = mode & 1; g_attn_plain_items = (mode >> 1) & 1; g_attn_no_pipe = (mode >> 2) & 1; return LICV_OK; }
 
 extern "C" int licv_attn_fwd(const licv_attn_args* x, void* stream) {
     LICV_CHECK_ARG(x && x->q && x->k && x->v && x->o, "attn_fwd: null pointer");
@@ -717,7 +714,7 @@ extern "C" int licv_attn_fwd(const licv_attn_args* x, void* stream) {
             const int xcd_map = (rgrid.x % 8 == 0 && !g_attn_plain_items) ? 1 : 0;
 #define RES_LAUNCH1(DK, DV, MI, PP) do { static bool attr_##DK##_##DV##_##MI##_##PP = false; \
                 if (!attr_##DK##_##DV##_##MI##_##PP) { (void)hipFuncSetAttribute((const void*)attn_resident_k<DK, DV, MI, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_##DK##_##DV##_##MI##_##PP = true; } \
-                attn_resident_k<DK, DV, MI, PP><<<rgrid, rblock, lds, rst>>>(p, skp, n_items, xcd_map, g_attn_stagger); } while (0)
+                attn_resident_k<DK, DV, MI, PP><<<rgrid, rblock, lds, rst>>>(p, skp, n_items, xcd_map); } while (0)
 // (the pipelined walker holds 88 more fragment registers: with 8 or 10 prefetch chunks per operand it spills at 96 columns)
 #define RES_LAUNCH(DK, DV, MI) do { if (g_attn_no_pipe || MI > (DK == 64 ? 8 : 6)) RES_LAUNCH1(DK, DV, MI, false); else RES_LAUNCH1(DK, DV, MI, true); } while (0)
             if (dpk == 64)      { if (mi == 6) RES_LAUNCH(64, 64, 6); else if (mi == 8) RES_LAUNCH(64, 64, 8); else RES_LAUNCH(64, 64, 10); }
