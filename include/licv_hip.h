@@ -161,6 +161,10 @@ int licv_gemm_flow_available(void);
 int licv_probe_mfma_loop(void* sink_f32, int blocks, int iters, void* stream);
 /* semantics probe: one wave writes {a', b'} = v_permlane16_swap(a = lane, b = 100 + lane) to out[2*lane], out[2*lane+1] (uint32) */
 int licv_probe_permlane16_swap(void* out_u32_128, void* stream);
+/* roofline probe: stream a cold [N, K] bf16 matrix with 4-wave workgroups (16 rows x K/splits per wave) doing nothing with the data;
+ * shape = bytes per row per instruction: 0 16 rows x 64 B (MFMA fragment order), 1 8 x 128 B, 2 2 x 512 B, 3 1 x 1 KB; depth = 16-byte
+ * loads per lane in flight per register set (4, 8 or 16) */
+int licv_probe_weight_stream(const void* W, int64_t ldw, int64_t N, int64_t K, int splits, int shape, int depth, void* sink_u32, void* stream);
 /* timing instrumentation: when non-NULL, wave 0 of every workgroup of the default kernel stores 5 wall_clock64() stamps
  * (start, pipeline filled, main loop done, output image in LDS, end) at dev_buffer[8 * blockIdx.x ...] (int64) */
 int licv_gemm_debug_timestamps(void* dev_buffer);

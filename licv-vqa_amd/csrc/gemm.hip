@@ -16,6 +16,7 @@
 // Both issue the MFMA with W as the A operand and A as the B operand, so each lane ends up with 4
 // CONSECUTIVE output columns of one row: 8-byte bf16 / 16-byte fp32 stores, vector bias/residual loads.
 // Workgroup ids are remapped so that the 8 XCDs (private L2s) each own a compact patch of the tile grid.
+#include <mutex>
 #include "gemm_common.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -1438,95 +1439,35 @@ void gemm_bf16_splitk_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t*
 // ------------------------------------------------------------------------------------------------
 #define SKINNY_KR_MAX 1024          // K elements per split: 32 rows x 1024 x 2 B + padding = 66 KB of LDS
 
-template <int MB>                   // 16-row blocks of A: 1 (M <= 16) or 2 (M <= 32)
-__global__ __launch_bounds__(256)
-void gemm_bf16_skinny_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw, float* __restrict__ ws,
-                        int M, int N, int K, int steps_per_split, int64_t np) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int fr = lane & 15, fq = lane >> 4;
-    const int nsteps = (K + 31) / 32;
-    const int s0 = blockIdx.y * steps_per_split, s1 = min(nsteps, s0 + steps_per_split);
-    const int ns = s1 - s0;
-    const int kbase = s0 * 32, kr = ns * 32;
-    const int xstr = kr * 2 + 16;                                    // LDS row stride in bytes
-    const int n = blockIdx.x * 64 + wave * 16 + fr;
-    const bf16_t* wp = W + (int64_t)min(n, N - 1) * ldw + kbase + fq * 8;
-    // The weight stream is software-pipelined in two register sets of UN fragments: set (s + UN) is requested before set s is
-    // multiplied, and the FIRST set before the activations are staged (it does not depend on them) — the first version loaded a
-    // set, waited, multiplied, and only then asked for the next, and began streaming after the staging barrier: 3.0 TB/s.
-    constexpr int UN = 8;
-    u32x4 wf[2][UN];
-    auto loadw = [&](int s, u32x4 (&dst)[UN]) {
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int k = kbase + (s + u) * 32 + fq * 8;
-            dst[u] = (s + u < ns && k < K) ? *reinterpret_cast<const u32x4*>(wp + (s + u) * 32) : u32x4{0u, 0u, 0u, 0u};
-        }
-    };
-    loadw(0, wf[0]);
-    // ---- activations of this K range -> LDS (zero rows past M, zero columns past K)
-    const int chunks = kr / 8;
-    for (int c = tid; c < MB * 16 * chunks; c += 256) {
-        const int row = c / chunks, ch = c - row * chunks;
-        const int k = kbase + ch * 8;
-        u32x4 v = u32x4{0u, 0u, 0u, 0u};
-        if (row < M && k < K) v = *reinterpret_cast<const u32x4*>(A + (int64_t)row * lda + k);
-        *reinterpret_cast<u32x4*>(smem + row * xstr + ch * 16) = v;
-    }
-    __syncthreads();
-    const char* xp = smem + fr * xstr + fq * 16;
-    floatx4 acc[MB];
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) acc[mb] = floatx4{0.f, 0.f, 0.f, 0.f};
-    auto mul = [&](int s, const u32x4 (&src)[UN]) {
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int so = s + u < ns ? (s + u) * 64 : 0;           // steps past the range carry zero weights: any in-range activations do
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) {
-                const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xp + mb * 16 * xstr + so);
-                acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&src[u]), xf, acc[mb], 0, 0, 0);
-            }
-        }
-    };
-    for (int s = 0; s < ns; s += 2 * UN) {
-        if (s + UN < ns) loadw(s + UN, wf[1]);
-        mul(s, wf[0]);
-        if (s + UN < ns) {
-            if (s + 2 * UN < ns) loadw(s + 2 * UN, wf[0]);
-            mul(s + UN, wf[1]);
-        }
-    }
-    // lane holds rows m = mb*16 + fr, columns n0 + fq*4 .. +3  (W was the A operand)
-    float* slice = ws + (int64_t)blockIdx.y * 32 * np;
-    const int64_t c0 = (int64_t)blockIdx.x * 64 + wave * 16 + fq * 4;
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
-        *reinterpret_cast<floatx4*>(slice + (int64_t)(mb * 16 + fr) * np + c0) = acc[mb];
-    if (MB == 1) *reinterpret_cast<floatx4*>(slice + (int64_t)(16 + fr) * np + c0) = floatx4{0.f, 0.f, 0.f, 0.f};
-}
-
 // Finalize of the skinny path: sum the fp32 slices in order and run the epilogue for <= 32 rows, four consecutive output
 // columns per thread.  Same rounding points, in the same order, as epilogue_staged + epilogue_rows_generic (y = bf16(acc + bias);
 // activation; SwiGLU pairing; row gate; gate scale; residual in the stream dtype) — the general finalize kernel walks
 // 128 x 128 tiles through an LDS image, 17 us per call for 24 rows; this one is a few microseconds.
-__global__ __launch_bounds__(256)
-void skinny_finalize_k(const float* __restrict__ ws, void* __restrict__ C, int64_t ldc, int M, int N, int64_t np, int splits, GemmEpi ep,
-                       int slice_rows) {              // rows a split's slice holds: 32 (weight-streaming kernel) or M padded to 128 (128-tile route)
+template <bool SC1>       // SC1: the slices were stored write-through by other workgroups of THIS launch and are read past this CU's L1
+__device__ __forceinline__ void skinny_finalize_item(const float* __restrict__ ws, void* __restrict__ C, int64_t ldc, int N, int64_t np, int splits,
+                                                     const GemmEpi& ep, int slice_rows, int m, int c) {      // row m, output columns c .. c + 3
     const int n_out = ep.swiglu ? N >> 1 : N;
-    const int groups = (n_out + 3) >> 2;
-    const int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (item >= (int64_t)M * groups) return;
-    const int m = (int)(item / groups), c = (int)(item - (int64_t)m * groups) * 4;
     const int nv = min(4, n_out - c);
     const int64_t slice = (int64_t)slice_rows * np;
+    const auto rsws = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ws), 0, 0xFFFFFFFF, 0x00020000);
     auto sum4 = [&](int col) -> floatx4 {
-        const float* p = ws + (int64_t)m * np + col;
-        floatx4 v = *reinterpret_cast<const floatx4*>(p);
+        if constexpr (SC1) {
+            const uint32_t o = (uint32_t)((int64_t)m * np + col) * 4u, st = (uint32_t)slice * 4u;
+            u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rsws, o, 0, 16);                               // aux 16 = sc1
+            floatx4 v = *reinterpret_cast<floatx4*>(&r);
 #pragma unroll 4
-        for (int sp = 1; sp < splits; ++sp) v += *reinterpret_cast<const floatx4*>(p + sp * slice);         // fixed order
-        return v;
+            for (int sp = 1; sp < splits; ++sp) {
+                r = __builtin_amdgcn_raw_buffer_load_b128(rsws, o + (uint32_t)sp * st, 0, 16);
+                v += *reinterpret_cast<floatx4*>(&r);                                                       // fixed order
+            }
+            return v;
+        } else {
+            const float* p = ws + (int64_t)m * np + col;
+            floatx4 v = *reinterpret_cast<const floatx4*>(p);
+#pragma unroll 4
+            for (int sp = 1; sp < splits; ++sp) v += *reinterpret_cast<const floatx4*>(p + sp * slice);     // fixed order
+            return v;
+        }
     };
     float y[4];
     if (!ep.swiglu) {
@@ -1571,6 +1512,145 @@ void skinny_finalize_k(const float* __restrict__ ws, void* __restrict__ C, int64
     }
 }
 
+__global__ __launch_bounds__(256)
+void skinny_finalize_k(const float* __restrict__ ws, void* __restrict__ C, int64_t ldc, int M, int N, int64_t np, int splits, GemmEpi ep,
+                       int slice_rows) {              // rows a split's slice holds: 32 (weight-streaming kernel) or M padded to 128 (128-tile route)
+    const int n_out = ep.swiglu ? N >> 1 : N;
+    const int groups = (n_out + 3) >> 2;
+    const int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (item >= (int64_t)M * groups) return;
+    const int m = (int)(item / groups), c = (int)(item - (int64_t)m * groups) * 4;
+    skinny_finalize_item<false>(ws, C, ldc, N, np, splits, ep, slice_rows, m, c);
+}
+
+template <int MB>                   // 16-row blocks of A: 1 (M <= 16) or 2 (M <= 32)
+__global__ __launch_bounds__(256)
+void gemm_bf16_skinny_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw, float* __restrict__ ws,
+                        int M, int N, int K, int steps_per_split, int64_t np, unsigned* __restrict__ tickets, void* __restrict__ C, int64_t ldc, GemmEpi ep) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int nsteps = (K + 31) / 32;
+    const int s0 = blockIdx.y * steps_per_split, s1 = min(nsteps, s0 + steps_per_split);
+    const int ns = s1 - s0;
+    const int kbase = s0 * 32, kr = ns * 32;
+    const int xstr = kr * 2 + 16;                                    // LDS row stride in bytes
+    const int n = blockIdx.x * 64 + wave * 16 + fr;
+    // The weight stream is software-pipelined in two register sets of UN fragments: set (s + UN) is requested before set s is
+    // multiplied, and the FIRST set before the activations are staged (it does not depend on them).  Every load is a BUFFER load
+    // outside any branch; a fragment that does not exist (a step past this split's range, k >= K, a row >= N) gets an out-of-range
+    // offset and comes back as zeros.  With `cond ? *p : 0` the compiler put each load in an exec-masked block of its own and its
+    // waitcnt pass then drained the queue (s_waitcnt vmcnt(0)) in front of the first MFMA of every set - the set just requested
+    // included, so only one set was ever in flight and its whole latency exposed: 2.7-3.0 TB/s cold, where the same access shape
+    // with counted waits streams 5.5 TB/s (tools/stream_probe.py).
+    constexpr int UN = 8;
+    constexpr uint32_t OOB = 0xFFFFFFFFu;
+    const auto rsw = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (int64_t)blockIdx.x * 64 * ldw), 0, 0xFFFFFFFF, 0x00020000);
+    const uint32_t wrow = (uint32_t)((wave * 16 + fr) * (int)ldw + kbase + fq * 8) * 2u;       // bytes from the workgroup's first row
+    const bool row_ok = n < N;
+    u32x4 wf[2][UN];
+    auto loadw = [&](int s, u32x4 (&dst)[UN]) {
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int k = kbase + (s + u) * 32 + fq * 8;
+            const bool ok = (int)row_ok & (int)(s + u < ns) & (int)(k < K);
+            dst[u] = __builtin_amdgcn_raw_buffer_load_b128(rsw, ok ? wrow + (uint32_t)(s + u) * 64u : OOB, 0, 0);
+        }
+    };
+    loadw(0, wf[0]);
+    // ---- activations of this K range -> LDS (zero rows past M, zero columns past K)
+    const auto rsa = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0xFFFFFFFF, 0x00020000);
+    const int chunks = kr / 8;
+    constexpr int XU = 8;                                           // loads in flight per thread (one at a time: ~16 serial L2 round trips per workgroup)
+    // rows 0 .. M - 1 and ONE zero row (index M) that every fragment row >= M reads: 25 rows instead of 32 at M = 24 is a third
+    // workgroup per CU (3 x 52 KB of LDS), and 768 workgroups are one round instead of one and a half
+    const int xrows = M + 1;
+    for (int c0 = tid; c0 < xrows * chunks; c0 += 256 * XU) {
+        u32x4 v[XU];
+#pragma unroll
+        for (int j = 0; j < XU; ++j) {
+            const int c = c0 + j * 256;
+            const int row = c / chunks, ch = c - row * chunks;
+            const int k = kbase + ch * 8;
+            const bool ok = (int)(c < xrows * chunks) & (int)(row < M) & (int)(k < K);
+            v[j] = __builtin_amdgcn_raw_buffer_load_b128(rsa, ok ? (uint32_t)(row * (int)lda + k) * 2u : OOB, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < XU; ++j) {
+            const int c = c0 + j * 256;
+            const int row = c / chunks, ch = c - row * chunks;
+            if (c < xrows * chunks) *reinterpret_cast<u32x4*>(smem + row * xstr + ch * 16) = v[j];
+        }
+    }
+    __syncthreads();
+    const char* xp[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) xp[mb] = smem + min(mb * 16 + fr, M) * xstr + fq * 16;
+    floatx4 acc[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) acc[mb] = floatx4{0.f, 0.f, 0.f, 0.f};
+    auto mul = [&](int s, const u32x4 (&src)[UN]) {
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int so = s + u < ns ? (s + u) * 64 : 0;           // steps past the range carry zero weights: any in-range activations do
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xp[mb] + so);
+                acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&src[u]), xf, acc[mb], 0, 0, 0);
+            }
+        }
+    };
+    for (int s = 0; s < ns; s += 2 * UN) {
+        loadw(s + UN, wf[1]);                                       // (sets past the range: all lanes out of range, no traffic)
+        mul(s, wf[0]);
+        loadw(s + 2 * UN, wf[0]);
+        mul(s + UN, wf[1]);
+    }
+    // lane holds rows m = mb*16 + fr, columns n0 + fq*4 .. +3  (W was the A operand)
+    float* slice = ws + (int64_t)blockIdx.y * 32 * np;
+    const int64_t c0 = (int64_t)blockIdx.x * 64 + wave * 16 + fq * 4;
+    if (!tickets) {                                                 // the caller runs skinny_finalize_k behind this launch
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+            *reinterpret_cast<floatx4*>(slice + (int64_t)(mb * 16 + fr) * np + c0) = acc[mb];
+        if (MB == 1) *reinterpret_cast<floatx4*>(slice + (int64_t)(16 + fr) * np + c0) = floatx4{0.f, 0.f, 0.f, 0.f};
+        return;
+    }
+    // ---- in-launch reduction: the workgroup that draws the last ticket of its 64-column tile sums the splits' slabs (in split
+    // order, as skinny_finalize_k does: same bits) and runs the epilogue - one launch less per projection of a decode step.
+    // Hand-off in the write-through form of cdna_hip_programming.md 6/G16 (R1), placement-independent: every slab store carries sc1,
+    // every storing wave drains its stores, the workgroup meets, one lane takes the ticket (relaxed, agent scope); the last
+    // arriver reads every slab with sc1 loads (past its CU's L1).  The first version used plain stores and an agent-scope RELEASE
+    // fence per workgroup: 768 L2 write-backs per launch, 63 us where the two-launch form took 32.  The flag travels through the
+    // (now idle) activation image: no second LDS object.
+    {
+        const auto rss = __builtin_amdgcn_make_buffer_rsrc(slice, 0, 0xFFFFFFFF, 0x00020000);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(&acc[mb]);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rss, (uint32_t)((int64_t)(mb * 16 + fr) * np + c0) * 4u, 0, 16);
+        }
+        if (MB == 1) __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, rss, (uint32_t)((int64_t)(16 + fr) * np + c0) * 4u, 0, 16);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned t = __hip_atomic_fetch_add(&tickets[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = t == gridDim.y - 1 ? 1 : 0;
+        if (last) __hip_atomic_store(&tickets[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // all tickets are zero again between launches
+        *reinterpret_cast<volatile int*>(smem) = last;
+    }
+    __syncthreads();
+    if (*reinterpret_cast<volatile int*>(smem) == 0) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");          // (no instruction: keeps the compiler from moving the slab loads above the ticket)
+    const int n_out = ep.swiglu ? N >> 1 : N;
+    const int gpt = ep.swiglu ? 8 : 16;                             // 4-column groups of output per 64 weight rows (SwiGLU pairs them: 32 outputs)
+    for (int item = tid; item < M * gpt; item += 256) {
+        const int m = item / gpt, c = ((int)blockIdx.x * gpt + item % gpt) * 4;
+        if (c < n_out) skinny_finalize_item<true>(ws, C, ldc, N, np, (int)gridDim.y, ep, 32, m, c);
+    }
+}
+
 // gate/up rows interleaved in blocks of 16: packed[32b + i] = gate[16b + i], packed[32b + 16 + i] = up[16b + i]
 __global__ __launch_bounds__(256)
 void pack_gate_up_k(const bf16_t* __restrict__ g, const bf16_t* __restrict__ u, bf16_t* __restrict__ out, int64_t inter, int64_t K) {
@@ -1596,6 +1676,9 @@ extern "C" int licv_gemm_debug_timestamps(void* dev_buffer) {
     return rc != LICV_OK ? rc : licv_gemm_exp_debug_timestamps(dev_buffer);
 }
 
+static int g_skinny_inlaunch = 0;   // knob 7: 1 = the skinny kernel reduces over its splits inside its own launch (last workgroup of a tile).  Off: measured cold at
+                                    // M = 24 it only moves the finalize's ~5 us into the producer's tail (12288 x 4096: 36.1 vs 32.3 us with the separate launch;
+                                    // 4096 x 4096: 16.9 vs 18.3), see tools/stream_bench.py; kept as a tested alternative
 static int g_pp_group = 0;      // experiment knob: tile-rows per XCD patch group (0 = heuristic)
 static int g_splitk_enabled = 1;
 static int g_big_tiles = 160;   // knob 6: fewest 256 x 256 tiles for which the 256-tile kernels are taken (see route_256)
@@ -1606,12 +1689,14 @@ static int g_flow_default = 1;  // auto mode takes the flow kernels where they a
 //   knob 1: tile-rows per XCD patch group (0 = the default 8)
 //   knob 2: 0 = never take a flow kernel by default;  knob 4: 0 = licv_gemm_splitk_plan always answers "one pass" (the
 //   batch-independence tests switch split-K off for every caller, the native layer runner included)
+//   knob 7: 1 = the skinny kernel reduces over its splits in its own launch (default 0: a separate finalize launch)
 extern "C" int licv_gemm_experiment(int knob, int value) {
     if (knob == 0) return licv_gemm_exp_knob(0, value);
     else if (knob == 1) g_pp_group = value; else if (knob == 2) g_flow_default = value;
     else if (knob == 4) g_splitk_enabled = value;
     else if (knob == 5) g_force_splits = value;
     else if (knob == 6) g_big_tiles = value;
+    else if (knob == 7) g_skinny_inlaunch = value;
     else return licv_set_error(LICV_E_BADARG, "gemm_experiment: unknown knob %d", knob);
     return LICV_OK;
 }
@@ -1789,6 +1874,26 @@ extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
     return LICV_OK;
 }
 
+// Tickets of the skinny kernel's in-launch reduction: one counter per 64-column tile, all zero between launches (the last arriver
+// of a tile resets it).  Launches on ONE stream are ordered and share a row of the pool; every stream gets a row of its own (the two
+// batch slices of the engine run their projections concurrently), a 17th stream falls back to the separate finalize launch.
+#define SKINNY_TICKET_ROWS 16
+#define SKINNY_TICKET_TILES 1024
+__device__ unsigned g_skinny_tickets[SKINNY_TICKET_ROWS][SKINNY_TICKET_TILES];
+static unsigned* skinny_tickets_for(hipStream_t st, int tiles) {
+    static std::mutex mu;
+    static hipStream_t owner[SKINNY_TICKET_ROWS];
+    static int used = 0;
+    static unsigned* base = nullptr;
+    if (tiles > SKINNY_TICKET_TILES) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!base && hipGetSymbolAddress((void**)&base, HIP_SYMBOL(g_skinny_tickets)) != hipSuccess) { base = nullptr; return nullptr; }
+    for (int i = 0; i < used; ++i) if (owner[i] == st) return base + (size_t)i * SKINNY_TICKET_TILES;
+    if (used == SKINNY_TICKET_ROWS) return nullptr;
+    owner[used] = st;
+    return base + (size_t)(used++) * SKINNY_TICKET_TILES;
+}
+
 // splits and workspace bytes the skinny-M path wants for (M, N, K); splits <= 1 means "use licv_gemm_bf16"
 extern "C" int licv_gemm_splitk_plan(int64_t M, int64_t N, int64_t K, int* splits, int64_t* workspace_bytes) {
     LICV_CHECK_ARG(splits && workspace_bytes, "gemm_splitk_plan: null pointer");
@@ -1879,12 +1984,15 @@ extern "C" int licv_gemm_bf16_splitk(const void* A, int64_t lda, const void* W, 
         hipStream_t sst = (hipStream_t)stream;
         const dim3 grid((unsigned)((N + 63) / 64), (unsigned)splits);
         const int mb = M <= 16 ? 1 : 2;
-        const size_t lds = (size_t)mb * 16 * (per * 32 * 2 + 16);
-        if (mb == 1) gemm_bf16_skinny_k<1><<<grid, 256, lds, sst>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, (float*)workspace, (int)M, (int)N, (int)K, per, np);
-        else         gemm_bf16_skinny_k<2><<<grid, 256, lds, sst>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, (float*)workspace, (int)M, (int)N, (int)K, per, np);
-        const int n_out = e->swiglu ? (int)(N / 2) : (int)N;
-        const int64_t items = (int64_t)M * ((n_out + 3) / 4);
-        skinny_finalize_k<<<dim3((unsigned)((items + 255) / 256)), dim3(256), 0, sst>>>((const float*)workspace, C, ldc, (int)M, (int)N, np, splits, eps, 32);
+        const size_t lds = (size_t)(M + 1) * (per * 32 * 2 + 16);
+        unsigned* tickets = g_skinny_inlaunch ? skinny_tickets_for(sst, (int)grid.x) : nullptr;
+        if (mb == 1) gemm_bf16_skinny_k<1><<<grid, 256, lds, sst>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, (float*)workspace, (int)M, (int)N, (int)K, per, np, tickets, C, ldc, eps);
+        else         gemm_bf16_skinny_k<2><<<grid, 256, lds, sst>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, (float*)workspace, (int)M, (int)N, (int)K, per, np, tickets, C, ldc, eps);
+        if (!tickets) {
+            const int n_out = e->swiglu ? (int)(N / 2) : (int)N;
+            const int64_t items = (int64_t)M * ((n_out + 3) / 4);
+            skinny_finalize_k<<<dim3((unsigned)((items + 255) / 256)), dim3(256), 0, sst>>>((const float*)workspace, C, ldc, (int)M, (int)N, np, splits, eps, 32);
+        }
         LICV_LAUNCH_CHECK();
         return LICV_OK;
     }

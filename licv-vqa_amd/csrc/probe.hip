@@ -44,3 +44,62 @@ extern "C" int licv_probe_permlane16_swap(void* out_u32_128, void* stream) {
     LICV_LAUNCH_CHECK();
     return LICV_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Weight-stream probe: what HBM rate does a given per-instruction ACCESS SHAPE reach when 4-wave workgroups stream a cold [N, K]
+// bf16 matrix the way the weight-streaming GEMMs do (each wave owns 16 rows x a K range, `UN` 16-byte loads per lane in flight in
+// each of two register sets, nothing but an XOR done with the data)?
+//   shape 0: 16 rows x 64 B per instruction (MFMA fragment order, what gemm_bf16_skinny_k issues)
+//   shape 1:  8 rows x 128 B   shape 2: 2 rows x 512 B   shape 3: 1 row x 1 KB
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_p;
+
+template <int SHAPE, int UN>
+__global__ __launch_bounds__(256)
+void weight_stream_probe_k(const bf16_t* __restrict__ W, int64_t ldw, int N, int K, int kr, unsigned* __restrict__ sink) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * 64 + wave * 16;
+    const int k0 = blockIdx.y * kr;
+    // instruction i of this wave covers IB bytes of each of IR rows; the wave's 16 rows x kr*2 bytes take 16*kr*2/1024 instructions
+    constexpr int IR = SHAPE == 0 ? 16 : SHAPE == 1 ? 8 : SHAPE == 2 ? 2 : 1;
+    constexpr int LPR = 64 / IR;                                 // lanes per row
+    const int r_in = lane / LPR, c_in = lane % LPR;
+    const int row_groups = 16 / IR;                              // instructions needed to cover the 16 rows at one K position
+    const int n_instr = 16 * kr * 2 / 1024;
+    u32x4_p acc = u32x4_p{0u, 0u, 0u, 0u};
+    u32x4_p buf[2][UN];
+    auto issue = [&](int i0, u32x4_p (&dst)[UN]) {
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int i = min(i0 + u, n_instr - 1);
+            const int kpos = i / row_groups, rg = i % row_groups;        // walk the rows first, then along K
+            const int row = min(n0 + rg * IR + r_in, N - 1);
+            const int k = k0 + kpos * (LPR * 8) + c_in * 8;
+            dst[u] = *reinterpret_cast<const u32x4_p*>(W + (int64_t)row * ldw + min(k, K - 8));
+        }
+    };
+    issue(0, buf[0]);
+    for (int i = 0; i < n_instr; i += 2 * UN) {
+        issue(i + UN, buf[1]);
+#pragma unroll
+        for (int u = 0; u < UN; ++u) acc ^= buf[0][u];
+        issue(i + 2 * UN, buf[0]);
+#pragma unroll
+        for (int u = 0; u < UN; ++u) acc ^= buf[1][u];
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345679u) sink[0] = acc.x;   // keeps the loads alive
+}
+
+extern "C" int licv_probe_weight_stream(const void* W, int64_t ldw, int64_t N, int64_t K, int splits, int shape, int depth, void* sink, void* stream) {
+    LICV_CHECK_ARG(W && sink && N % 64 == 0 && splits > 0 && K % (splits * 512) == 0, "probe_weight_stream: N %% 64, K %% (splits * 512) must be 0");
+    const dim3 grid((unsigned)(N / 64), (unsigned)splits);
+    const int kr = (int)(K / splits);
+    hipStream_t st = (hipStream_t)stream;
+#define WS_LAUNCH(S, U) weight_stream_probe_k<S, U><<<grid, 256, 0, st>>>((const bf16_t*)W, ldw, (int)N, (int)K, kr, (unsigned*)sink)
+    if (depth <= 4)       { if (shape == 0) WS_LAUNCH(0, 4); else if (shape == 1) WS_LAUNCH(1, 4); else if (shape == 2) WS_LAUNCH(2, 4); else WS_LAUNCH(3, 4); }
+    else if (depth <= 8)  { if (shape == 0) WS_LAUNCH(0, 8); else if (shape == 1) WS_LAUNCH(1, 8); else if (shape == 2) WS_LAUNCH(2, 8); else WS_LAUNCH(3, 8); }
+    else                  { if (shape == 0) WS_LAUNCH(0, 16); else if (shape == 1) WS_LAUNCH(1, 16); else if (shape == 2) WS_LAUNCH(2, 16); else WS_LAUNCH(3, 16); }
+#undef WS_LAUNCH
+    LICV_LAUNCH_CHECK();
+    return LICV_OK;
+}

@@ -670,8 +670,31 @@ def test_gemm_skinny_weight_streaming_kernel(M, N, K, epi):
         kw = dict(residual=torch.randn(M, N, generator=gen).to(torch.bfloat16).to(DEV))
     splits, ws = O_._splitk_plan(M, N, K)
     assert splits >= 2 and ws == splits * 32 * ((N + 127) // 128 * 128) * 4
+    res0 = kw["residual"].clone() if "residual" in kw else None
     y1 = O_.linear(a, w, **kw).clone()
     assert torch.equal(y1, O_.linear(a, w, **kw))
+    # the alternative form - the reduction over the splits inside the producer's launch (knob 7 = 1: last workgroup of a tile, write-through
+    # slabs + ticket) - must give the same bits as the separate finalize launch: 30 back-to-back launches, half of them on a second stream
+    # with a ticket row of its own, must all agree (a missed hand-off shows as a stale or half-written slab)
+    from licv import _lib
+    side = torch.cuda.Stream()
+    outs = []
+    try:
+        _lib.lib().licv_gemm_experiment(7, 1)
+        for i in range(30):
+            if i % 2:
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    outs.append(O_.linear(a, w, **kw))
+                torch.cuda.current_stream().wait_stream(side)
+            else:
+                outs.append(O_.linear(a, w, **kw))
+        torch.cuda.synchronize()
+    finally:
+        _lib.lib().licv_gemm_experiment(7, 0)
+    assert all(torch.equal(o, y1) for o in outs)
+    if res0 is not None:
+        assert torch.equal(kw["residual"], res0)            # (the residual operand is read, never written)
     try:
         O_.set_splitk(False)
         ref = O_.linear(a, w, **kw).clone()
