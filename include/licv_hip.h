@@ -91,6 +91,11 @@ int licv_layernorm_fwd(const void* x_bf16, const void* w_bf16, const void* b_bf1
 int licv_rotary_fwd(void* x_bf16, const void* cos_bf16, const void* sin_bf16, const int64_t* position_ids,
                     int64_t rows, int64_t n_heads, int64_t head_dim, int64_t ld, int64_t tensor_stride,
                     int n_tensors, int64_t n_pos, void* stream);
+/* rotary + KV-cache append of one fused QKV projection in one launch (hooked generate, ref:inference.py:300-321 -> HF generate's
+ * past_key_values): qkv is (batch * S, 3H) bf16; Q heads are rotated in place, the rotated K heads and V go to
+ * cache[b, past + s, 0:H | H:2H] (cache: (batch, cache_max_len, 2H) bf16).  Same arithmetic as licv_rotary_fwd. */
+int licv_rotary_kv_append(void* qkv_bf16, const void* cos_bf16, const void* sin_bf16, const int64_t* position_ids, int64_t batch, int64_t S,
+                          int64_t n_heads, int64_t head_dim, int64_t n_pos, void* cache_bf16, int64_t cache_max_len, int64_t past, void* stream);
 
 /* ---- dense layers: nn.Linear on MFMA (every F.linear under hf:idefics/ and hf:idefics2/) ----
  * C[M,N] = epilogue( A[M,K] (bf16, lda) x W[N,K]^T (bf16, ldw) ), fp32 accumulation.

@@ -570,6 +570,43 @@ void rotary_fwd_k(bf16_t* __restrict__ x, const bf16_t* __restrict__ cosT, const
     }
 }
 
+// Decode / prefill with a KV cache: rotary on the Q and K heads of the fused projection and the append of (rotated K | V) to the
+// cache in ONE launch (one workgroup per row).  Q is rotated in place, K goes straight to cache[b, past + s, 0:H], V is copied to
+// cache[b, past + s, H:2H]; the arithmetic is rotary_fwd_k's, value for value (the K columns of qkv itself are left unrotated:
+// with a cache nothing reads them).
+__global__ __launch_bounds__(256)
+void rotary_kv_append_k(bf16_t* __restrict__ qkv, const bf16_t* __restrict__ cosT, const bf16_t* __restrict__ sinT,
+                        const int64_t* __restrict__ pos, int64_t S, int n_heads, int head_dim, int64_t H, int64_t n_pos,
+                        bf16_t* __restrict__ cache, int64_t max_len, int64_t past) {
+    const int64_t row = blockIdx.x;                       // b * S + s
+    const int64_t b = row / S, sq = row - b * S;
+    const int half = head_dim >> 1, qper = half >> 2;
+    int64_t p = pos[row];
+    p = p < 0 ? 0 : (p >= n_pos ? n_pos - 1 : p);
+    bf16_t* crow = cache + (b * max_len + past + sq) * 2 * H;
+    for (int idx = threadIdx.x; idx < 2 * n_heads * qper; idx += blockDim.x) {
+        const int g = idx % qper, hd = (idx / qper) % n_heads, t = idx / (qper * n_heads);
+        const int i = g * 4;
+        bf16_t* base = qkv + row * 3 * H + t * H + (int64_t)hd * head_dim;
+        const floatx4 lo = RowIO<LICV_BF16>::load4(base, i);
+        const floatx4 hi = RowIO<LICV_BF16>::load4(base, i + half);
+        const floatx4 c = RowIO<LICV_BF16>::load4(cosT, p * head_dim + i);
+        const floatx4 s = RowIO<LICV_BF16>::load4(sinT, p * head_dim + i);
+        floatx4 olo, ohi;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            olo[j] = rbf(lo[j] * c[j]) + rbf(-hi[j] * s[j]);
+            ohi[j] = rbf(hi[j] * c[j]) + rbf(lo[j] * s[j]);
+        }
+        bf16_t* dst = t == 0 ? base : crow + (int64_t)hd * head_dim;
+        store4_bf16(dst, i, olo);
+        store4_bf16(dst, i + half, ohi);
+    }
+    const uint4* vsrc = reinterpret_cast<const uint4*>(qkv + row * 3 * H + 2 * H);
+    uint4* vdst = reinterpret_cast<uint4*>(crow + H);
+    for (int64_t i = threadIdx.x; i < H / 8; i += blockDim.x) vdst[i] = vsrc[i];
+}
+
 // ------------------------------------------------------------------------------------------------
 // gathers / layout
 // ------------------------------------------------------------------------------------------------
@@ -858,6 +895,20 @@ extern "C" int licv_rotary_fwd(void* x, const void* cosT, const void* sinT, cons
     const int64_t total = rows * n_tensors * n_heads * (head_dim / 8);
     rotary_fwd_k<<<flat_blocks(total), 256, 0, (hipStream_t)stream>>>((bf16_t*)x, (const bf16_t*)cosT, (const bf16_t*)sinT,
         position_ids, rows, (int)n_heads, (int)head_dim, ld, tensor_stride, n_tensors, n_pos);
+    LICV_LAUNCH_CHECK();
+    return LICV_OK;
+}
+
+extern "C" int licv_rotary_kv_append(void* qkv, const void* cosT, const void* sinT, const int64_t* position_ids, int64_t batch, int64_t S,
+                                     int64_t n_heads, int64_t head_dim, int64_t n_pos, void* cache, int64_t cache_max_len, int64_t past,
+                                     void* stream) {
+    LICV_CHECK_ARG(qkv && cosT && sinT && position_ids && cache, "rotary_kv_append: null pointer");
+    LICV_CHECK_ARG(head_dim > 0 && head_dim % 8 == 0 && n_heads > 0 && n_pos > 0, "rotary_kv_append: head_dim (%lld) must be a multiple of 8", (long long)head_dim);
+    LICV_CHECK_ARG(past >= 0 && S > 0 && past + S <= cache_max_len, "rotary_kv_append: %lld + %lld tokens do not fit a cache of %lld", (long long)past, (long long)S, (long long)cache_max_len);
+    LICV_CHECK_ARG(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)cache & 15) == 0, "rotary_kv_append: misaligned pointer");
+    if (batch <= 0) return LICV_OK;
+    rotary_kv_append_k<<<(unsigned)(batch * S), 256, 0, (hipStream_t)stream>>>((bf16_t*)qkv, (const bf16_t*)cosT, (const bf16_t*)sinT,
+        position_ids, S, (int)n_heads, (int)head_dim, n_heads * head_dim, n_pos, (bf16_t*)cache, cache_max_len, past);
     LICV_LAUNCH_CHECK();
     return LICV_OK;
 }

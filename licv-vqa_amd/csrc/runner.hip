@@ -11,16 +11,6 @@
 
 #define RUN(call) do { int rc__ = (call); if (rc__ != LICV_OK) return rc__; } while (0)
 
-// cache[b, past + s, :] = qkv[b, s, H : 3H]   (the K|V columns of the fused projection)
-__global__ __launch_bounds__(256)
-void kv_append_k(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ cache, int64_t S, int64_t H, int64_t max_len, int64_t past) {
-    const int64_t row = blockIdx.x;                       // b * S + s
-    const int64_t b = row / S, s = row - b * S;
-    const uint4* src = reinterpret_cast<const uint4*>(qkv + row * 3 * H + H);
-    uint4* dst = reinterpret_cast<uint4*>(cache + (b * max_len + past + s) * 2 * H);
-    for (int64_t i = threadIdx.x; i < 2 * H / 8; i += blockDim.x) dst[i] = src[i];
-}
-
 namespace {
 struct Ctx {
     const licv_idefics_text_weights* w;
@@ -120,7 +110,7 @@ extern "C" int licv_idefics_text_forward(const licv_idefics_text_weights* w, con
         } else if (!xn_valid) { RUN(licv_rmsnorm_fwd(x.h, x.h_dt, D.in_ln, c->x, M, H, 1, H, H, w->rms_eps, 0, stream)); xin = c->x; }
         xn_valid = false;
         RUN(linear(x, xin, M, D.qkv_w, 3 * H, H, c->qkv, 3 * H, LICV_BF16));
-        RUN(licv_rotary_fwd(c->qkv, w->cos, w->sin, c->position_ids, M, nh, hd, 3 * H, H, 2, w->rope_len, stream));
+        if (!c->kv_cache) RUN(licv_rotary_fwd(c->qkv, w->cos, w->sin, c->position_ids, M, nh, hd, 3 * H, H, 2, w->rope_len, stream));
         licv_attn_args a;
         a.q = c->qkv; a.q_bs = S * 3 * H; a.q_rs = 3 * H;
         a.o = c->o; a.B = B; a.Sq = S; a.n_heads = nh; a.n_kv_heads = nh; a.head_dim = hd; a.scale = att_scale; a.mask_mode = 1;
@@ -129,8 +119,8 @@ extern "C" int licv_idefics_text_forward(const licv_idefics_text_weights* w, con
             a.k = (const char*)c->qkv + H * 2; a.v = (const char*)c->qkv + 2 * H * 2; a.kv_bs = S * 3 * H; a.kv_rs = 3 * H; a.Sk = S;
         } else {
             void* cache = c->kv_cache[l];
-            kv_append_k<<<(unsigned)M, 256, 0, st>>>((const bf16_t*)c->qkv, (bf16_t*)cache, S, H, c->cache_max_len, c->past);
-            LICV_LAUNCH_CHECK();
+            // rotary (Q in place, K on its way into the cache) and the append in one launch
+            RUN(licv_rotary_kv_append(c->qkv, w->cos, w->sin, c->position_ids, B, S, nh, hd, w->rope_len, cache, c->cache_max_len, c->past, stream));
             a.k = cache; a.v = (const char*)cache + H * 2; a.kv_bs = c->cache_max_len * 2 * H; a.kv_rs = 2 * H; a.Sk = c->Sk;
         }
         RUN(licv_attn_fwd(&a, stream));

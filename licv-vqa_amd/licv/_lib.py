@@ -74,6 +74,7 @@ def lib() -> C.CDLL:
             "licv_rmsnorm_fwd": [P, I, P, P, I64, I64, I64, I64, I64, F, I, P],
             "licv_layernorm_fwd": [P, P, P, P, I64, I64, I64, I64, I64, I64, I64, F, P],
             "licv_rotary_fwd": [P, P, P, P, I64, I64, I64, I64, I64, I, I64, P],
+            "licv_rotary_kv_append": [P, P, P, P, I64, I64, I64, I64, I64, P, I64, I64, P],
             "licv_gemm_bf16": [P, I64, P, I64, P, I64, I64, I64, I64, C.POINTER(GemmEpilogue), P],
             "licv_pack_gate_up": [P, P, P, I64, I64, P],
             "licv_quantize_rows_fp8": [P, I, P, P, I64, I64, I64, I64, P],

@@ -43,7 +43,7 @@ class _IdeficsDecoder:
         return self._fwd(new_ids, am, self.iam)
 
     def replicate(self, nb):                       # HF prefills B*nb identical rows; replicate the prompt state instead
-        self.cache.kv = [t.repeat_interleave(nb, 0) for t in self.cache.kv]
+        self.cache.replicate(nb)
         if self.cache.xkv is not None:             # beams of one question share the image side: replicated once, never reordered
             self.cache.xkv = [t.repeat_interleave(nb, 0) for t in self.cache.xkv]
         self.image_states = self.image_states.repeat_interleave(nb, 0)
@@ -81,7 +81,7 @@ class _Idefics2Decoder:
         return self._fwd(new_ids, am, None)
 
     def replicate(self, nb):
-        self.cache.kv = [t.repeat_interleave(nb, 0) for t in self.cache.kv]
+        self.cache.replicate(nb)
         self.pos = self.pos.repeat_interleave(nb, 0)
 
     def reorder(self, flat):

@@ -122,12 +122,21 @@ class KVCache2:
 
     def __init__(self, arch: Idefics2Arch, batch: int, max_len: int, device):
         self.max_len, self.len = max_len, 0
-        self.kv = [torch.empty((batch, max_len, 2 * arch.num_kv_heads * arch.head_dim), dtype=torch.bfloat16, device=device)
-                   for _ in range(arch.num_layers)]
+        # one allocation for all layers: the beam reorder of a decode step is then ONE gather launch instead of one per layer
+        self._all = torch.empty((arch.num_layers, batch, max_len, 2 * arch.num_kv_heads * arch.head_dim), dtype=torch.bfloat16, device=device)
+        self.kv = list(self._all.unbind(0))
 
     def reorder(self, idx: torch.Tensor):
-        for i in range(len(self.kv)):
-            self.kv[i] = self.kv[i].index_select(0, idx)
+        # rows (layer, beam) of the flattened cache: index_select along dim 0 takes torch's vectorised gather (along dim 1 of the 4-d
+        # tensor it falls to a generic element-wise kernel, 8x slower than the per-layer gathers it was meant to replace)
+        L, B = self._all.shape[:2]
+        rows = (torch.arange(L, device=idx.device).unsqueeze(1) * B + idx.unsqueeze(0)).reshape(-1)
+        self._all = self._all.reshape(L * B, -1).index_select(0, rows).view(L, idx.numel(), *self._all.shape[2:])
+        self.kv = list(self._all.unbind(0))
+
+    def replicate(self, nb: int):                  # every row nb times, in place (beams of one question start from one prefill)
+        self._all = self._all.repeat_interleave(nb, 1)
+        self.kv = list(self._all.unbind(0))
 
 
 class _HostFlags:
