@@ -1085,6 +1085,387 @@ void gemm_bf16_flow64_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t*
 #undef F64_BIAS1
 #undef F64_LOAD_BIAS
 }
+// ------------------------------------------------------------------------------------------------
+// fp8 (OCP e4m3) operands on the 2x instruction: gemm_bf16_flow64_k in BYTES - the same ring, pieces, rendezvous, counted waits
+// and register-direct epilogues; a K tile is 128 bytes a row = 128 fp8 elements - with v_mfma_f32_16x16x128_f8f6f4 (8 passes, 32
+// cycles: 64 per wave and K tile where the bf16 kernel issues 128 of 16 cycles, so the operand stream per cycle is the same and
+// the K extent per cycle doubles).  a_scale[m] * w_scale[n] multiply the fp32 accumulators in the epilogue, ahead of the bias.
+// Needs K % 128 == 0, K >= 512, N % 128 == 0.
+// ------------------------------------------------------------------------------------------------
+template <int EPI>      // 0 plain/bias, 1 GELU(erf), 2 GELU(tanh), 3 ReLU, 4 SwiGLU (N/2 output columns), 5 bias + bf16 residual (may alias C)
+__global__ __launch_bounds__(256)
+void gemm_fp8_flow64_k(const char* __restrict__ A, int64_t lda, const char* __restrict__ W, int64_t ldw,
+                       const float* __restrict__ a_scale, const float* __restrict__ w_scale,
+                       bf16_t* C, int ldc, int M, int N, int K, int tiles_m, int tiles_n, const bf16_t* __restrict__ bias, int group,
+                       const bf16_t* res = nullptr, int ld_res = 0) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // 10 units x 16 KiB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntiles = tiles_m * tiles_n;
+    const int nt = K / 128;                                          // K tiles of 128 fp8 elements (128 bytes a row, as the bf16 kernel's); >= 4, host-guaranteed
+    constexpr int NST = (EPI == 4) ? 16 : 32;                        // epilogue store instructions per wave and tile
+    // ... of which this many can still be in flight when the epilogue ends (EPI 5 waits for its residual loads block by block, and
+    // vector-memory operations retire in order: only the stores issued after the last such wait remain)
+    constexpr int NSTF = (EPI == 5) ? 8 : NST;
+    const auto crs = __builtin_amdgcn_make_buffer_rsrc((void*)C, 0, (int)((int64_t)M * ldc * 2), 0x00020000);
+    // EPI 5: the residual rows through a descriptor of their own (rows past M read as zero and are never stored)
+    const auto rrs = __builtin_amdgcn_make_buffer_rsrc((void*)(EPI == 5 ? res : C), 0, (int)((int64_t)M * (EPI == 5 ? ld_res : ldc) * 2), 0x00020000);
+    // Bias: each lane's 8 x 4 values (accumulator block j covers columns colbase + 16 j + 4 (lane / 16) ...) arrive by eight 8-byte
+    // buffer loads issued ONE TILE AHEAD — in the prologue for the first tile, at the end of an epilogue for the next tile — so no
+    // epilogue waits for them (through the scalar cache, as the 8-wave kernel does it, a tile paid four dependent scalar-load
+    // latencies with nothing on the CU to hide them: -15 % on the ViT QKV shape).  The loads are inline asm: invisible to the
+    // compiler's own wait insertion (which would drain the LDS-DMA pieces in flight at the first use), counted by hand like the
+    // pieces.  No bias: a descriptor of zero records, every load returns 0 without touching memory, same counts.
+    // ... plus, one tile ahead in the same way, the scales of the fp8 operands: a_scale of the lane's 8 rows (eight 4-byte loads) and
+    // w_scale of its 8 x 4 columns - those in COMPACT form: the 32 values depend on lane / 16 only, so lane (fq, fr) keeps elements
+    // fr and fr + 16 of its group's list (element e = 4 j + r is column 16 j + 4 fq + r) and the epilogue fetches element e from lane
+    // e % 16 of the lane's own row of 16 with one DPP move (row_newbcast).  Held unpacked, one tile ahead, the 32 registers did not
+    // fit beside the 128 fragment registers: the compiler parked them in the accumulator file.
+    constexpr int NB = (EPI == 4) ? 10 : 12;                         // scale (+ bias) loads per wave and tile
+    const auto brs = __builtin_amdgcn_make_buffer_rsrc((void*)(bias ? bias : C), 0, bias ? N * 2 : 0, 0x00020000);
+    // (bias in the compact form of the scales below: bf16 elements fr and fr + 16 of the lane group's 32 columns, one register once merged)
+    unsigned bc0 = 0, bc1 = 0;
+#define F8_BS1(KK, DST, VOFF) asm volatile("buffer_load_ushort %0, %1, %2, 0 offen offset:%c3" : "=v"(DST) : "v"(VOFF), "s"(brs), "i"((KK) * 128) : "memory")
+    const auto wsr = __builtin_amdgcn_make_buffer_rsrc((void*)w_scale, 0, N * 4, 0x00020000);
+    const auto asr = __builtin_amdgcn_make_buffer_rsrc((void*)a_scale, 0, M * 4, 0x00020000);     // rows past M: scale 0, rows never stored
+    float swc[2];
+    float sar[8];
+#define F8_WS1(KK, VOFF) asm volatile("buffer_load_dword %0, %1, %2, 0 offen offset:%c3" : "=v"(swc[KK]) : "v"(VOFF), "s"(wsr), "i"((KK) * 256) : "memory")
+#define F8_AS1(I, VOFF) asm volatile("buffer_load_dword %0, %1, %2, 0 offen offset:%c3" : "=v"(sar[I]) : "v"(VOFF), "s"(asr), "i"((I) * 64) : "memory")
+    // element e = fr + 16 kk: column 16 (e / 4) + 4 fq + e % 4 = 64 kk + 16 (fr / 4) + 4 fq + fr % 4
+#define F8_LOAD_SCALES(M_TILE, N_TILE) do { const int wv_ = ((N_TILE) + wn * 128 + 16 * ((lane & 15) >> 2) + 4 * (lane >> 4) + (lane & 3)) * 4; \
+        const int av_ = ((M_TILE) + wm * 128 + (lane & 15)) * 4; \
+        F8_WS1(0, wv_); F8_WS1(1, wv_); \
+        if constexpr (EPI != 4) { const int bvo_ = wv_ >> 1; F8_BS1(0, bc0, bvo_); F8_BS1(1, bc1, bvo_); } \
+        F8_AS1(0, av_); F8_AS1(1, av_); F8_AS1(2, av_); F8_AS1(3, av_); F8_AS1(4, av_); F8_AS1(5, av_); F8_AS1(6, av_); F8_AS1(7, av_); } while (0)
+    // w_scale of column 16 j + 4 fq + r of the wave's 128 (E = 4 j + r): lane E % 16 of this lane's row holds it in swc[E / 16]
+    auto swf = [&](auto e_c) -> float {
+        constexpr int E = decltype(e_c)::value;
+        float r;            // (volatile: as a builtin the 32 fetches were hoisted out of the row loop and held in 32 registers again)
+        asm volatile("v_mov_b32_dpp %0, %1 row_newbcast:%c2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(swc[E >> 4]), "i"(E & 15));
+        return r;
+    };
+    typedef __attribute__((address_space(3))) char* lds_ptr;
+    typedef const __attribute__((address_space(3))) char* lds_cptr;
+    typedef const __attribute__((address_space(3))) bf16x8* lds_fptr;
+    const lds_ptr ring_w = (lds_ptr)smem;
+    const lds_cptr ring = (lds_cptr)smem;
+    auto wrap = [](int u) { return u >= 10 ? u - 10 : u; };
+
+    // ONE set of operand sources: those of the output tile whose K tiles are being ISSUED (its corner in two buffer descriptors,
+    // per-lane byte offsets of the wave's 8 + 8 pieces).  It moves on to the workgroup's next output tile two K tiles before the
+    // multiplication does.  piece (half, q): rows half * 128 + 32 * wave + 8 q + lane / 8 of the tile; LDS position lane % 8 holds
+    // source chunk (lane % 8) ^ (row % 8); rows past M / N re-read the last valid row (those outputs are never stored)
+    // (fp8 form: the 16 per-piece offsets of the bf16 kernel are ONE register per operand - the lane's row within its wave's first
+    //  8-row block and its swizzled chunk - plus a wave-uniform row-block term added when the piece is issued; rows past M / N fall
+    //  outside the descriptor's range instead of being clamped: 14 registers that the fragments of the 128-deep MFMA need)
+    int mP = 0, nP = 0;
+    const int pchunk = (lane & 7) ^ ((lane >> 3) & 7);
+    const int baseA = (wave * 32 + (lane >> 3)) * (int)lda + pchunk * 16;
+    const int baseW = (wave * 32 + (lane >> 3)) * (int)ldw + pchunk * 16;
+    auto rA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0xFFFFFFFF, 0x00020000);
+    auto rW = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, 0xFFFFFFFF, 0x00020000);
+    auto set_sources = [&](int t) {
+        int tm, tn;
+        tile_coords(t, tiles_m, tiles_n, tm, tn, group);
+        mP = tm * 256; nP = tn * 256;
+        rA = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (int64_t)mP * lda), 0, min(M - mP, 256) * (int)lda, 0x00020000);      // (lda, ldw: bytes)
+        rW = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (int64_t)nP * ldw), 0, min(N - nP, 256) * (int)ldw, 0x00020000);
+    };
+    // The ring as five PAIRS of units (32 KiB each: W rows 0-127 | W rows 128-255, or the two A units): K tile g has its W pair at
+    // position 2 g mod 5 and its A pair at 2 g + 1 mod 5.  A pair is filled by the wave's 8 pieces at consecutive KiB of its own 4 KiB
+    // of each unit: the LDS destination (M0) starts at pair + 4096 wave and steps by 1 KiB, + 13 KiB from unit 0 to unit 1.
+    // (s_add_u32 writes SCC: declared, or the compiler keeps a loop condition in it across the statement.)
+    // A piece is two instructions, as the vendor library issues it: the load, then the M0 step for the NEXT piece (so no wait state
+    // sits between an M0 write and the load that uses it); M0 is set one MFMA before a pair's first piece.  The compiler has no LDS-DMA
+    // of its own in this kernel, so nothing else writes M0 between these statements.
+    const int lds_base = __builtin_amdgcn_readfirstlane((int)(uintptr_t)ring_w) + wave * 4096;
+    auto nx = [](int pair) { const int n = pair + 32768; return n >= 163840 ? n - 163840 : n; };
+#define F64_M0(ADDR) asm volatile("s_mov_b32 m0, %0" :: "s"(ADDR) : "memory")
+#define F64_PIECE(VOFF, RSRC, KB, STEP) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds\n\ts_add_u32 m0, m0, %3" :: "v"(VOFF), "s"(RSRC), "s"(KB), "i"(STEP) : "memory", "scc")
+    // the p-th piece (0-7) of the pair being filled: W or A rows, this K tile's byte offset in a row
+    auto piece_w = [&](auto p_c, int kb) {
+        constexpr int p = decltype(p_c)::value;
+        const int vo = baseW + ((p >> 2) * 128 + (p & 3) * 8) * (int)ldw;    // (locals: an asm operand alone does not capture in a generic lambda)
+        const auto r = rW;
+        F64_PIECE(vo, r, kb, (p == 3 ? 13312 : 1024));
+    };
+    auto piece_a = [&](auto p_c, int kb) {
+        constexpr int p = decltype(p_c)::value;
+        const int vo = baseA + ((p >> 2) * 128 + (p & 3) * 8) * (int)lda;
+        const auto r = rA;
+        F64_PIECE(vo, r, kb, (p == 3 ? 13312 : 1024));
+    };
+
+    // The 256 accumulators are NOT C++ values: accumulator (i, j) is a[4 (8 i + j) : 4 (8 i + j) + 3], named literally in the MFMA
+    // and in the epilogue's reads.  As values under this loop (a conditional epilogue that reads and clears them inside the K-tile
+    // loop) the register allocator kept part of them in arch VGPRs, moved them with v_accvgpr_write ahead of every MFMA and spilled
+    // to scratch (scratch traffic would also break the counted vmcnt waits).  The clearing statement below declares all of
+    // a[0:255] clobbered, which reserves that half of the register file; the compiler itself never touches it as long as its own
+    // values fit the 256 arch VGPRs (checked by licv_gemm_flow_available: no private segment; tests: kernels agree bit for bit).
+#include "gemm_acc256_clear.inc"
+    // fragment (row i * 16 + lane % 16 of the unit, K chunk kk * 4 + lane / 16): the swizzle term is (lane % 16) % 8 = lane % 8 for every i
+    const int fo0 = (lane & 15) * 128 + ((((lane >> 4)) ^ (lane & 7)) << 4);
+    const int fo1 = (lane & 15) * 128 + ((((lane >> 4) + 4) ^ (lane & 7)) << 4);
+    // a lane's operand of the 128-deep MFMA: 32 bytes = the 16-byte chunks (lane / 16) and (lane / 16) + 4 of its row - for A and W
+    // alike, so both sides pair the same K elements (the sum does not care in which order k is visited)
+    typedef __attribute__((ext_vector_type(8))) int i32x8;
+    i32x8 fa[8], fw[8];
+    // accumulator (i, j) += W fragment j (x) A fragment i; M = 8 i + j is a compile-time constant at every call
+#define F64_MFMA(M, w, a) asm volatile("v_mfma_f32_16x16x128_f8f6f4 a[%c2:%c3], %0, %1, a[%c2:%c3]" :: "v"(w), "v"(a), "i"(4 * (M)), "i"(4 * (M) + 3))
+    // read accumulator (i, j) into four floats and clear it (the next tile's first MFMA then accumulates onto zero)
+    auto take = [&](auto m_c, float (&v)[4]) {
+        constexpr int R = 4 * decltype(m_c)::value;
+        asm volatile("v_accvgpr_read_b32 %0, a[%c4]\n\tv_accvgpr_read_b32 %1, a[%c5]\n\tv_accvgpr_read_b32 %2, a[%c6]\n\tv_accvgpr_read_b32 %3, a[%c7]\n\t"
+                     "v_accvgpr_write_b32 a[%c4], 0\n\tv_accvgpr_write_b32 a[%c5], 0\n\tv_accvgpr_write_b32 a[%c6], 0\n\tv_accvgpr_write_b32 a[%c7], 0"
+                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "i"(R), "i"(R + 1), "i"(R + 2), "i"(R + 3));
+    };
+
+    int tile = blockIdx.x;                                   // the output tile being multiplied
+    if (tile >= ntiles) return;
+    set_sources(tile);
+    int mC = mP, nC = nP;                                    // its corner (the epilogue's addresses)
+
+    F8_LOAD_SCALES(mC, nC);
+    // prologue: K tiles 0 and 1 of the first output tile (pairs 0-3)
+    F64_M0(lds_base);
+    asm volatile("s_nop 0" ::: "memory");
+    static_for<0, 8>([&](auto pc) { piece_w(pc, 0); });
+    F64_M0(lds_base + 32768);
+    asm volatile("s_nop 0" ::: "memory");
+    static_for<0, 8>([&](auto pc) { piece_a(pc, 0); });
+    F64_M0(lds_base + 65536);
+    asm volatile("s_nop 0" ::: "memory");
+    static_for<0, 8>([&](auto pc) { piece_w(pc, 128); });
+    F64_M0(lds_base + 98304);
+    asm volatile("s_nop 0" ::: "memory");
+    static_for<0, 8>([&](auto pc) { piece_a(pc, 128); });
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");        // my pieces of K tile 0 have landed
+    __builtin_amdgcn_s_barrier();                            // K tile 0 published
+    const int rdW0 = fo0 + wn * Q64_UNIT, rdW1 = fo1 + wn * Q64_UNIT;      // fragment-read offsets inside a pair, both K halves
+    const int rdA0 = fo0 + wm * Q64_UNIT, rdA1 = fo1 + wm * Q64_UNIT;
+    auto read_frag = [&](i32x8& f, lds_cptr p0, lds_cptr p1) {       // two ds_read_b128 into the halves of one 8-register operand
+        const u32x4 lo = *(const __attribute__((address_space(3))) u32x4*)p0;
+        const u32x4 hi = *(const __attribute__((address_space(3))) u32x4*)p1;
+        f[0] = (int)lo.x; f[1] = (int)lo.y; f[2] = (int)lo.z; f[3] = (int)lo.w;
+        f[4] = (int)hi.x; f[5] = (int)hi.y; f[6] = (int)hi.z; f[7] = (int)hi.w;
+    };
+#pragma unroll
+    for (int j = 0; j < 8; ++j) read_frag(fw[j], ring + rdW0 + j * 2048, ring + rdW1 + j * 2048);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) read_frag(fa[i], ring + 32768 + rdA0 + i * 2048, ring + 32768 + rdA1 + i * 2048);
+
+    int pW = 0;                                              // ring position (bytes) of the W pair of the K tile being multiplied
+    int extra = 0;                                           // what this wave's last epilogue left queued: its stores (NSTF, if it was inside N) + the NB bias loads
+    // One K tile of the workgroup's stream (g-th of the stream).  Nothing in it depends on where in an output tile it is except the
+    // DATA of the pieces it issues (set_sources two K tiles before a seam; kb) and, for a tile's first K tile (FIRST), the counted wait
+    // that has the previous epilogue's stores and bias loads in its queue.  After the last tile's K tile nt - 2 there is nothing left
+    // to fetch: the same pieces are issued once more (K tiles 0 and 1 of the last tile again, into pairs that are free by the
+    // protocol and never read), so every count stays what it is in the steady state.
+    auto ktile = [&](auto first_c, int kb) {
+        constexpr bool FIRST = decltype(first_c)::value;
+        const int pA = nx(pW), pW1 = nx(pA), pA1 = nx(pW1), pW2 = nx(pA1);     // pairs of g (A), g + 1 (W, A), g + 2 (W; its A pair is pW)
+        // The 64 MFMAs of K tile g (16 x 16 x 128, 32 cycles each: the cycles of the bf16 kernel's 128) run row by row, accumulator
+        // (i, j) = W fragment j x A fragment i, on ONE set of fragments: a fragment is dead once its last MFMA has issued, and is
+        // re-read for K tile g + 1 right then - A fragment i after row i (rows 0-3: after the rendezvous that publishes K tile g + 1),
+        // W fragment j after MFMA (7, j), eight MFMAs (256 cycles) before K tile g + 1 needs it.
+        // ---- step 0, rows 0-3: pieces of the W pair of K tile g + 2
+        static_for<0, 32>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            constexpr int i = m >> 3, j = m & 7;
+            if constexpr (m == 0) F64_M0(lds_base + pW2);
+            if constexpr (m >= 2 && m < 26 && (m - 2) % 3 == 0) piece_w(std::integral_constant<int, (m - 2) / 3>{}, kb);
+            F64_MFMA(m, fw[j], fa[i]);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        // ---- step 1, rows 4-7: rendezvous (K tile g + 1 published, every wave done with the LDS of K tile g), re-reads, pieces of
+        // the A pair of K tile g + 2
+        {
+            const lds_cptr pw0 = ring + pW1 + rdW0, pw1 = ring + pW1 + rdW1;
+            const lds_cptr pa0 = ring + pA1 + rdA0, pa1 = ring + pA1 + rdA1;
+            static_for<32, 64>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                constexpr int i = m >> 3, j = m & 7;
+                if constexpr (m == 35) F64_M0(lds_base + pW);        // the pair of K tile g's W units, free since the rendezvous
+                if constexpr (m >= 36 && m < 60 && (m - 36) % 3 == 0) piece_a(std::integral_constant<int, (m - 36) / 3>{}, kb);
+                F64_MFMA(m, fw[j], fa[i]);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (m == 33) {
+                    // in flight, oldest first: W(g+1), A(g+1), [the previous epilogue's stores and bias / scale loads,] W(g+2): retire K tile g + 1
+                    if constexpr (FIRST) {
+                        if (extra == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                        else if (extra == NB) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(8 + NB) : "memory");
+                        else asm volatile("s_waitcnt vmcnt(%0)" :: "i"(8 + NSTF + NB > 63 ? 63 : 8 + NSTF + NB) : "memory");     // (the counter holds 63: one operation stricter there)
+                    } else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (m >= 34 && m < 38) { read_frag(fa[m - 34], pa0 + (m - 34) * 2048, pa1 + (m - 34) * 2048); __builtin_amdgcn_sched_barrier(0); }   // rows 0-3, dead since step 0
+                if constexpr (j == 7 && i < 7) { read_frag(fa[i], pa0 + i * 2048, pa1 + i * 2048); __builtin_amdgcn_sched_barrier(0); }                         // row i just ended
+                if constexpr (i == 7) { read_frag(fw[j], pw0 + j * 2048, pw1 + j * 2048); __builtin_amdgcn_sched_barrier(0); }
+                if constexpr (m == 63) { read_frag(fa[7], pa0 + 7 * 2048, pa1 + 7 * 2048); __builtin_amdgcn_sched_barrier(0); }
+            });
+        }
+        pW = pW1;
+    };
+    for (;;) {
+        ktile(std::true_type{}, 256);
+        for (int t = 1; t + 2 < nt; ++t) ktile(std::false_type{}, (t + 2) * 128);
+        if (tile + (int)gridDim.x < ntiles) set_sources(tile + gridDim.x);
+        ktile(std::false_type{}, 0);
+        ktile(std::false_type{}, 128);
+
+        // ==== the output tile is complete: register-direct epilogue of tile (mC, nC); the next tile's K tiles 0 and 1 are in flight
+        // or landed meanwhile, its first fragments are being read into set 0.  Every accumulator is cleared as it is read.
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");    // the last MFMAs' results (inline asm: no hazard tracking by the compiler)
+        __builtin_amdgcn_sched_barrier(0);
+        const int colbase = nC + wn * 128;                   // wave-uniform; N % 128 == 0 -> a wave is all in or all out
+        const bool inside = colbase < N;
+        if (inside) {                                        // one wave-uniform branch around the whole epilogue: every load / store below
+                                                             // always issues, so the counted waits (mine and the compiler's) are exact
+            const int fr = lane & 15, fq = lane >> 4;
+            if constexpr (EPI != 4) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(sar[j]));   // loaded a tile ago (retired in order ahead of pieces long since waited for)
+                asm volatile("" : "+v"(swc[0]), "+v"(swc[1]), "+v"(bc0), "+v"(bc1));
+                const unsigned bcm = (bc0 & 0xffffu) | (bc1 << 16);
+                // bias of column 16 j + 4 fq + r (E = 4 j + r): lane E % 16 of the row, half E / 16
+                auto bvf = [&](auto e_c) -> float {
+                    constexpr int E = decltype(e_c)::value;
+                    unsigned r;
+                    asm volatile("v_mov_b32_dpp %0, %1 row_newbcast:%c2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(bcm), "i"(E & 15));
+                    return __uint_as_float(E < 16 ? (r << 16) : (r & 0xffff0000u));
+                };
+                const uint32_t off0 = (uint32_t)(((mC + wm * 128 + fr) * ldc + colbase + (fq & 1) * 16 + (fq >> 1) * 8) * 2);
+                // EPI 5: out = bf16(residual + y0), y0 = bf16(acc + bias) (the rounding points of epilogue_rows_res).  The residual of
+                // block b = 4 i + p (16 rows x 32 columns per wave-instruction, 16 B per lane, the addresses the store will use) is in
+                // flight 8 blocks ahead, in 32 registers: issued at the start for blocks 0-7, then the load of block b + 8 right after
+                // the store of block b.  One counted wait per block: the operations younger than the load of block b are the 7 loads
+                // after it, or — from block 7 on — the 7 store / load pairs issued since (14), and at the end the stores alone.
+                u32x4 rres[8];
+                const uint32_t roff0 = EPI == 5 ? (uint32_t)(((mC + wm * 128 + fr) * ld_res + colbase + (fq & 1) * 16 + (fq >> 1) * 8) * 2) : 0u;
+                if constexpr (EPI == 5) {
+                    static_for<0, 8>([&](auto bc) {
+                        constexpr int bb = decltype(bc)::value;
+                        rres[bb] = __builtin_amdgcn_raw_buffer_load_b128(rrs, roff0 + (uint32_t)((bb >> 2) * 16 * ld_res * 2 + (bb & 3) * 64), 0, 0);
+                    });
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                static_for<0, 8>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    static_for<0, 4>([&](auto pc) {
+                        constexpr int p = decltype(pc)::value;
+                        float y[2][4], c[2][4];
+                        take(std::integral_constant<int, 8 * i + 2 * p>{}, c[0]);
+                        take(std::integral_constant<int, 8 * i + 2 * p + 1>{}, c[1]);
+                        float sc[2][4], bb[2][4];                       // a_scale[m] * w_scale[n] is applied as (acc * a) * w, like the 8-wave kernel
+                        static_for<0, 8>([&](auto ec) {
+                            constexpr int e8 = decltype(ec)::value;
+                            sc[e8 >> 2][e8 & 3] = swf(std::integral_constant<int, 8 * p + e8>{});
+                            bb[e8 >> 2][e8 & 3] = bvf(std::integral_constant<int, 8 * p + e8>{});
+                        });
+                        if constexpr (EPI == 1) {                       // erf GELU, two values per packed instruction
+    #pragma unroll
+                            for (int h = 0; h < 2; ++h)
+    #pragma unroll
+                                for (int r = 0; r < 4; r += 2) {
+                                    const f32x2 g2 = gelu_erf_fast2(f32x2{rbf(c[h][r] * sar[i] * sc[h][r] + bb[h][r]), rbf(c[h][r + 1] * sar[i] * sc[h][r + 1] + bb[h][r + 1])});
+                                    y[h][r] = g2[0]; y[h][r + 1] = g2[1];
+                                }
+                        } else {
+    #pragma unroll
+                            for (int h = 0; h < 2; ++h)
+    #pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const float v = c[h][r] * sar[i] * sc[h][r] + bb[h][r];     // C = (Aq . Wq^T) * a_scale[m] * w_scale[n] (+ bias)
+                                    y[h][r] = (EPI == 0 || EPI == 5) ? v : act_apply(rbf(v), EPI);
+                                }
+                        }
+                        uint32_t a0 = pack_bf2(y[0][0], y[0][1]), a1 = pack_bf2(y[0][2], y[0][3]);
+                        uint32_t b0 = pack_bf2(y[1][0], y[1][1]), b1 = pack_bf2(y[1][2], y[1][3]);
+                        swap16(a0, b0);
+                        swap16(a1, b1);
+                        u32x4 outv = u32x4{a0, a1, b0, b1};         // 8 consecutive columns of y0 = bf16(acc + bias)
+                        if constexpr (EPI == 5) {
+                            constexpr int bb = 4 * i + p;
+                            constexpr int younger = bb < 7 ? 7 + bb : (bb <= 24 ? 14 : 7 + (31 - bb));
+                            __builtin_amdgcn_sched_barrier(0);
+                            asm volatile("s_waitcnt vmcnt(%0)" :: "i"(younger) : "memory");
+                            __builtin_amdgcn_sched_barrier(0);
+                            float q[8], tt[8], z[8];
+                            unpack8(rres[bb & 7], q);
+                            unpack8(outv, tt);
+    #pragma unroll
+                            for (int e = 0; e < 8; ++e) z[e] = q[e] + tt[e];
+                            outv = pack8(z);
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b128(outv, crs, off0 + (uint32_t)(i * 16 * ldc * 2 + p * 64), 0, 0);
+                        if constexpr (EPI == 5 && 4 * i + p + 8 < 32) {
+                            constexpr int nb = 4 * i + p + 8;
+                            __builtin_amdgcn_sched_barrier(0);
+                            rres[nb & 7] = __builtin_amdgcn_raw_buffer_load_b128(rrs, roff0 + (uint32_t)((nb >> 2) * 16 * ld_res * 2 + (nb & 3) * 64), 0, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                });
+            } else {
+                // packed column blocks of 16: acc[.][4q] gate / acc[.][4q+1] up of output block 2q, acc[.][4q+2] / acc[.][4q+3] of 2q+1
+                const uint32_t off0 = (uint32_t)(((mC + wm * 128 + fr) * ldc + (colbase >> 1) + (fq & 1) * 16 + (fq >> 1) * 8) * 2);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(sar[j]));
+                asm volatile("" : "+v"(swc[0]), "+v"(swc[1]));
+                static_for<0, 8>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    static_for<0, 2>([&](auto qc) {
+                        constexpr int q = decltype(qc)::value;
+                        float y[2][4], c[4][4];
+                        take(std::integral_constant<int, 8 * i + 4 * q>{}, c[0]);
+                        take(std::integral_constant<int, 8 * i + 4 * q + 1>{}, c[1]);
+                        take(std::integral_constant<int, 8 * i + 4 * q + 2>{}, c[2]);
+                        take(std::integral_constant<int, 8 * i + 4 * q + 3>{}, c[3]);
+                        float sc[4][4];
+                        static_for<0, 16>([&](auto ec) { constexpr int e16 = decltype(ec)::value; sc[e16 >> 2][e16 & 3] = swf(std::integral_constant<int, 16 * q + e16>{}); });
+    #pragma unroll
+                        for (int h = 0; h < 2; ++h)
+    #pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                y[h][r] = rbf(silu_fast(rbf(c[2 * h][r] * sar[i] * sc[2 * h][r]))) * rbf(c[2 * h + 1][r] * sar[i] * sc[2 * h + 1][r]);
+                        uint32_t a0 = pack_bf2(y[0][0], y[0][1]), a1 = pack_bf2(y[0][2], y[0][3]);
+                        uint32_t b0 = pack_bf2(y[1][0], y[1][1]), b1 = pack_bf2(y[1][2], y[1][3]);
+                        swap16(a0, b0);
+                        swap16(a1, b1);
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{a0, a1, b0, b1}, crs, off0 + (uint32_t)(i * 16 * ldc * 2 + q * 64), 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                });
+            }
+        } else {
+            // a wave past N (the last tile column when N % 256 == 128): nothing to store, but its accumulators start the next tile too
+            static_for<0, 64>([&](auto mc) {
+                constexpr int R = 4 * decltype(mc)::value;
+                asm volatile("v_accvgpr_write_b32 a[%c0], 0\n\tv_accvgpr_write_b32 a[%c1], 0\n\tv_accvgpr_write_b32 a[%c2], 0\n\tv_accvgpr_write_b32 a[%c3], 0"
+                             :: "i"(R), "i"(R + 1), "i"(R + 2), "i"(R + 3));
+            });
+        }
+        asm volatile("s_nop 1" ::: "memory");                // accumulator writes (v_accvgpr_write) ahead of the next inline-asm MFMA
+        __builtin_amdgcn_sched_barrier(0);
+        if (tile + (int)gridDim.x >= ntiles) break;
+        tile += gridDim.x;
+        mC = mP; nC = nP;
+        F8_LOAD_SCALES(mC, nC);
+        __builtin_amdgcn_sched_barrier(0);
+        extra = (inside ? NSTF : 0) + NB;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the spare pieces issued after the last tile's K tile nt - 2 land in LDS: not after the workgroup is gone
+#undef F64_MFMA
+#undef F64_M0
+#undef F64_PIECE
+#undef F8_BS1
+#undef F8_WS1
+#undef F8_AS1
+#undef F8_LOAD_SCALES
+}
 
 // ------------------------------------------------------------------------------------------------
 // "mid" kernel (round 3): 128 x 128 tiles for the row counts between the weight-streaming kernel (M <= 32) and the 256-tile
@@ -1676,6 +2057,7 @@ extern "C" int licv_gemm_debug_timestamps(void* dev_buffer) {
     return rc != LICV_OK ? rc : licv_gemm_exp_debug_timestamps(dev_buffer);
 }
 
+static int g_fp8_flow64 = 1;       // knob 8: 0 = fp8 GEMMs stay on the 8-wave kernel with the 32-deep fp8 MFMA (A/B, tests)
 static int g_skinny_inlaunch = 0;   // knob 7: 1 = the skinny kernel reduces over its splits inside its own launch (last workgroup of a tile).  Off: measured cold at
                                     // M = 24 it only moves the finalize's ~5 us into the producer's tail (12288 x 4096: 36.1 vs 32.3 us with the separate launch;
                                     // 4096 x 4096: 16.9 vs 18.3), see tools/stream_bench.py; kept as a tested alternative
@@ -1690,6 +2072,7 @@ static int g_flow_default = 1;  // auto mode takes the flow kernels where they a
 //   knob 2: 0 = never take a flow kernel by default;  knob 4: 0 = licv_gemm_splitk_plan always answers "one pass" (the
 //   batch-independence tests switch split-K off for every caller, the native layer runner included)
 //   knob 7: 1 = the skinny kernel reduces over its splits in its own launch (default 0: a separate finalize launch)
+//   knob 8: 0 = fp8 GEMMs never take the 4-wave kernel on the 128-deep MFMA
 extern "C" int licv_gemm_experiment(int knob, int value) {
     if (knob == 0) return licv_gemm_exp_knob(0, value);
     else if (knob == 1) g_pp_group = value; else if (knob == 2) g_flow_default = value;
@@ -1697,6 +2080,7 @@ extern "C" int licv_gemm_experiment(int knob, int value) {
     else if (knob == 5) g_force_splits = value;
     else if (knob == 6) g_big_tiles = value;
     else if (knob == 7) g_skinny_inlaunch = value;
+    else if (knob == 8) g_fp8_flow64 = value;
     else return licv_set_error(LICV_E_BADARG, "gemm_experiment: unknown knob %d", knob);
     return LICV_OK;
 }
@@ -1739,8 +2123,23 @@ static bool flow64_scratch_free() {
     return ok == 1;
 }
 
-// 1: the 8-wave flow kernel is usable; 2: the 4-wave flow64 kernel as well (bit 1)
-extern "C" int licv_gemm_flow_available(void) { return (flow_scratch_free() ? 1 : 0) | (flow64_scratch_free() ? 2 : 0); }
+// per epilogue family: an instantiation with a private segment (spills would sit in the counted vmcnt queue) is not used
+static bool fp8_flow64_scratch_free(int epi) {
+    static int ok[6] = {-1, -1, -1, -1, -1, -1};
+    if (ok[0] < 0) {
+        const void* fns[6] = {(const void*)gemm_fp8_flow64_k<0>, (const void*)gemm_fp8_flow64_k<1>, (const void*)gemm_fp8_flow64_k<2>,
+                              (const void*)gemm_fp8_flow64_k<3>, (const void*)gemm_fp8_flow64_k<4>, (const void*)gemm_fp8_flow64_k<5>};
+        for (int i = 0; i < 6; ++i) {
+            hipFuncAttributes at;
+            ok[i] = (hipFuncGetAttributes(&at, fns[i]) == hipSuccess && at.localSizeBytes == 0) ? 1 : 0;
+            (void)hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 10 * Q64_UNIT);
+        }
+    }
+    return ok[epi] == 1;
+}
+
+// 1: the 8-wave flow kernel is usable; 2: the 4-wave flow64 kernel as well (bit 1); 4: its fp8 form (bit 2)
+extern "C" int licv_gemm_flow_available(void) { return (flow_scratch_free() ? 1 : 0) | (flow64_scratch_free() ? 2 : 0) | (fp8_flow64_scratch_free(0) && fp8_flow64_scratch_free(4) ? 4 : 0); }
 
 // Which tile size a dense GEMM takes.  The 256 x 256 kernels (flow64 / quad64) need enough tiles to fill the 256 CUs: below
 // g_big_tiles of them (the vision tower on a few images: 2056 rows = 9 tile rows; Idefics2's 1-shot text stack) the 128 x 128
@@ -2051,6 +2450,29 @@ extern "C" int licv_gemm_fp8(const void* Aq, int64_t lda, const float* a_scale, 
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_fp8_pingpong_k, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES); attr = true; }
     const int tiles_m = (int)((M + 255) / 256), tiles_n = (int)((N + 255) / 256);
+    // the 4-wave kernel on the 128-deep MFMA: the flow64 conditions in bytes (whole waves in or out of N, four 128-byte K tiles,
+    // accumulator-only epilogues or a bf16 residual, 32-bit offsets), and no private segment in any instantiation
+    const bool res_ok = e->residual && e->residual_dtype == LICV_BF16 && !e->act && !e->swiglu && e->ld_res % 8 == 0 &&
+                        (int64_t)(M + 256) * e->ld_res * 2 < (1ll << 31);
+    const bool f64 = g_fp8_flow64 && M >= 512 && N >= 256 && N % 128 == 0 && K % 128 == 0 && K >= 512 && e->out_dtype == LICV_BF16 &&
+                     (!e->residual || res_ok) && !e->row_gate && !e->use_scale && (int64_t)(M + 256) * ldc * 2 < (1ll << 31) && ldc % 8 == 0 &&
+                     lda * 510 < (1ll << 31) && ldw * 510 < (1ll << 31) && (!e->bias_bf16 || ((uintptr_t)e->bias_bf16 & 3) == 0) &&
+                     ((uintptr_t)a_scale & 3) == 0 && ((uintptr_t)w_scale & 15) == 0 &&
+                     fp8_flow64_scratch_free(e->residual ? 5 : (e->swiglu ? 4 : e->act));
+    if (f64) {
+        const int pp_group = g_pp_group > 0 ? g_pp_group : (tiles_n <= 6 ? 2 : 8);
+        const dim3 grid(min(tiles_m * tiles_n, g_num_cus)), block(256);
+#define F8FLOW(E) gemm_fp8_flow64_k<E><<<grid, block, 10 * Q64_UNIT, (hipStream_t)stream>>>( \
+            (const char*)Aq, lda, (const char*)Wq, ldw, a_scale, w_scale, (bf16_t*)C, (int)ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep.bias, pp_group)
+        if (e->residual)
+            gemm_fp8_flow64_k<5><<<grid, block, 10 * Q64_UNIT, (hipStream_t)stream>>>(
+                (const char*)Aq, lda, (const char*)Wq, ldw, a_scale, w_scale, (bf16_t*)C, (int)ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep.bias, pp_group,
+                (const bf16_t*)e->residual, (int)e->ld_res);
+        else if (e->swiglu) F8FLOW(4); else if (e->act == 1) F8FLOW(1); else if (e->act == 2) F8FLOW(2); else if (e->act == 3) F8FLOW(3); else F8FLOW(0);
+#undef F8FLOW
+        LICV_LAUNCH_CHECK();
+        return LICV_OK;
+    }
     gemm_fp8_pingpong_k<<<dim3(tiles_m * tiles_n), dim3(512), RING_STAGES * RING_STAGE_BYTES, (hipStream_t)stream>>>(
         (const char*)Aq, lda, (const char*)Wq, ldw, C, ldc, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep);
     LICV_LAUNCH_CHECK();
