@@ -414,7 +414,7 @@ def main():
         trainer, train_args = build_trainer(arch, sd, dev, B, S, n_img, min_len, rank, hw=IDEFICS2_IMAGE[preset] if is2 else None)
         eng = trainer.m.interface.engine
     elif is2:
-        eng = Idefics2Engine(Idefics2Weights(sd, arch, dev, fp8_text="fp8" in args.workload))
+        eng = Idefics2Engine(Idefics2Weights(sd, arch, dev, fp8_text="fp8" in args.workload, fp8_vision="fp8" in args.workload))
     else:
         eng = IdeficsEngine(IdeficsWeights(sd, arch, dev))
     if args.batch_streams >= 0 and hasattr(eng, "batch_streams"):
@@ -580,7 +580,7 @@ def main():
         "value": qps, "unit": "questions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "ms_per_step_median": median_ms, "value_at_median": B * world / (median_ms * 1e-3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "fp8 e4m3 text-stack GEMM operands (fp32 accumulate), bf16 elsewhere" if "fp8" in args.workload else "bf16", "data": f"synthetic (random-init {preset} weights, seeded image+text batches)",
+        "dtype": "fp8 e4m3 GEMM operands in the text stack and the SigLIP tower (v_mfma_f32_16x16x128_f8f6f4, fp32 accumulate), bf16 elsewhere" if "fp8" in args.workload else "bf16", "data": f"synthetic (random-init {preset} weights, seeded image+text batches)",
         "config": {"workload": args.workload, "arch": preset, "questions_per_gpu": B, "seq_len": S, "images_per_question": n_img,
                    "hooked_layers": 0 if args.no_hooks else arch.num_layers, "parallelism": f"dp{world}",
                    **({"train": "teacher fwd + student fwd/bwd + KL; accumulate 2; 1 all-reduce of 131 105 fp32 + AdamW per optimiser step"} if training else {})},

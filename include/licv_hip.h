@@ -140,6 +140,19 @@ int licv_gemm_bf16_splitk(const void* A, int64_t lda, const void* W, int64_t ldw
  * once with the same kernel (rows = output channels); activations per call. */
 int licv_quantize_rows_fp8(const void* x, int x_dtype, void* q_fp8, float* scale, int64_t rows, int64_t dim,
                            int64_t ld_x, int64_t ld_q, void* stream);
+/* The row kernels that feed an fp8 GEMM write the fp8 image of their rows themselves (exactly licv_quantize_rows_fp8 of the bf16
+ * rows they produce: e4m3 bytes (rows, dim) + one fp32 scale per row) - `out_bf16` may be NULL when nothing else reads the rows.
+ * Rows are contiguous (ld = dim).  rmsnorm: as licv_rmsnorm_fwd; add_rmsnorm: as licv_add_rmsnorm_fwd without gate / scale;
+ * inject_renorm_add: as licv_inject_renorm_add_fwd (xn_bf16 may be NULL); layernorm: as licv_layernorm_fwd, dim % 8 == 0. */
+int licv_rmsnorm_fwd_q8(const void* x, int x_dtype, const void* w_bf16, void* out_bf16, void* q_fp8, float* q_scale, int64_t rows, int64_t dim,
+                        float eps, int flavour, void* stream);
+int licv_add_rmsnorm_fwd_q8(void* h, int h_dtype, const void* branch_bf16, const void* w_bf16, void* out_bf16, void* q_fp8, float* q_scale,
+                            int64_t rows, int64_t dim, float eps, int flavour, void* stream);
+int licv_inject_renorm_add_fwd_q8(const void* branch, int branch_dtype, const float* icv_row, const float* alpha,
+                                  const void* residual, int residual_dtype, float* out_f32, int64_t rows, int64_t hidden,
+                                  const void* norm_w_bf16, void* xn_bf16, void* q_fp8, float* q_scale, float norm_eps, int norm_flavour, void* stream);
+int licv_layernorm_fwd_q8(const void* x_bf16, const void* w_bf16, const void* b_bf16, void* out_bf16, void* q_fp8, float* q_scale,
+                          int64_t rows, int64_t dim, float eps, void* stream);
 /* C = epilogue( (Aq . Wq^T) * a_scale[m] * w_scale[n] ), fp32 accumulate on v_mfma_f32_16x16x32_fp8_fp8; same epilogue
  * struct as licv_gemm_bf16.  Aq (M, K) and Wq (N, K) e4m3 bytes, K >= 256, K % 64 == 0, leading dims in bytes. */
 int licv_gemm_fp8(const void* Aq, int64_t lda, const float* a_scale, const void* Wq, int64_t ldw, const float* w_scale,

@@ -33,12 +33,44 @@ __device__ __forceinline__ void store4_bf16(void* p, int64_t i, floatx4 v) {
 // ------------------------------------------------------------------------------------------------
 // ICV hook forward.  ref:icv_src/icv_model/icv_intervention.py:62-84
 // ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+// fp8 image of a normalised row, written by the kernel that produced the row (BASELINE configs[4]: the GEMM that follows takes OCP
+// e4m3 operands with one scale per row).  Exactly licv_quantize_rows_fp8 applied to the row's bf16 values - amax, scale =
+// max(amax, 1e-12) / 448, e4m3(y / scale) - without the separate pass over it (that pass cost as much as the fp8 GEMMs it fed:
+// 7 % of the Idefics2 32-shot step).  q == nullptr: off.  The bf16 row itself need not be written at all then (out == nullptr).
+// ------------------------------------------------------------------------------------------------
+struct Q8Out { uint8_t* q; float* scale; };
+
+template <int NCH>       // y: the row as NCH x 4 values per lane, chunk c at element (c * 64 + lane) * 4, already rounded to bf16
+__device__ __forceinline__ void emit_row_fp8(const floatx4 (&y)[NCH], int dim, int lane, uint8_t* __restrict__ qrow, float* __restrict__ scale_slot) {
+    float amax = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const bool ok = (c * 64 + lane) * 4 < dim;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) amax = fmaxf(amax, ok ? fabsf(y[c][j]) : 0.f);
+    }
+    amax = wave_max(amax);
+    const float sc = fmaxf(amax, 1e-12f) / 448.0f;
+    if (lane == 0) *scale_slot = sc;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int i = (c * 64 + lane) * 4;
+        if (i < dim) {
+            int w = __builtin_amdgcn_cvt_pk_fp8_f32(y[c][0] / sc, y[c][1] / sc, 0, false);
+            w = __builtin_amdgcn_cvt_pk_fp8_f32(y[c][2] / sc, y[c][3] / sc, w, true);
+            *reinterpret_cast<int*>(qrow + i) = w;
+        }
+    }
+}
+
 template <int DT, int NCH, bool FUSE_NORM>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK)
 void inject_renorm_fwd_k(const void* __restrict__ h, const float* __restrict__ icv, const float* __restrict__ alpha,
                          float* __restrict__ out, int64_t rows, int hidden,
                          const bf16_t* __restrict__ norm_w, bf16_t* __restrict__ xn, float eps,
-                         const void* __restrict__ res, int res_dt, int norm_flavour, const bf16_t* __restrict__ pre = nullptr) {
+                         const void* __restrict__ res, int res_dt, int norm_flavour, const bf16_t* __restrict__ pre = nullptr,
+                         Q8Out q8 = Q8Out{nullptr, nullptr}) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -134,9 +166,12 @@ void inject_renorm_fwd_k(const void* __restrict__ h, const float* __restrict__ i
                 floatx4 y;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) y[j] = wvv[c][j] * (norm_flavour == 1 ? x[c][j] * rs : rbf(x[c][j] * rs));
-                store4_bf16(xn, base + i, y);
+                if (xn) store4_bf16(xn, base + i, y);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x[c][j] = rbf(y[j]);
             }
         }
+        if (q8.q) emit_row_fp8<NCH>(x, hidden, lane, q8.q + base, q8.scale + row);
     }
 }
 
@@ -207,7 +242,7 @@ void inject_renorm_bwd_k(const void* __restrict__ h, const float* __restrict__ i
 template <int DT, int NCH>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK)
 void rmsnorm_fwd_k(const void* __restrict__ x, const bf16_t* __restrict__ w, bf16_t* __restrict__ out,
-                   int64_t rows, int dim, int64_t inner, int64_t ld_x, int64_t ld_out, float eps, int flavour) {
+                   int64_t rows, int dim, int64_t inner, int64_t ld_x, int64_t ld_out, float eps, int flavour, Q8Out q8 = Q8Out{nullptr, nullptr}) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -240,9 +275,12 @@ void rmsnorm_fwd_k(const void* __restrict__ x, const bf16_t* __restrict__ w, bf1
                 const float n = v[c][j] * rs;
                 y[j] = wv[c][j] * (single_round ? n : rbf(n));
             }
-            store4_bf16(out, ob + i, y);
+            if (out) store4_bf16(out, ob + i, y);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[c][j] = rbf(y[j]);
         }
     }
+    if (q8.q) emit_row_fp8<NCH>(v, dim, lane, q8.q + row * dim, q8.scale + row);       // (contiguous rows: the q8 entry point takes inner = 1)
 }
 
 // h += branch (in place, in the stream's dtype: a bf16 stream rounds the sum — the o-projection's residual epilogue, folded in here so
@@ -250,7 +288,8 @@ void rmsnorm_fwd_k(const void* __restrict__ x, const bf16_t* __restrict__ w, bf1
 template <int DT, int NCH>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK)
 void add_rmsnorm_fwd_k(void* __restrict__ h, const bf16_t* __restrict__ branch, const bf16_t* __restrict__ w, bf16_t* __restrict__ out,
-                       int64_t rows, int dim, float eps, int flavour, const float* __restrict__ row_gate, int use_scale, float scale) {
+                       int64_t rows, int dim, float eps, int flavour, const float* __restrict__ row_gate, int use_scale, float scale,
+                       Q8Out q8 = Q8Out{nullptr, nullptr}) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -298,9 +337,12 @@ void add_rmsnorm_fwd_k(void* __restrict__ h, const bf16_t* __restrict__ branch, 
                 const float n = v[c][j] * rs;
                 y[j] = wv[c][j] * (single_round ? n : rbf(n));
             }
-            store4_bf16(out, base + i, y);
+            if (out) store4_bf16(out, base + i, y);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[c][j] = rbf(y[j]);
         }
     }
+    if (q8.q) emit_row_fp8<NCH>(v, dim, lane, q8.q + base, q8.scale + row);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -324,7 +366,7 @@ template <int NCH>      // chunks of 512 elements
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK)
 void layernorm8_fwd_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, const bf16_t* __restrict__ b,
                       bf16_t* __restrict__ out, int64_t rows, int dim, int64_t inner, int64_t ld_x, int64_t ld_out,
-                      int64_t out_group, int64_t out_group_extra, float eps) {
+                      int64_t out_group, int64_t out_group_extra, float eps, Q8Out q8 = Q8Out{nullptr, nullptr}) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -362,7 +404,33 @@ void layernorm8_fwd_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w
             load8_bf16(b + i, bv);
 #pragma unroll
             for (int j = 0; j < 8; ++j) y[j] = (v[c][j] - mean) * rstd * wv[j] + bv[j];
-            store8_bf16(op + i, y);
+            if (out) store8_bf16(op + i, y);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[c][j] = rbf(y[j]);
+        }
+    }
+    if (q8.q) {                                              // the fp8 image of the row (contiguous rows), see emit_row_fp8
+        float amax = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const bool ok = (c * 64 + lane) * 8 < dim;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) amax = fmaxf(amax, ok ? fabsf(v[c][j]) : 0.f);
+        }
+        amax = wave_max(amax);
+        const float sc = fmaxf(amax, 1e-12f) / 448.0f;
+        if (lane == 0) q8.scale[row] = sc;
+        uint8_t* qrow = q8.q + row * dim;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int i = (c * 64 + lane) * 8;
+            if (i < dim) {
+                int w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[c][0] / sc, v[c][1] / sc, 0, false);
+                w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[c][2] / sc, v[c][3] / sc, w0, true);
+                int w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[c][4] / sc, v[c][5] / sc, 0, false);
+                w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[c][6] / sc, v[c][7] / sc, w1, true);
+                *reinterpret_cast<int2*>(qrow + i) = int2{w0, w1};
+            }
         }
     }
 }
@@ -703,12 +771,12 @@ static inline int flat_blocks(int64_t total) {
 
 static int inject_fwd_impl(const void* h, int h_dtype, const float* icv_row, const float* alpha, float* out, int64_t rows, int64_t hidden,
                            const void* norm_w, void* xn_out, float norm_eps, const void* res, int res_dt, int norm_flavour, void* stream,
-                           const void* pre);
+                           const void* pre, Q8Out q8);
 
 extern "C" int licv_inject_renorm_fwd(const void* h, int h_dtype, const float* icv_row, const float* alpha,
                                       float* out, int64_t rows, int64_t hidden,
                                       const void* norm_w, void* xn_out, float norm_eps, void* stream) {
-    return inject_fwd_impl(h, h_dtype, icv_row, alpha, out, rows, hidden, norm_w, xn_out, norm_eps, nullptr, 0, 0, stream, nullptr);
+    return inject_fwd_impl(h, h_dtype, icv_row, alpha, out, rows, hidden, norm_w, xn_out, norm_eps, nullptr, 0, 0, stream, nullptr, Q8Out{nullptr, nullptr});
 }
 
 // The same hook with the layer's last residual add folded in: the edited tensor is h + branch (the stream's dtype: a bf16 stream
@@ -718,7 +786,7 @@ extern "C" int licv_inject_renorm_pre_fwd(const void* h, int h_dtype, const void
                                           float* out, int64_t rows, int64_t hidden,
                                           const void* norm_w, void* xn_out, float norm_eps, void* stream) {
     LICV_CHECK_ARG(branch_bf16, "inject_renorm_pre_fwd: null branch");
-    return inject_fwd_impl(h, h_dtype, icv_row, alpha, out, rows, hidden, norm_w, xn_out, norm_eps, nullptr, 0, 0, stream, branch_bf16);
+    return inject_fwd_impl(h, h_dtype, icv_row, alpha, out, rows, hidden, norm_w, xn_out, norm_eps, nullptr, 0, 0, stream, branch_bf16, Q8Out{nullptr, nullptr});
 }
 
 extern "C" int licv_inject_renorm_add_fwd(const void* branch, int branch_dtype, const float* icv_row, const float* alpha,
@@ -728,16 +796,27 @@ extern "C" int licv_inject_renorm_add_fwd(const void* branch, int branch_dtype, 
     LICV_CHECK_ARG(residual_dtype == LICV_BF16 || residual_dtype == LICV_F32, "inject_renorm_add_fwd: bad residual dtype");
     LICV_CHECK_ARG(norm_flavour == 0 || norm_flavour == 1, "inject_renorm_add_fwd: bad norm flavour");
     return inject_fwd_impl(branch, branch_dtype, icv_row, alpha, out, rows, hidden, norm_w, xn_out, norm_eps, residual, residual_dtype,
-                           norm_flavour, stream, nullptr);
+                           norm_flavour, stream, nullptr, Q8Out{nullptr, nullptr});
+}
+
+// ... with the fp8 image of the normalised rows (and, optionally, no bf16 copy of them: xn_out may be NULL)
+extern "C" int licv_inject_renorm_add_fwd_q8(const void* branch, int branch_dtype, const float* icv_row, const float* alpha,
+                                             const void* residual, int residual_dtype, float* out, int64_t rows, int64_t hidden,
+                                             const void* norm_w, void* xn_out, void* q_fp8, float* q_scale, float norm_eps, int norm_flavour, void* stream) {
+    LICV_CHECK_ARG(residual && norm_w && q_fp8 && q_scale, "inject_renorm_add_fwd_q8: null pointer");
+    LICV_CHECK_ARG(residual_dtype == LICV_BF16 || residual_dtype == LICV_F32, "inject_renorm_add_fwd_q8: bad residual dtype");
+    LICV_CHECK_ARG(norm_flavour == 0 || norm_flavour == 1, "inject_renorm_add_fwd_q8: bad norm flavour");
+    return inject_fwd_impl(branch, branch_dtype, icv_row, alpha, out, rows, hidden, norm_w, xn_out, norm_eps, residual, residual_dtype,
+                           norm_flavour, stream, nullptr, Q8Out{(uint8_t*)q_fp8, q_scale});
 }
 
 static int inject_fwd_impl(const void* h, int h_dtype, const float* icv_row, const float* alpha, float* out, int64_t rows, int64_t hidden,
                            const void* norm_w, void* xn_out, float norm_eps, const void* res, int res_dt, int norm_flavour, void* stream,
-                           const void* pre) {
+                           const void* pre, Q8Out q8) {
     LICV_CHECK_ARG(h && icv_row && out, "inject_renorm_fwd: null pointer");
     LICV_CHECK_ARG(hidden > 0 && hidden % 4 == 0, "inject_renorm_fwd: hidden (%lld) must be a positive multiple of 4", (long long)hidden);
     LICV_CHECK_ARG(h_dtype == LICV_BF16 || h_dtype == LICV_F32, "inject_renorm_fwd: bad dtype %d", h_dtype);
-    LICV_CHECK_ARG((norm_w == nullptr) == (xn_out == nullptr), "inject_renorm_fwd: norm_w and xn_out go together");
+    LICV_CHECK_ARG((norm_w == nullptr) == (xn_out == nullptr && q8.q == nullptr), "inject_renorm_fwd: norm_w and xn_out (or the fp8 image) go together");
     if (rows <= 0) return LICV_OK;
     const int64_t dim_ = hidden;
     const int nch = pick_nch(hidden);
@@ -745,7 +824,7 @@ static int inject_fwd_impl(const void* h, int h_dtype, const float* icv_row, con
     const dim3 grid(row_blocks(rows)), block(64 * WAVES_PER_BLOCK);
     const bool fuse = norm_w != nullptr;
 #define LAUNCH_INJ(DTV, FUSE) inject_renorm_fwd_k<DTV, N, FUSE><<<grid, block, 0, st>>>( \
-        h, icv_row, alpha, out, rows, (int)hidden, (const bf16_t*)norm_w, (bf16_t*)xn_out, norm_eps, res, res_dt, norm_flavour, (const bf16_t*)pre)
+        h, icv_row, alpha, out, rows, (int)hidden, (const bf16_t*)norm_w, (bf16_t*)xn_out, norm_eps, res, res_dt, norm_flavour, (const bf16_t*)pre, q8)
     if (h_dtype == LICV_F32) { if (fuse) { DISPATCH_NCH(nch, LAUNCH_INJ(LICV_F32, true)); } else { DISPATCH_NCH(nch, LAUNCH_INJ(LICV_F32, false)); } }
     else                     { if (fuse) { DISPATCH_NCH(nch, LAUNCH_INJ(LICV_BF16, true)); } else { DISPATCH_NCH(nch, LAUNCH_INJ(LICV_BF16, false)); } }
 #undef LAUNCH_INJ
@@ -815,6 +894,65 @@ extern "C" int licv_add_rmsnorm_fwd(void* h, int h_dtype, const void* branch_bf1
                                                                            row_gate, use_scale, scale)
     if (h_dtype == LICV_F32) { DISPATCH_NCH(nch, LAUNCH_ARMS(LICV_F32)); } else { DISPATCH_NCH(nch, LAUNCH_ARMS(LICV_BF16)); }
 #undef LAUNCH_ARMS
+    LICV_LAUNCH_CHECK();
+    return LICV_OK;
+}
+
+// ---- norms that also (or only: out may be NULL) write the fp8 image of their rows; contiguous rows of `dim` elements
+extern "C" int licv_rmsnorm_fwd_q8(const void* x, int x_dtype, const void* w, void* out, void* q_fp8, float* q_scale, int64_t rows, int64_t dim,
+                                   float eps, int flavour, void* stream) {
+    LICV_CHECK_ARG(x && w && q_fp8 && q_scale, "rmsnorm_fwd_q8: null pointer");
+    LICV_CHECK_ARG(dim >= 256 && dim % 4 == 0, "rmsnorm_fwd_q8: dim (%lld) must be a multiple of 4, >= 256", (long long)dim);
+    LICV_CHECK_ARG(x_dtype == LICV_BF16 || x_dtype == LICV_F32, "rmsnorm_fwd_q8: bad dtype %d", x_dtype);
+    LICV_CHECK_ARG(flavour == 0 || flavour == 1, "rmsnorm_fwd_q8: bad flavour %d", flavour);
+    if (rows <= 0) return LICV_OK;
+    const int64_t dim_ = dim;
+    const int nch = pick_nch(dim);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(row_blocks(rows)), block(64 * WAVES_PER_BLOCK);
+    const Q8Out q8{(uint8_t*)q_fp8, q_scale};
+#define LAUNCH_RMSQ(DTV) rmsnorm_fwd_k<DTV, N><<<grid, block, 0, st>>>(x, (const bf16_t*)w, (bf16_t*)out, rows, (int)dim, 1, dim, dim, eps, flavour, q8)
+    if (x_dtype == LICV_F32) { DISPATCH_NCH(nch, LAUNCH_RMSQ(LICV_F32)); } else { DISPATCH_NCH(nch, LAUNCH_RMSQ(LICV_BF16)); }
+#undef LAUNCH_RMSQ
+    LICV_LAUNCH_CHECK();
+    return LICV_OK;
+}
+
+extern "C" int licv_add_rmsnorm_fwd_q8(void* h, int h_dtype, const void* branch_bf16, const void* w, void* out, void* q_fp8, float* q_scale,
+                                       int64_t rows, int64_t dim, float eps, int flavour, void* stream) {
+    LICV_CHECK_ARG(h && branch_bf16 && w && q_fp8 && q_scale, "add_rmsnorm_fwd_q8: null pointer");
+    LICV_CHECK_ARG(dim > 0 && dim % 4 == 0, "add_rmsnorm_fwd_q8: dim (%lld) must be a multiple of 4", (long long)dim);
+    LICV_CHECK_ARG(h_dtype == LICV_BF16 || h_dtype == LICV_F32, "add_rmsnorm_fwd_q8: bad dtype %d", h_dtype);
+    LICV_CHECK_ARG(flavour == 0 || flavour == 1, "add_rmsnorm_fwd_q8: bad flavour %d", flavour);
+    if (rows <= 0) return LICV_OK;
+    const int64_t dim_ = dim;
+    const int nch = pick_nch(dim);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(row_blocks(rows)), block(64 * WAVES_PER_BLOCK);
+    const Q8Out q8{(uint8_t*)q_fp8, q_scale};
+#define LAUNCH_ARMSQ(DTV) add_rmsnorm_fwd_k<DTV, N><<<grid, block, 0, st>>>(h, (const bf16_t*)branch_bf16, (const bf16_t*)w, (bf16_t*)out, rows, (int)dim, eps, flavour, \
+                                                                            nullptr, 0, 0.f, q8)
+    if (h_dtype == LICV_F32) { DISPATCH_NCH(nch, LAUNCH_ARMSQ(LICV_F32)); } else { DISPATCH_NCH(nch, LAUNCH_ARMSQ(LICV_BF16)); }
+#undef LAUNCH_ARMSQ
+    LICV_LAUNCH_CHECK();
+    return LICV_OK;
+}
+
+extern "C" int licv_layernorm_fwd_q8(const void* x, const void* w, const void* b, void* out, void* q_fp8, float* q_scale, int64_t rows, int64_t dim,
+                                     float eps, void* stream) {
+    LICV_CHECK_ARG(x && w && b && q_fp8 && q_scale, "layernorm_fwd_q8: null pointer");
+    LICV_CHECK_ARG(dim >= 256 && dim <= 4096 && dim % 8 == 0, "layernorm_fwd_q8: dim (%lld) must be a multiple of 8 in [256, 4096]", (long long)dim);
+    LICV_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)b & 15) == 0 && (!out || ((uintptr_t)out & 15) == 0) && ((uintptr_t)q_fp8 & 7) == 0,
+                   "layernorm_fwd_q8: misaligned pointer");
+    if (rows <= 0) return LICV_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(row_blocks(rows)), block(64 * WAVES_PER_BLOCK);
+    const Q8Out q8{(uint8_t*)q_fp8, q_scale};
+    const int n8 = (int)((dim + 511) / 512);
+#define LAUNCH_LN8Q(NC) layernorm8_fwd_k<NC><<<grid, block, 0, st>>>((const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)out, rows, (int)dim, 1, dim, dim, 0, 0, eps, q8)
+    switch (n8) { case 1: LAUNCH_LN8Q(1); break; case 2: LAUNCH_LN8Q(2); break; case 3: LAUNCH_LN8Q(3); break; case 4: LAUNCH_LN8Q(4); break;
+                  case 5: LAUNCH_LN8Q(5); break; case 6: LAUNCH_LN8Q(6); break; case 7: LAUNCH_LN8Q(7); break; default: LAUNCH_LN8Q(8); break; }
+#undef LAUNCH_LN8Q
     LICV_LAUNCH_CHECK();
     return LICV_OK;
 }

@@ -78,6 +78,10 @@ def lib() -> C.CDLL:
             "licv_gemm_bf16": [P, I64, P, I64, P, I64, I64, I64, I64, C.POINTER(GemmEpilogue), P],
             "licv_pack_gate_up": [P, P, P, I64, I64, P],
             "licv_quantize_rows_fp8": [P, I, P, P, I64, I64, I64, I64, P],
+            "licv_rmsnorm_fwd_q8": [P, I, P, P, P, P, I64, I64, F, I, P],
+            "licv_add_rmsnorm_fwd_q8": [P, I, P, P, P, P, P, I64, I64, F, I, P],
+            "licv_inject_renorm_add_fwd_q8": [P, I, P, P, P, I, P, I64, I64, P, P, P, P, F, I, P],
+            "licv_layernorm_fwd_q8": [P, P, P, P, P, P, I64, I64, F, P],
             "licv_gemm_fp8": [P, I64, P, P, I64, P, P, I64, I64, I64, I64, P, P],
             "licv_gemm_splitk_plan": [I64, I64, I64, P, P],
             "licv_gemm_bf16_splitk": [P, I64, P, I64, P, I64, I64, I64, I64, P, I, P, I64, P],

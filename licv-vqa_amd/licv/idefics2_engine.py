@@ -29,6 +29,7 @@ class _SigLayer:
     ln1_w: torch.Tensor; ln1_b: torch.Tensor; qkv_w: torch.Tensor; qkv_b: torch.Tensor
     out_w: torch.Tensor; out_b: torch.Tensor; ln2_w: torch.Tensor; ln2_b: torch.Tensor
     fc1_w: torch.Tensor; fc1_b: torch.Tensor; fc2_w: torch.Tensor; fc2_b: torch.Tensor
+    q8: Optional[dict] = None           # fp8 copies of the four projection weights when fp8_vision
 
 
 @dataclass
@@ -48,11 +49,13 @@ class Idefics2Weights:
     """Engine-layout weights from an HF-named ``Idefics2ForConditionalGeneration`` state dict (bf16)."""
 
     def __init__(self, sd: Dict[str, torch.Tensor], arch: Idefics2Arch, device="cuda", max_positions: int = 4096,
-                 fp8_text: bool = False):
+                 fp8_text: bool = False, fp8_vision: bool = False):
         """fp8_text (BASELINE configs[4], "fp8 weights"): the text stack's projection weights are ALSO stored as OCP e4m3 with one
-        scale per output channel; GEMMs with >= 512 rows then quantise their input per row and run on the fp8 MFMA."""
+        scale per output channel; GEMMs with >= 512 rows then take their input as e4m3 rows with one scale per row (written by the
+        norm kernel that produces them, or by the row quantiser) and run on the fp8 MFMA.  fp8_vision: the same for the four
+        projections of every SigLIP layer."""
         a, dev = arch, torch.device(device)
-        self.arch, self.device, self.fp8_text = arch, dev, fp8_text
+        self.arch, self.device, self.fp8_text, self.fp8_vision = arch, dev, fp8_text, fp8_vision
         g = lambda k: _bf(sd[k], dev)
         cat = lambda p, names, suf: torch.cat([g(p + f"{n}.{suf}") for n in names]).contiguous()
         vp = "model.vision_model."
@@ -78,6 +81,9 @@ class Idefics2Weights:
                                       g(p + "layer_norm2.weight"), g(p + "layer_norm2.bias"),
                                       pad_rows(g(p + "mlp.fc1.weight")), pad_rows(g(p + "mlp.fc1.bias")),
                                       _pad_cols(g(p + "mlp.fc2.weight"), ipad), g(p + "mlp.fc2.bias")))
+        if fp8_vision:
+            for L in self.vit:
+                L.q8 = {n: ops.quantize_fp8(getattr(L, n)) for n in ("qkv_w", "out_w", "fc1_w", "fc2_w")}
         self.post_ln_w, self.post_ln_b = g(vp + "post_layernorm.weight"), g(vp + "post_layernorm.bias")
         cp = "model.connector."
         mp = cp + "modality_projection."
@@ -274,16 +280,23 @@ class Idefics2Engine:
         del cols, pos_rows
         act = "gelu_tanh" if a.v_act == "gelu_pytorch_tanh" else "gelu"
         mode, kvld = (0, None) if all_valid else (2, valid)
+        fp8v = w.fp8_vision and n * T >= 512            # e4m3 operands: the LayerNorms write the fp8 rows themselves, no bf16 copy
         for L in w.vit:
-            y = ops.layernorm(x, L.ln1_w, L.ln1_b, a.v_ln_eps)
-            qkv = ops.linear(y, L.qkv_w, bias=L.qkv_b)
+            if fp8v:
+                qkv = ops.linear_fp8(*ops.layernorm_q8(x, L.ln1_w, L.ln1_b, a.v_ln_eps), *L.q8["qkv_w"], bias=L.qkv_b)
+            else:
+                qkv = ops.linear(ops.layernorm(x, L.ln1_w, L.ln1_b, a.v_ln_eps), L.qkv_w, bias=L.qkv_b)
             o = ops.attention(qkv, qkv.view(-1)[E:], qkv.view(-1)[2 * E:], n, T, T, nh, nh, hd, T * 3 * E, 3 * E, T * 3 * E, 3 * E,
                               hd ** -0.5, mode, key_valid=kvld)
             del qkv
-            ops.linear(o.view(n * T, E), L.out_w, bias=L.out_b, residual=x, out=x)
-            y = ops.layernorm(x, L.ln2_w, L.ln2_b, a.v_ln_eps)
-            y = ops.linear(y, L.fc1_w, bias=L.fc1_b, act=act)
-            ops.linear(y, L.fc2_w, bias=L.fc2_b, residual=x, out=x)
+            if fp8v:
+                ops.linear_fp8(*ops.quantize_fp8(o.view(n * T, E)), *L.q8["out_w"], bias=L.out_b, residual=x, out=x)
+                y = ops.linear_fp8(*ops.layernorm_q8(x, L.ln2_w, L.ln2_b, a.v_ln_eps), *L.q8["fc1_w"], bias=L.fc1_b, act=act)
+                ops.linear_fp8(*ops.quantize_fp8(y), *L.q8["fc2_w"], bias=L.fc2_b, residual=x, out=x)
+            else:
+                ops.linear(o.view(n * T, E), L.out_w, bias=L.out_b, residual=x, out=x)
+                y = ops.linear(ops.layernorm(x, L.ln2_w, L.ln2_b, a.v_ln_eps), L.fc1_w, bias=L.fc1_b, act=act)
+                ops.linear(y, L.fc2_w, bias=L.fc2_b, residual=x, out=x)
             del y, o
         x = ops.layernorm(x, w.post_ln_w, w.post_ln_b, a.v_ln_eps)
         return self._connector(x, valid, n, T)
@@ -316,11 +329,18 @@ class Idefics2Engine:
     @staticmethod
     def _tlin(x: torch.Tensor, L: _TextLayer, name: str, **kw) -> torch.Tensor:
         """A text-stack projection: fp8 operands when the layer carries fp8 weights and the GEMM is large, else bf16."""
+        if isinstance(x, tuple):                         # rows already in e4m3 (written by the norm kernel that produced them)
+            return ops.linear_fp8(x[0], x[1], *L.q8[name], **kw)
         if L.q8 is not None and name in L.q8 and x.shape[0] >= 512:
             xq, xs = ops.quantize_fp8(x)
             wq, ws = L.q8[name]
             return ops.linear_fp8(xq, xs, wq, ws, **kw)
         return ops.linear(x, getattr(L, name), **kw)
+
+    @staticmethod
+    def _q8_in(L: _TextLayer, name: str, M: int) -> bool:
+        """Does projection `name` of this layer take e4m3 rows (then its producer writes them, see ops.*_q8)?"""
+        return L.q8 is not None and name in L.q8 and M >= 512
 
     def forward(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
                 pixel_values: Optional[torch.Tensor] = None, pixel_attention_mask: Optional[torch.Tensor] = None,
@@ -381,7 +401,12 @@ class Idefics2Engine:
         ldq = qd + 2 * kd
         xn = None
         for l, L in enumerate(w.text):
-            x = xn if xn is not None else ops.rmsnorm(h, L.in_ln, a.rms_eps, 1)
+            if xn is not None:
+                x = xn
+            elif self._q8_in(L, "qkv_w", M) and capture is None:
+                x = ops.rmsnorm_q8(h, L.in_ln, a.rms_eps, 1)
+            else:
+                x = ops.rmsnorm(h, L.in_ln, a.rms_eps, 1)
             xn = None
             qkv = self._tlin(x, L, "qkv_w")
             ops.rotary_(qkv, w.cos, w.sin, pos, M, nh, hd, ldq, qd, 1)
@@ -395,7 +420,10 @@ class Idefics2Engine:
                 o = ops.attention(qkv, cache, cache.view(-1)[kd:], B, S, Sk, nh, nkv, hd, S * ldq, ldq, kv_cache.max_len * 2 * kd, 2 * kd,
                                   hd ** -0.5, 1, key_valid=key_valid)
             if M >= 512 and capture is None and self.fold_residual:   # the residual add folded into the norm that follows (as in IdeficsEngine): bit-identical
-                x = ops.add_rmsnorm_(h, self._tlin(o.view(M, qd), L, "o_w"), L.post_ln, a.rms_eps, 1)
+                if self._q8_in(L, "gu_w", M):
+                    x = ops.add_rmsnorm_q8_(h, self._tlin(o.view(M, qd), L, "o_w"), L.post_ln, a.rms_eps, 1)
+                else:
+                    x = ops.add_rmsnorm_(h, self._tlin(o.view(M, qd), L, "o_w"), L.post_ln, a.rms_eps, 1)
             else:
                 self._tlin(o.view(M, qd), L, "o_w", residual=h, out=h)
                 x = ops.rmsnorm(h, L.post_ln, a.rms_eps, 1)
@@ -408,7 +436,10 @@ class Idefics2Engine:
                     capture.setdefault("mlp_raw", []).append(m.view(B, S, H).clone())
                 al = alpha[0, i:i + 1] if alpha is not None else None
                 nw = w.text[l + 1].in_ln if l + 1 < a.num_layers else w.final_ln
-                if self.fuse_hook_norm:
+                if self.fuse_hook_norm and capture is None and l + 1 < a.num_layers and self._q8_in(w.text[l + 1], "qkv_w", M):
+                    h, xq_, xs_ = ops.inject_renorm_add_q8(m, icv[0, i], h, al, nw, norm_eps=a.rms_eps, norm_flavour=1)
+                    xn = (xq_, xs_)
+                elif self.fuse_hook_norm:
                     h, xn = ops.inject_renorm_add(m, icv[0, i], h, alpha=al, norm_weight=nw, norm_eps=a.rms_eps, norm_flavour=1)
                 else:
                     h = ops.inject_renorm_add(m, icv[0, i], h, alpha=al)

@@ -266,6 +266,55 @@ def quantize_fp8(x: torch.Tensor):
     return q, sc
 
 
+def _q8_bufs(rows: int, dim: int, device):
+    return torch.empty((rows, dim), dtype=torch.uint8, device=device), torch.empty((rows,), dtype=torch.float32, device=device)
+
+
+def rmsnorm_q8(x: torch.Tensor, w: torch.Tensor, eps: float, flavour: int = 0, want_bf16: bool = False):
+    """RMSNorm whose rows leave as fp8: (q uint8 (rows, dim), scale fp32 (rows,)) == quantize_fp8(rmsnorm(x)); the bf16 rows
+    themselves are written only if want_bf16 (third return value)."""
+    dim = x.shape[-1]
+    rows = x.numel() // dim
+    assert x.is_contiguous()
+    q, sc = _q8_bufs(rows, dim, x.device)
+    out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if want_bf16 else None
+    check(_lib.lib().licv_rmsnorm_fwd_q8(_p(x), _dt(x), _p(w), _p(out), _p(q), _p(sc), rows, dim, float(eps), flavour, _stream(x)))
+    return (q, sc, out) if want_bf16 else (q, sc)
+
+
+def add_rmsnorm_q8_(h: torch.Tensor, branch: torch.Tensor, w: torch.Tensor, eps: float, flavour: int = 0):
+    """h += branch (in place), returns the fp8 image (q, scale) of the RMSNorm of the new h (== quantize_fp8(add_rmsnorm_(h, branch, ...)))."""
+    dim = h.shape[-1]
+    rows = h.numel() // dim
+    assert h.is_contiguous() and branch.is_contiguous() and branch.dtype == torch.bfloat16 and branch.numel() == h.numel()
+    q, sc = _q8_bufs(rows, dim, h.device)
+    check(_lib.lib().licv_add_rmsnorm_fwd_q8(_p(h), _dt(h), _p(branch), _p(w), None, _p(q), _p(sc), rows, dim, float(eps), flavour, _stream(h)))
+    return q, sc
+
+
+def inject_renorm_add_q8(branch: torch.Tensor, icv_row: torch.Tensor, residual: torch.Tensor, alpha: Optional[torch.Tensor],
+                         norm_weight: torch.Tensor, norm_eps: float = 1e-6, norm_flavour: int = 1):
+    """inject_renorm_add with the fused RMSNorm's rows leaving as fp8: returns (out fp32, q, scale)."""
+    H = branch.shape[-1]
+    assert branch.is_contiguous() and residual.is_contiguous() and residual.shape == branch.shape
+    rows = branch.numel() // H
+    out = torch.empty(branch.shape, dtype=torch.float32, device=branch.device)
+    q, sc = _q8_bufs(rows, H, branch.device)
+    check(_lib.lib().licv_inject_renorm_add_fwd_q8(_p(branch), _dt(branch), _p(icv_row), _p(alpha), _p(residual), _dt(residual), _p(out), rows, H,
+                                                   _p(norm_weight), None, _p(q), _p(sc), float(norm_eps), norm_flavour, _stream(branch)))
+    return out, q, sc
+
+
+def layernorm_q8(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float):
+    """LayerNorm whose rows leave as fp8 only: (q, scale) == quantize_fp8(layernorm(x))."""
+    dim = x.shape[-1]
+    rows = x.numel() // dim
+    assert x.is_contiguous() and x.dtype == torch.bfloat16
+    q, sc = _q8_bufs(rows, dim, x.device)
+    check(_lib.lib().licv_layernorm_fwd_q8(_p(x), _p(w), _p(b), None, _p(q), _p(sc), rows, dim, float(eps), _stream(x)))
+    return q, sc
+
+
 def linear_fp8(aq: torch.Tensor, a_scale: torch.Tensor, wq: torch.Tensor, w_scale: torch.Tensor, bias: Optional[torch.Tensor] = None,
                act=None, swiglu: bool = False, row_gate: Optional[torch.Tensor] = None, scale: Optional[float] = None,
                residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None):

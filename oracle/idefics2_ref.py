@@ -62,7 +62,33 @@ def navit_position_ids(patch_mask, n_side):
     return fh, fw, boundaries
 
 
-def vision_tower(pixel_values, patch_mask, sd, arch):
+# ----------------------------------------------------------------------------- fp8 projections (the build's configs[4] mode)
+def fp8_linear(x, w, bias=None):
+    """CPU restatement of the build's fp8 text-stack projection (BASELINE configs[4]; the reference has no fp8 mode, so this
+    pins the ARITHMETIC the HIP path claims, csrc/rowwise.hip quantize_rows_fp8_k / emit_row_fp8 + csrc/gemm.hip gemm_fp8_flow64_k,
+    gemm_fp8_pingpong_k):
+    per-row dynamic activation scale amax/448 and per-output-channel weight scale amax/448, both operands rounded to OCP
+    e4m3 (round to nearest even), exact products accumulated in fp32, scales applied to the accumulator, one rounding to the
+    activation dtype."""
+    if torch.is_autocast_enabled("cpu"):                 # autocast hands a linear bf16 operands, and returns bf16
+        x, w = x.to(torch.bfloat16), w.to(torch.bfloat16)
+    dt = x.dtype
+    with torch.autocast("cpu", enabled=False):
+        xf, wf = x.float(), w.float()
+        sx = xf.abs().amax(-1, keepdim=True).clamp_min(1e-12) / 448.0
+        sw = wf.abs().amax(-1, keepdim=True).clamp_min(1e-12) / 448.0
+        xq = (xf / sx).to(torch.float8_e4m3fn).float()
+        wq = (wf / sw).to(torch.float8_e4m3fn).float()
+        y = (xq @ wq.t()) * sx * sw.t()
+        if bias is not None:                             # the build adds the bias to the scaled fp32 accumulator: ONE rounding
+            y = y + bias.float()
+    return y.to(dt)
+
+
+
+def vision_tower(pixel_values, patch_mask, sd, arch, fp8: bool = False):
+    """fp8: the four projections of every layer through ``fp8_linear`` (the build's fp8_vision mode; not a reference feature)."""
+    lin = (lambda x_, sd_, name: fp8_linear(x_, sd_[name + ".weight"], sd_.get(name + ".bias"))) if fp8 else _lin
     p = "model.vision_model."
     n = pixel_values.shape[0]
     x = F.conv2d(pixel_values, sd[p + "embeddings.patch_embedding.weight"], sd[p + "embeddings.patch_embedding.bias"], stride=arch.v_patch)
@@ -84,16 +110,16 @@ def vision_tower(pixel_values, patch_mask, sd, arch):
         res = x
         y = F.layer_norm(x, (arch.v_hidden,), sd[lp + "layer_norm1.weight"], sd[lp + "layer_norm1.bias"], arch.v_ln_eps)
         B, T, _ = y.shape
-        q = _lin(y, sd, lp + "self_attn.q_proj").view(B, T, nh, hd).transpose(1, 2)
-        k = _lin(y, sd, lp + "self_attn.k_proj").view(B, T, nh, hd).transpose(1, 2)
-        v = _lin(y, sd, lp + "self_attn.v_proj").view(B, T, nh, hd).transpose(1, 2)
+        q = lin(y, sd, lp + "self_attn.q_proj").view(B, T, nh, hd).transpose(1, 2)
+        k = lin(y, sd, lp + "self_attn.k_proj").view(B, T, nh, hd).transpose(1, 2)
+        v = lin(y, sd, lp + "self_attn.v_proj").view(B, T, nh, hd).transpose(1, 2)
         m = None if mask is None else mask.to(q.dtype)
         o = eager_attention(q, k, v, m, hd ** -0.5).reshape(B, T, -1).contiguous()
-        x = res + _lin(o, sd, lp + "self_attn.out_proj")
+        x = res + lin(o, sd, lp + "self_attn.out_proj")
         res = x
         y = F.layer_norm(x, (arch.v_hidden,), sd[lp + "layer_norm2.weight"], sd[lp + "layer_norm2.bias"], arch.v_ln_eps)
-        y = F.gelu(_lin(y, sd, lp + "mlp.fc1"), approximate="tanh")
-        x = res + _lin(y, sd, lp + "mlp.fc2")
+        y = F.gelu(lin(y, sd, lp + "mlp.fc1"), approximate="tanh")
+        x = res + lin(y, sd, lp + "mlp.fc2")
     return F.layer_norm(x, (arch.v_hidden,), sd[p + "post_layernorm.weight"], sd[p + "post_layernorm.bias"], arch.v_ln_eps)
 
 
@@ -129,7 +155,7 @@ def connector(x, patch_valid, sd, arch):
     return rms_norm(lat, sd[rp + "norm.weight"], arch.rms_eps)
 
 
-def image_features(pixel_values, pixel_attention_mask, sd, arch):
+def image_features(pixel_values, pixel_attention_mask, sd, arch, fp8_vision: bool = False):
     """hf:idefics2/modeling_idefics2.py:817-862: drop all-zero padding images, patch mask, tower, connector.
     Returns (n_real_images * r_latents, H)."""
     dtype = sd["model.text_model.embed_tokens.weight"].dtype
@@ -139,35 +165,16 @@ def image_features(pixel_values, pixel_attention_mask, sd, arch):
     pv = pv[real].contiguous()
     pam = pixel_attention_mask.view(B * N, *pixel_attention_mask.shape[2:])[real].contiguous()
     pmask = patch_mask_from_pixels(pam, arch.v_patch)
-    x = vision_tower(pv, pmask, sd, arch)
+    x = vision_tower(pv, pmask, sd, arch, fp8=fp8_vision)
     feats = connector(x, pmask.view(pv.shape[0], -1), sd, arch)
     return feats.reshape(-1, feats.shape[-1])
 
 
 # ----------------------------------------------------------------------------- Mistral text model
-def fp8_linear(x, w):
-    """CPU restatement of the build's fp8 text-stack projection (BASELINE configs[4]; the reference has no fp8 mode, so this
-    pins the ARITHMETIC the HIP path claims, csrc/rowwise.hip quantize_rows_fp8_k + csrc/gemm.hip gemm_fp8_pingpong_k):
-    per-row dynamic activation scale amax/448 and per-output-channel weight scale amax/448, both operands rounded to OCP
-    e4m3 (round to nearest even), exact products accumulated in fp32, scales applied to the accumulator, one rounding to the
-    activation dtype."""
-    if torch.is_autocast_enabled("cpu"):                 # autocast hands a linear bf16 operands, and returns bf16
-        x, w = x.to(torch.bfloat16), w.to(torch.bfloat16)
-    dt = x.dtype
-    with torch.autocast("cpu", enabled=False):
-        xf, wf = x.float(), w.float()
-        sx = xf.abs().amax(-1, keepdim=True).clamp_min(1e-12) / 448.0
-        sw = wf.abs().amax(-1, keepdim=True).clamp_min(1e-12) / 448.0
-        xq = (xf / sx).to(torch.float8_e4m3fn).float()
-        wq = (wf / sw).to(torch.float8_e4m3fn).float()
-        y = (xq @ wq.t()) * sx * sw.t()
-    return y.to(dt)
-
-
 def forward(sd: Dict[str, torch.Tensor], arch, input_ids, attention_mask, pixel_values=None, pixel_attention_mask=None,
             icv: Optional[torch.Tensor] = None, hook_layers: Optional[Sequence[int]] = None, capture: Optional[dict] = None,
             image_hidden_states: Optional[torch.Tensor] = None, position_ids: Optional[torch.Tensor] = None,
-            fp8_text: bool = False, scatter_len: Optional[int] = None):
+            fp8_text: bool = False, scatter_len: Optional[int] = None, fp8_vision: bool = False):
     """logits (B, S, V).  icv (1, n_hooked, H) fp32, already alpha-scaled; the hook edits the MLP output of text layer l.
     fp8_text: the four projections of every text layer run through ``fp8_linear`` (the build's configs[4] mode).
     scatter_len: only `<image>` tokens at positions < scatter_len receive image features (a cache-less decode re-runs the whole
@@ -176,7 +183,7 @@ def forward(sd: Dict[str, torch.Tensor], arch, input_ids, attention_mask, pixel_
     B, S = input_ids.shape
     h = F.embedding(input_ids, sd[tp + "embed_tokens.weight"])
     if image_hidden_states is None and pixel_values is not None:
-        image_hidden_states = image_features(pixel_values, pixel_attention_mask, sd, arch)
+        image_hidden_states = image_features(pixel_values, pixel_attention_mask, sd, arch, fp8_vision=fp8_vision)
     if image_hidden_states is not None:
         special = input_ids == arch.image_token_id
         if scatter_len is not None:

@@ -90,3 +90,45 @@ def test_gemm_fp8_matches_dequantised_product(M, N, K, epi):
         _lib.lib().licv_gemm_experiment(8, 1)
     assert (other - y).abs().max() <= tol
     assert (other - out).abs().max() <= tol
+
+
+@pytest.mark.parametrize("dim", [256, 1152, 4096])
+def test_norm_kernels_write_the_fp8_rows_of_their_output(dim):
+    """The producers of fp8 GEMM inputs (RMSNorm, residual add + RMSNorm, hook + RMSNorm, LayerNorm) write the e4m3 rows and their
+    scales themselves: byte for byte what the row quantiser makes of the bf16 rows the plain kernels write (and the stream / hook
+    outputs are untouched by the extra output)."""
+    from licv import ops
+    rows = 77
+    g = torch.Generator().manual_seed(dim)
+    w = (1 + 0.1 * torch.randn(dim, generator=g)).to(torch.bfloat16).to(DEV)
+    b = (0.1 * torch.randn(dim, generator=g)).to(torch.bfloat16).to(DEV)
+    for dt in (torch.bfloat16, torch.float32):
+        for flavour in (0, 1):
+            x = (torch.randn(rows, dim, generator=g) * 3).to(dt).to(DEV)
+            x[3] = 0
+            q, sc, out = ops.rmsnorm_q8(x, w, 1e-6, flavour, want_bf16=True)
+            ref = ops.rmsnorm(x, w, 1e-6, flavour)
+            rq, rs = ops.quantize_fp8(ref)
+            assert torch.equal(out, ref) and torch.equal(q, rq) and torch.equal(sc, rs)
+            q2, sc2 = ops.rmsnorm_q8(x, w, 1e-6, flavour)
+            assert torch.equal(q2, rq) and torch.equal(sc2, rs)
+            h1, h2 = x.clone(), x.clone()
+            br = (torch.randn(rows, dim, generator=g)).to(torch.bfloat16).to(DEV)
+            ref = ops.add_rmsnorm_(h1, br, w, 1e-6, flavour)
+            q, sc = ops.add_rmsnorm_q8_(h2, br, w, 1e-6, flavour)
+            rq, rs = ops.quantize_fp8(ref)
+            assert torch.equal(h1, h2) and torch.equal(q, rq) and torch.equal(sc, rs)
+        res = (torch.randn(rows, dim, generator=g)).to(dt).to(DEV)
+        br = (torch.randn(rows, dim, generator=g)).to(torch.bfloat16).to(DEV)
+        icv = (torch.randn(dim, generator=g) * 0.1).to(DEV)
+        al = torch.tensor([0.7], device=DEV)
+        o1, xn = ops.inject_renorm_add(br, icv, res, alpha=al, norm_weight=w, norm_eps=1e-6, norm_flavour=1)
+        o2, q, sc = ops.inject_renorm_add_q8(br, icv, res, al, w, norm_eps=1e-6, norm_flavour=1)
+        rq, rs = ops.quantize_fp8(xn)
+        assert torch.equal(o1, o2) and torch.equal(q, rq) and torch.equal(sc, rs)
+    if dim % 8 == 0:
+        x = (torch.randn(rows, dim, generator=g) * 2 + 0.5).to(torch.bfloat16).to(DEV)
+        ref = ops.layernorm(x, w, b, 1e-6)
+        q, sc = ops.layernorm_q8(x, w, b, 1e-6)
+        rq, rs = ops.quantize_fp8(ref)
+        assert torch.equal(q, rq) and torch.equal(sc, rs)

@@ -102,13 +102,15 @@ def test_w1_idefics9b_widths_truncated_depth_vs_oracle():
     assert torch.equal(lg.float().cpu().argmax(-1)[sure], g16.argmax(-1)[sure])
 
 
-@pytest.mark.parametrize("fp8", [False, True], ids=["bf16", "fp8_text"])
+@pytest.mark.parametrize("fp8", [False, True, "all"], ids=["bf16", "fp8_text", "fp8_text_and_vision"])
 def test_w2_idefics2_8b_widths_truncated_depth_vs_oracle(fp8):
     from licv.idefics2_engine import Idefics2Engine, Idefics2Weights
     torch.set_num_threads(max(torch.get_num_threads(), 8))
     arch = IDEFICS2_8B.with_(v_layers=2, r_depth=2, num_layers=2)
     sd = trained_like_(synth_idefics2_weights(arch, seed=911, dtype=torch.float32, device=DEV), 2)
-    eng = Idefics2Engine(Idefics2Weights(sd, arch, DEV, fp8_text=fp8))
+    fp8_vis = fp8 == "all"
+    fp8 = bool(fp8)
+    eng = Idefics2Engine(Idefics2Weights(sd, arch, DEV, fp8_text=fp8, fp8_vision=fp8_vis))
     batch = synth_vqa_batch_idefics2(arch, 1, 512, 2, 378, 504, seed=912, min_len=500, dtype=torch.float32, ragged=True)
     layers = [0, 1]
     icv = torch.randn(1, 2, arch.hidden_size, generator=torch.Generator().manual_seed(913)) * 0.05
@@ -127,7 +129,8 @@ def test_w2_idefics2_8b_widths_truncated_depth_vs_oracle(fp8):
                           img=c["image_hidden_states"].float())
         del s
     rep = []
-    _check(cap["image_hidden_states"], gold["bf16"]["img"], gold["f32"]["img"], "connector output (2 x 64 x 4096)", rep)
+    if not fp8_vis:
+        _check(cap["image_hidden_states"], gold["bf16"]["img"], gold["f32"]["img"], "connector output (2 x 64 x 4096)", rep)
     if not fp8:
         _check(torch.stack([t.float() for t in cap["mlp_raw"]]), gold["bf16"]["raw"], gold["f32"]["raw"], "MLP branch (pre-hook)", rep)
         _check(torch.stack([t.float() for t in cap["layer_out"]]), gold["bf16"]["out"], gold["f32"]["out"], "layer outputs", rep)
@@ -161,11 +164,50 @@ def test_w2_idefics2_8b_widths_truncated_depth_vs_oracle(fp8):
             rep.append(f"fp8 {name} projection ({x.shape[0]} x {ref.shape[1]} x {K}): {100 * same:.2f} % bit-identical, worst {worst:.2f} of one bf16 ulp")
             # the only freedom is the order of the fp32 accumulation over K (the SwiGLU form rounds twice: silu, product)
             assert same >= 0.97 and worst <= (2.0 if name.startswith("gate") else 1.0), rep[-1]
+        if fp8_vis:
+            # the SigLIP projections (bias in the fp32 epilogue, GELU, residual in place), same bar, on identical inputs
+            vp = "model.vision_model.encoder.layers.0."
+            V0 = eng.w.vit[0]
+            assert all(set(L.q8) == {"qkv_w", "out_w", "fc1_w", "fc2_w"} for L in eng.w.vit)
+            E, I = arch.v_hidden, arch.v_inter
+            ipad = V0.fc1_w.shape[0]
+            for name, keys, K in (("SigLIP qkv + bias", ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj"), E),
+                                  ("SigLIP out + bias + residual", ("self_attn.out_proj",), E),
+                                  ("SigLIP fc1 + bias + GELU(tanh)", ("mlp.fc1",), E), ("SigLIP fc2 + bias + residual", ("mlp.fc2",), I)):
+                x = torch.randn(1944, K, generator=g).to(torch.bfloat16)
+                res = torch.randn(1944, E, generator=g).to(torch.bfloat16) if "residual" in name else None
+                xd = x.to(DEV)
+                if name.startswith("SigLIP fc2"):                   # the engine's fc1 output is padded to a multiple of 64 columns (zeros)
+                    xd = torch.nn.functional.pad(xd, (0, ipad - I))
+                wname = {"SigLIP qkv": "qkv_w", "SigLIP out": "out_w", "SigLIP fc1": "fc1_w", "SigLIP fc2": "fc2_w"}[name[:10]]
+                bias = getattr(V0, wname.replace("_w", "_b"))
+                kwl = dict(bias=bias)
+                if "GELU" in name: kwl["act"] = "gelu_tanh"
+                if res is not None: kwl["residual"] = res.to(DEV)
+                got = ops.linear_fp8(*ops.quantize_fp8(xd.contiguous()), *V0.q8[wname], **kwl).float().cpu()
+                with torch.no_grad():
+                    outs = [R2.fp8_linear(x, s[vp + k + ".weight"], s[vp + k + ".bias"]) for k in keys]
+                    ref = torch.cat(outs, dim=-1)
+                    if "GELU" in name: ref = torch.nn.functional.gelu(ref.float(), approximate="tanh").to(torch.bfloat16)
+                    if res is not None: ref = res + ref
+                    ref = ref.float()
+                got = got[:, : ref.shape[1]]
+                same = float((got == ref).float().mean())
+                tol = (ref.abs() * 2.0 ** -7 + ref.abs().max() * 2.0 ** -9) * 1.001
+                worst = float(((got - ref).abs() / tol).max())
+                rep.append(f"fp8 {name} ({x.shape[0]} x {ref.shape[1]} x {K}): {100 * same:.2f} % bit-identical, worst {worst:.2f} of one bf16 ulp")
+                assert same >= 0.95 and worst <= 2.0, rep[-1]
         # (b) whole truncated model: deviation from the fp8 oracle and from the plain bf16 oracle (= the quantisation noise itself)
         kw = dict(batch)
         kw["pixel_values"] = batch["pixel_values"].to(torch.bfloat16)
         with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
-            g8 = R2.forward(s, arch, **kw, icv=icv, hook_layers=layers, fp8_text=True).float()
+            c8 = {}
+            g8 = R2.forward(s, arch, **kw, icv=icv, hook_layers=layers, fp8_text=True, fp8_vision=fp8_vis, capture=c8).float()
+        if fp8_vis:
+            a_img, b_img = c8["image_hidden_states"].float(), cap["image_hidden_states"].float().cpu().view_as(c8["image_hidden_states"])
+            rel = float((a_img - b_img).norm() / a_img.norm())
+            rep.append(f"fp8 SigLIP tower -> connector output vs fp8 oracle: relative L2 {rel:.3f}")
+            assert rel <= 0.1, rep[-1]
         valid = batch["attention_mask"].bool()
         b = lg.float().cpu()
         for what, a in (("fp8 oracle", g8), ("plain bf16 oracle (quantisation noise)", gold["bf16"]["logits"])):
