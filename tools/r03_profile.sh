@@ -7,6 +7,12 @@ COMMIT=${1:-unknown}
 QUICK=${2:-}
 OUT=gpurun_out/r03
 mkdir -p $OUT
+if [ "$QUICK" = "partB" ]; then
+for W in idefics9b_train_bs8 idefics9b_generate_bs8 idefics9b_student_bs8 idefics2_8b_1shot_bs8 idefics2_8b_32shot_bs8 idefics2_8b_32shot_fp8_bs8 frontend_images_bs8; do
+  timeout -k 10 400 python3 bench.py --workload $W --steps 8 --warmup 3 > $OUT/bench_$W.json.log 2>$OUT/bench_$W.err
+  echo "$W rc=$?"
+done
+ls $OUT; exit 0; fi
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-gpu-baseline --batch-streams 1 > $OUT/kt.log 2>&1 || exit 1
 python3 tools/summarize_rocprof.py $OUT/kt $OUT/bench_headline_serial_kernel_stats.md "bench.py --steps 5 --warmup 2 --batch-streams 1 (7 forwards, one stream: the configuration roofline.achieved is measured in) on 1xMI355X, headline workload, build at $COMMIT" > /dev/null
 echo "serial kernel trace done"
@@ -25,7 +31,8 @@ python3 - <<PY
 import json
 p="$OUT/pmc_headline_gemm.json"; d=json.load(open(p)); d["commit"]="$COMMIT"; json.dump(d, open(p,"w"), indent=1)
 PY
-for W in idefics9b_train_bs8 idefics9b_generate_bs8 idefics9b_student_bs8 idefics2_8b_1shot_bs8 idefics2_8b_32shot_bs8 idefics2_8b_32shot_fp8_bs8; do
+if [ "$QUICK" = "partA" ]; then rm -rf $OUT/kt $OUT/kt2 $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE; ls $OUT; exit 0; fi
+for W in idefics9b_train_bs8 idefics9b_generate_bs8 idefics9b_student_bs8 idefics2_8b_1shot_bs8 idefics2_8b_32shot_bs8 idefics2_8b_32shot_fp8_bs8 frontend_images_bs8; do
   timeout -k 10 400 python3 bench.py --workload $W --steps 8 --warmup 3 > $OUT/bench_$W.json.log 2>$OUT/bench_$W.err
   echo "$W rc=$?"
 done
