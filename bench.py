@@ -584,7 +584,7 @@ def main():
         "config": {"workload": args.workload, "arch": preset, "questions_per_gpu": B, "seq_len": S, "images_per_question": n_img,
                    "hooked_layers": 0 if args.no_hooks else arch.num_layers, "parallelism": f"dp{world}",
                    **({"train": "teacher fwd + student fwd/bwd + KL; accumulate 2; 1 all-reduce of 131 105 fp32 + AdamW per optimiser step"} if training else {})},
-        "roofline": {"bound": "mfma", "kernel": "gemm_bf16_flow_k / gemm_bf16_lean_k (256x256 tile, LDS-DMA ring, two wave groups half a K stage apart; small shapes: gemm_bf16_tile128_k)", "achieved": fl / tg / 1e12 if tg else None,
+        "roofline": {"bound": "mfma", "kernel": ("gemm_fp8_flow64_k / gemm_bf16_flow64_k" if "fp8" in args.workload else "gemm_bf16_flow64_k") + " (256x256 tile per CU, four waves of 128x128, 256 AGPR accumulators, LDS-DMA ring of ten 16 KiB units, persistent K-tile stream, register-direct epilogues; N % 128 != 0: gemm_bf16_quad64_k / gemm_bf16_flow_k; M < 512: gemm_bf16_mid_k)", "achieved": fl / tg / 1e12 if tg else None,
                      "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": (fl / tg / 1e12) / PEAK_BF16_TFLOPS if tg else None,
                      "traffic": pmc["traffic_bytes_per_launch"] / 1e9 if pmc else None, "traffic_unit": "GB per launch (average over the step's GEMM launches)",
                      "traffic_source": (f"profiles/{pmc_file.name} (measured at commit {pmc.get('commit', 'of round 1')}, GEMM sources {pmc.get('gemm_src_sha16')}, kernels {pmc.get('kernel')}): "
@@ -608,8 +608,8 @@ def main():
         wb = weight_bytes(arch)
         passes = 5 if generating else 1                                  # prefill + 4 single-token steps for 5 new tokens
         alg = wb["vision"] + wb["perceiver"] + passes * wb["language"] - (passes - 1) * cross_kv_weight_bytes(arch)
-        res["roofline"] = {"bound": "hbm", "kernel": "weight-streaming GEMM family over the whole step (gemm_bf16_skinny_k / gemm_bf16_stream_k / "
-                           "gemm_bf16_splitk_k + finalize; native layer runner)", "achieved": alg / (ms_per_step * 1e-3) / 1e9,
+        res["roofline"] = {"bound": "hbm", "kernel": "weight-streaming GEMM family over the whole step (gemm_bf16_skinny_k for M <= 32, gemm_bf16_mid_k for M <= 256, "
+                           "split-K + skinny_finalize_k; native layer runner)", "achieved": alg / (ms_per_step * 1e-3) / 1e9,
                            "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": alg / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None,
                            "algorithmic_GB_per_step": alg / 1e9, "weight_GB": {k: v / 1e9 for k, v in wb.items()}, "weight_passes": passes,
                            "floor_ms_at_peak": alg / PEAK_HBM_GBS / 1e6,
