@@ -211,7 +211,8 @@ typedef struct {
 
 int licv_attn_fwd(const licv_attn_args* a, void* stream);
 /* tests / A-B timing: bit 0 = always the tiled kernel (never the resident-K/V variant used for short unmasked keys);
- * bit 1 = the resident variant walks its items in blockIdx order instead of grouping consecutive heads on one XCD */
+ * bit 1 = the resident variant walks its items in blockIdx order instead of grouping consecutive heads on one XCD;
+ * bit 2 = the resident variant leaves its LDS read schedule to the compiler; bit 3 = so does the tiled kernel at head dim 128 */
 int licv_attn_select(int mode);
 
 /* ---- small data-movement kernels ---- */

@@ -152,9 +152,9 @@ __device__ __forceinline__ float max_over_groups(float x) {
 
 // One tile of the pipelined walk: NST live 16-key sub-tiles (4 = a full tile), MASKED = keys past Sk are cut (ragged tile),
 // NEXTK = read the K fragments of the tile at `kn` for the next call while this tile's softmax / PV run.
-template <int DPK, int DPV, int NST, bool MASKED, bool NEXTK>
+template <int DPK, int DPV, int NST, bool MASKED, bool NEXTK, typename MaskF>
 __device__ __forceinline__ void attn_tile_pipe(bf16x8 (&kf)[4][DPK / 32], const char* vt, const char* kn, const bf16x8 (&qf)[DPK / 32],
-                                               floatx4 (&oacc)[DPV / 16], float& m_run, float& l_run, float sc, int g, int keys_left) {
+                                               floatx4 (&oacc)[DPV / 16], float& m_run, float& l_run, float sc, MaskF&& allowed) {
     constexpr int VSTR = lds_stride(DPV), KSTR = lds_stride(DPK);
     constexpr int KS = DPK / 32, DT = DPV / 16, NS2 = (NST + 1) / 2;
     // V^T fragments of this tile: in flight across QK and the softmax
@@ -188,7 +188,7 @@ __device__ __forceinline__ void attn_tile_pipe(bf16x8 (&kf)[4][DPK / 32], const 
         for (int st = 0; st < NST; ++st)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (st * 16 + g * 4 + r >= keys_left) s[st][r] = -INFINITY;
+                if (!allowed(st, r)) s[st][r] = -INFINITY;
     }
     // online softmax, log2 domain
     float tmax = max3_f32(max3_f32(s[0][0], s[0][1], s[0][2]), max3_f32(s[0][3], s[1][0], s[1][1]), max3_f32(s[1][2], s[1][3], s[2][0]));
@@ -247,14 +247,16 @@ __device__ __forceinline__ void attn_unit_pipe(const char* sK, const char* sV, i
     for (int st = 0; st < 4; ++st)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) kf[st][ks] = *reinterpret_cast<const bf16x8*>(kp + st * 16 * KSTR + ks * 64);
+    auto all = [](int, int) -> bool { return true; };
     for (int t = 0; t < nfull; ++t)
-        attn_tile_pipe<DPK, DPV, 4, false, true>(kf, vp + t * ATT_KB * VSTR, kp + (t + 1) * ATT_KB * KSTR, qf, oacc, m_run, l_run, sc, g, 64);
+        attn_tile_pipe<DPK, DPV, 4, false, true>(kf, vp + t * ATT_KB * VSTR, kp + (t + 1) * ATT_KB * KSTR, qf, oacc, m_run, l_run, sc, all);
     const char* vt = vp + nfull * ATT_KB * VSTR;
     const int left = Sk - nfull * ATT_KB;
-    if (nst_last == 1)      attn_tile_pipe<DPK, DPV, 1, true, false>(kf, vt, nullptr, qf, oacc, m_run, l_run, sc, g, left);
-    else if (nst_last == 2) attn_tile_pipe<DPK, DPV, 2, true, false>(kf, vt, nullptr, qf, oacc, m_run, l_run, sc, g, left);
-    else if (nst_last == 3) attn_tile_pipe<DPK, DPV, 3, true, false>(kf, vt, nullptr, qf, oacc, m_run, l_run, sc, g, left);
-    else if (nst_last == 4) attn_tile_pipe<DPK, DPV, 4, true, false>(kf, vt, nullptr, qf, oacc, m_run, l_run, sc, g, left);
+    auto in_range = [&](int st, int r) -> bool { return st * 16 + g * 4 + r < left; };
+    if (nst_last == 1)      attn_tile_pipe<DPK, DPV, 1, true, false>(kf, vt, nullptr, qf, oacc, m_run, l_run, sc, in_range);
+    else if (nst_last == 2) attn_tile_pipe<DPK, DPV, 2, true, false>(kf, vt, nullptr, qf, oacc, m_run, l_run, sc, in_range);
+    else if (nst_last == 3) attn_tile_pipe<DPK, DPV, 3, true, false>(kf, vt, nullptr, qf, oacc, m_run, l_run, sc, in_range);
+    else if (nst_last == 4) attn_tile_pipe<DPK, DPV, 4, true, false>(kf, vt, nullptr, qf, oacc, m_run, l_run, sc, in_range);
 }
 
 template <int DPK, int DPV, typename MaskF>
@@ -269,9 +271,9 @@ __device__ __forceinline__ void attn_tile_n(int nst, const char* kt, const char*
 
 // MODE = mask mode as a compile-time constant: the image-mask bookkeeping (run-time divisions, per-image bit sets) and the
 // causal bounds otherwise sit in every instantiation's tile loop (1600 scalar instructions, SGPR spills to VGPR lanes).
-template <int DPK, int DPV, int QT, int NW, int MODE>   // NW waves per workgroup, QT 16-query sub-tiles per wave: QT*NW*16 queries
+template <int DPK, int DPV, int QT, int NW, int MODE, bool PIPE = false>   // NW waves per workgroup, QT 16-query sub-tiles per wave: QT*NW*16 queries
 __global__ __launch_bounds__(NW * 64, 2)      // 2 waves per SIMD guaranteed (3 at head_dim 128 spills once MODE is a constant: 183 -> 251 us)
-void attn_fwd_k(AttnP a) {
+void attn_fwd_k(AttnP a) {                    // PIPE: full tiles through attn_tile_pipe (every fragment of a phase in registers before the phase)
     constexpr int NTHR = NW * 64;
     constexpr int SLAB = NW * 16;               // queries per slab (one sub-tile of every wave)
     constexpr int KSTR = lds_stride(DPK), VSTR = lds_stride(DPV);   // conflict-free row strides
@@ -354,8 +356,15 @@ void attn_fwd_k(AttnP a) {
     auto tile_live = [&](int t) -> bool { return !img_skip || ((used >> ((t * ATT_KB) / a.img_len)) & 1ull); };
     auto next_tile = [&](int t) -> int { while (t < ntiles && !tile_live(t)) ++t; return t; };
 
-    const bf16_t* kbase = a.k + (int64_t)b * a.kv_bs + (int64_t)kvh * a.hd;
-    const bf16_t* vbase = a.v + (int64_t)b * a.kv_bs + (int64_t)kvh * a.hd;
+    // The next tile's K / V (and key-valid flags) are BUFFER loads outside any branch; a chunk that does not exist (key >= Sk,
+    // column >= hd, thread past the tile) gets an out-of-range offset and comes back as zeros.  With the loads inside `if`s the
+    // compiler's waitcnt pass waited for them (vmcnt(0)) at the first LDS-dependent instruction of the tile being multiplied:
+    // the prefetch was synchronous.  (When fits32 is false - a (batch, head) slice beyond 2 GB - the host does not launch this kernel.)
+    const auto rsk = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.k + (int64_t)b * a.kv_bs + (int64_t)kvh * a.hd), 0, 0xFFFFFFFF, 0x00020000);
+    const auto rsv = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.v + (int64_t)b * a.kv_bs + (int64_t)kvh * a.hd), 0, 0xFFFFFFFF, 0x00020000);
+    const bool use_kv = a.key_valid && (MODE == 1 || MODE == 2);
+    const auto rsf = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(use_kv ? a.key_valid + (int64_t)b * a.Sk : (const int32_t*)a.k), 0, 0xFFFFFFFF, 0x00020000);
+    constexpr uint32_t OOB = 0xFFFFFFFFu;
     u32x4 rk[KLD], rv[VLD];
     int rvalid = 1;
     auto load_tile = [&](int t) {
@@ -364,25 +373,21 @@ void attn_fwd_k(AttnP a) {
         for (int i = 0; i < KLD; ++i) {
             const int c = tid + i * NTHR;
             const int row = c / KCH, ch = c % KCH;
-            u32x4 r = u32x4{0u, 0u, 0u, 0u};
-            if (c < ATT_KB * KCH && key0 + row < a.Sk && ch * 8 < a.hd)
-                r = *reinterpret_cast<const u32x4*>(kbase + (int64_t)(key0 + row) * a.kv_rs + ch * 8);
-            rk[i] = r;
+            const bool ok = (int)(c < ATT_KB * KCH) & (int)(key0 + row < a.Sk) & (int)(ch * 8 < a.hd);
+            rk[i] = __builtin_amdgcn_raw_buffer_load_b128(rsk, ok ? (uint32_t)((key0 + row) * (int)a.kv_rs + ch * 8) * 2u : OOB, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < VLD; ++i) {
             const int c = tid + i * NTHR;
             const int row = c / VCH, ch = c % VCH;
-            u32x4 r = u32x4{0u, 0u, 0u, 0u};
-            if (c < ATT_KB * VCH && key0 + row < a.Sk && ch * 8 < a.hd)
-                r = *reinterpret_cast<const u32x4*>(vbase + (int64_t)(key0 + row) * a.kv_rs + ch * 8);
-            rv[i] = r;
+            const bool ok = (int)(c < ATT_KB * VCH) & (int)(key0 + row < a.Sk) & (int)(ch * 8 < a.hd);
+            rv[i] = __builtin_amdgcn_raw_buffer_load_b128(rsv, ok ? (uint32_t)((key0 + row) * (int)a.kv_rs + ch * 8) * 2u : OOB, 0, 0);
         }
-        if (tid < ATT_KB) {
+        {
             const int key = key0 + tid;
-            int ok = key < a.Sk;
-            if (ok && a.key_valid && (MODE == 1 || MODE == 2)) ok = a.key_valid[(int64_t)b * a.Sk + key] != 0;
-            rvalid = ok;
+            const bool in = (int)(tid < ATT_KB) & (int)(key < a.Sk);
+            const int f = __builtin_amdgcn_raw_buffer_load_b32(rsf, (in && use_kv) ? (uint32_t)key * 4u : OOB, 0, 0);
+            rvalid = in ? (use_kv ? (f != 0) : 1) : 0;
         }
     };
     auto store_tile = [&]() {
@@ -452,7 +457,19 @@ void attn_fwd_k(AttnP a) {
                 }
                 return ok;
             };
-            attn_tile_n<DPK, DPV>(nst, sK, sV, qf[qs], oacc[qs], m_run[qs], l_run[qs], sc, g, ql, need_mask, allowed);
+            if (PIPE && nst >= 4) {
+                bf16x8 kf[4][DPK / 32];
+                const char* kp = sK + ql * KSTR + g * 16;
+#pragma unroll
+                for (int st = 0; st < 4; ++st)
+#pragma unroll
+                    for (int ks = 0; ks < DPK / 32; ++ks) kf[st][ks] = *reinterpret_cast<const bf16x8*>(kp + st * 16 * KSTR + ks * 64);
+                const char* vp = sV + (g * 4 + (ql >> 2)) * VSTR + (ql & 3) * 8;
+                if (need_mask) attn_tile_pipe<DPK, DPV, 4, true, false>(kf, vp, nullptr, qf[qs], oacc[qs], m_run[qs], l_run[qs], sc, allowed);
+                else           attn_tile_pipe<DPK, DPV, 4, false, false>(kf, vp, nullptr, qf[qs], oacc[qs], m_run[qs], l_run[qs], sc, allowed);
+            } else {
+                attn_tile_n<DPK, DPV>(nst, sK, sV, qf[qs], oacc[qs], m_run[qs], l_run[qs], sc, g, ql, need_mask, allowed);
+            }
         }
         __syncthreads();                                   // everyone done reading this tile
         if (tn < ntiles) store_tile();
@@ -675,8 +692,9 @@ extern "C" int licv_attn_debug_timestamps(void* dev_buffer) {
 
 static int g_attn_force_tiled = 0;      // tests / A-B timing: bit 0 = never use the resident-K/V variant
 static int g_attn_plain_items = 0;      //                     bit 1 = resident variant takes items in blockIdx order (no XCD grouping)
+static int g_attn_tiled_no_pipe = 0;    //                     bit 3 = the TILED kernel at head dim 128 leaves the LDS read schedule of its full tiles to the compiler
 static int g_attn_no_pipe = 0;          //                     bit 2 = resident variant leaves the LDS read schedule to the compiler (attn_tile)
-extern "C" int licv_attn_select(int mode) { g_attn_force_tiled = mode & 1; g_attn_plain_items = (mode >> 1) & 1; g_attn_no_pipe = (mode >> 2) & 1; return LICV_OK; }
+extern "C" int licv_attn_select(int mode) { g_attn_force_tiled = mode & 1; g_attn_plain_items = (mode >> 1) & 1; g_attn_no_pipe = (mode >> 2) & 1; g_attn_tiled_no_pipe = (mode >> 3) & 1; return LICV_OK; }
 
 extern "C" int licv_attn_fwd(const licv_attn_args* x, void* stream) {
     LICV_CHECK_ARG(x && x->q && x->k && x->v && x->o, "attn_fwd: null pointer");
@@ -744,16 +762,20 @@ extern "C" int licv_attn_fwd(const licv_attn_args* x, void* stream) {
     //        MFMA + 32 LDS reads + 20 s_waitcnt per 64 keys and runs at ~47 % issue utilisation with 2 waves per SIMD, but the tile
     //        function needs ~190 registers beside the K/V prefetch: 88 / 158 spills, 362 -> 440 / 575 us.  More waves in flight
     //        need a tile function rebuilt for <= 120 registers (K / V^T fragments in halves), not a launch parameter.
+    LICV_CHECK_ARG(x->Sk * x->kv_rs * 2 < (1ll << 32) && x->Sk * 4 < (1ll << 32), "attn_fwd: one (batch, head) slice of K / V spans more than 4 GB");
     const int hd = p.hd;
     const int64_t qtiles = (x->Sq + ATT_QB - 1) / ATT_QB;
     const int64_t nblk = x->B * x->n_heads * qtiles;
     LICV_CHECK_ARG(nblk < (1ll << 31), "attn_fwd: grid too large");
     const dim3 grid((unsigned)nblk), block(256);
     hipStream_t st = (hipStream_t)stream;
+    // Full tiles through attn_tile_pipe (all K fragments, then all V^T fragments, in registers before the MFMAs that use them) where
+    // it does not cost a wave per SIMD: head dim 128 runs at 2 waves per SIMD either way (177 -> 254 VGPRs): language self-attention
+    // 138.5 -> 124.9 us (800 tokens), Mistral 2900 tokens 669 -> 546 us; at 96 / 80 it would go from 3 waves to 2: SigLIP 1659 -> 1939 us.
 #define ATT_LAUNCH(DK, DV) do { switch (p.mask_mode) { \
-        case 0:  attn_fwd_k<DK, DV, 1, 4, 0><<<grid, block, 0, st>>>(p); break; \
-        case 1:  attn_fwd_k<DK, DV, 1, 4, 1><<<grid, block, 0, st>>>(p); break; \
-        case 2:  attn_fwd_k<DK, DV, 1, 4, 2><<<grid, block, 0, st>>>(p); break; \
+        case 0:  if (DK == 128 && !g_attn_tiled_no_pipe) attn_fwd_k<DK, DV, 1, 4, 0, DK == 128><<<grid, block, 0, st>>>(p); else attn_fwd_k<DK, DV, 1, 4, 0><<<grid, block, 0, st>>>(p); break; \
+        case 1:  if (DK == 128 && !g_attn_tiled_no_pipe) attn_fwd_k<DK, DV, 1, 4, 1, DK == 128><<<grid, block, 0, st>>>(p); else attn_fwd_k<DK, DV, 1, 4, 1><<<grid, block, 0, st>>>(p); break; \
+        case 2:  if (DK == 128 && !g_attn_tiled_no_pipe) attn_fwd_k<DK, DV, 1, 4, 2, DK == 128><<<grid, block, 0, st>>>(p); else attn_fwd_k<DK, DV, 1, 4, 2><<<grid, block, 0, st>>>(p); break; \
         default: attn_fwd_k<DK, DV, 1, 4, 3><<<grid, block, 0, st>>>(p); break; } } while (0)
     if (hd <= 16)        ATT_LAUNCH(32, 16);
     else if (hd <= 32)   ATT_LAUNCH(32, 32);

@@ -402,9 +402,17 @@ def test_attention_self(hd, mode):
         mask = valid.bool()[:, None, None, :].expand(B, 1, S, S)
     ref = _ref_attn(q, k, v, mask, hd ** -0.5).transpose(1, 2).reshape(B, S, H)
     d = qkv.to(DEV)
-    out = ops().attention(d, d.view(-1)[H:], d.view(-1)[2 * H:], B, S, S, nh, nh, hd, S * 3 * H, 3 * H, S * 3 * H, 3 * H,
-                          hd ** -0.5, {"none": 0, "causal": 1, "keypad": 2}[mode], key_valid=valid.to(DEV))
+    run = lambda: ops().attention(d, d.view(-1)[H:], d.view(-1)[2 * H:], B, S, S, nh, nh, hd, S * 3 * H, 3 * H, S * 3 * H, 3 * H,
+                                  hd ** -0.5, {"none": 0, "causal": 1, "keypad": 2}[mode], key_valid=valid.to(DEV))
+    out = run()
     _attn_close(out, ref)
+    if hd == 128:          # head dim 128 takes the hand-pipelined tile function for its full tiles: same arithmetic, same bits as the plain one
+        from licv import _lib
+        try:
+            _lib.lib().licv_attn_select(8)
+            assert torch.equal(run(), out)
+        finally:
+            _lib.lib().licv_attn_select(0)
 
 
 @pytest.mark.parametrize("hd,S,Sq,B,nh", [(80, 257, 257, 3, 4), (96, 321, 64, 3, 4), (64, 200, 130, 3, 4), (80, 257, 257, 21, 16), (72, 193, 140, 5, 8),
