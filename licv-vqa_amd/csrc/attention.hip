@@ -15,6 +15,7 @@
 //   * O^T keeps the query on the lane too, so the running rescale is one multiply per register and the
 //     epilogue stores 4 consecutive head-dim elements (8 bytes) per lane.
 #include "common.h"
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
@@ -683,6 +684,170 @@ void attn_resident_k(AttnP a, int skp, int n_items, int xcd_map) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Long unmasked key sequences (SigLIP at 972+ patch tokens: K and V of a head do not fit LDS): the resident kernel's machinery on
+// key CHUNKS.  An item = (batch, head, block of 128 queries: one 16-query sub-tile per wave, its (m, l, O) state in registers for
+// the whole item); the keys go through LDS in chunks of CHUNK = 256 (four pipelined tiles per wave and chunk, one rendezvous pair
+// per chunk instead of the tiled kernel's per 64 keys), the next chunk - of this item, or the first of the next one - travelling
+// global -> registers meanwhile.  Against the tiled kernel: K / V are re-read per 128 queries instead of 64, a quarter of the
+// barriers, every LDS fragment in registers before its MFMAs, and no global load in a branch.
+// ------------------------------------------------------------------------------------------------
+#define ATT_CHUNK 256
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {     // compile-time loop (register arrays indexed by constants only)
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+template <int DPK, int DPV, int MAXI>   // MAXI: 16-byte chunks per thread per operand (>= ATT_CHUNK * DPV/8 / 512)
+__global__ __launch_bounds__(512, 2)
+void attn_chunked_k(AttnP a, int n_items, int qblocks) {
+    constexpr int KSTR = lds_stride(DPK), VSTR = lds_stride(DPV);
+    constexpr int KS = DPK / 32, DT = DPV / 16;
+    constexpr int ROWS = ATT_CHUNK + 16;                    // (the transposing V read touches one 16-row group past the last real one)
+    extern __shared__ __attribute__((aligned(16))) char rsm[];
+    char* sK = rsm;
+    char* sV = rsm + ROWS * KSTR;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, ql = lane & 15;
+    const float sc = a.scale * 1.4426950408889634f;
+    const int nch = (a.Sk + ATT_CHUNK - 1) / ATT_CHUNK;     // key chunks per item
+    const int G = (int)gridDim.x;
+    constexpr int HC = DPV / 8;
+    constexpr uint32_t OOB = 0xFFFFFFFFu;
+    for (int o = tid * 16; o < ROWS * (KSTR + VSTR); o += 512 * 16) *reinterpret_cast<u32x4*>(rsm + o) = u32x4{0u, 0u, 0u, 0u};
+    auto rsrc = [](const void* p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0xFFFFFFFF, 0x00020000); };
+    // item -> (batch, head, query block): the query blocks of one (batch, head) are consecutive items (they share its K / V in L2)
+    // The prefetch of the next chunk is cut in four parts, part t issued ahead of tile t of the chunk being multiplied: issued in one
+    // go at the head of the chunk, the 8 waves' 80 loads kept the CU's address unit busy for ~2.5 k cycles in which nothing else ran
+    // (a quarter of the chunk).  Straight-line code: every part always issues (only a tile's arithmetic is skipped in a ragged chunk).
+    auto fetch_part = [&](auto part, int item, int chunk, u32x4 (&rk)[MAXI], u32x4 (&rv)[MAXI]) {
+        constexpr int P = decltype(part)::value;             // 0..3, or 4 = all
+        constexpr int I0 = P == 4 ? 0 : P * MAXI / 4, I1 = P == 4 ? MAXI : (P + 1) * MAXI / 4;
+        const bool item_ok = item < n_items;
+        const int pair = (item_ok ? item : 0) / qblocks;
+        const int hh = pair % a.nh, bb = pair / a.nh;
+        const int kvh = hh / (a.nh / a.nkv);
+        const auto rsk = rsrc(a.k + (int64_t)bb * a.kv_bs + (int64_t)kvh * a.hd);
+        const auto rsv = rsrc(a.v + (int64_t)bb * a.kv_bs + (int64_t)kvh * a.hd);
+        const int key0 = chunk * ATT_CHUNK;
+#pragma unroll
+        for (int i = I0; i < I1; ++i) {
+            const int c = tid + i * 512;
+            const int row = c / HC, ch = c % HC;
+            const bool ok = (int)item_ok & (int)(row < ATT_CHUNK) & (int)(key0 + row < a.Sk) & (int)(ch * 8 < a.hd);
+            const uint32_t off = ok ? (uint32_t)((key0 + row) * (int)a.kv_rs + ch * 8) * 2u : OOB;
+            rk[i] = __builtin_amdgcn_raw_buffer_load_b128(rsk, off, 0, 0);
+            rv[i] = __builtin_amdgcn_raw_buffer_load_b128(rsv, off, 0, 0);
+        }
+    };
+    // (every row of the chunk is written: keys past Sk arrive as zeros, so a ragged last chunk leaves no stale rows behind)
+    auto park = [&](const u32x4 (&rk)[MAXI], const u32x4 (&rv)[MAXI]) {
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+            const int c = tid + i * 512;
+            const int row = c / HC, ch = c % HC;
+            if (row < ATT_CHUNK && ch * 8 < a.hd) {
+                *reinterpret_cast<u32x4*>(sK + row * KSTR + ch * 16) = rk[i];
+                *reinterpret_cast<u32x4*>(sV + row * VSTR + ch * 16) = rv[i];
+            }
+        }
+    };
+    auto load_q = [&](int item, bf16x8 (&q)[KS]) {
+        const bool item_ok = item < n_items;
+        const int it = item_ok ? item : 0;
+        const int pair = it / qblocks, qb = it % qblocks;
+        const int hh = pair % a.nh, bb = pair / a.nh;
+        const auto rsq = rsrc(a.q + (int64_t)bb * a.q_bs + (int64_t)hh * a.hd);
+        const int qrow = qb * 128 + wave * 16 + ql;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int d = ks * 32 + g * 8;
+            const bool ok = (int)item_ok & (int)(qrow < a.Sq) & (int)(d < a.hd);
+            const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rsq, ok ? (uint32_t)(qrow * (int)a.q_rs + d) * 2u : OOB, 0, 0);
+            q[ks] = *reinterpret_cast<const bf16x8*>(&r);
+        }
+    };
+
+    int item = (int)blockIdx.x;
+    bf16x8 qf[KS], qf_next[KS];
+    {
+        u32x4 rk[MAXI], rv[MAXI];
+        fetch_part(std::integral_constant<int, 4>{}, item, 0, rk, rv);
+        load_q(item, qf);
+        load_q(item + G, qf_next);
+        __syncthreads();                        // the zero fill is complete before any real chunk lands on it
+        if (item < n_items) park(rk, rv);
+        __syncthreads();
+    }
+    for (; item < n_items; item += G) {
+        const int pair = item / qblocks, qb = item % qblocks;
+        const int head = pair % a.nh, b = pair / a.nh;
+        const auto rso = rsrc(a.o + ((int64_t)b * a.Sq * a.nh + head) * a.hd);
+        floatx4 oacc[DT];
+#pragma unroll
+        for (int i = 0; i < DT; ++i) oacc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+        float m_run = -INFINITY, l_run = 0.f;
+        const bool wave_live = qb * 128 + wave * 16 < a.Sq;           // (the last query block of a head may not fill all 8 waves)
+        int c = 0;
+        do {
+            const bool last = c + 1 >= nch;
+            u32x4 rk[MAXI], rv[MAXI];
+            const int nitem = last ? item + G : item, nchunk = last ? 0 : c + 1;
+            const int left = min(ATT_CHUNK, a.Sk - c * ATT_CHUNK);     // real keys in this chunk
+            const int nfull = wave_live ? left >> 6 : 0, nst_last = wave_live ? ((left & 63) + 15) >> 4 : 0;
+            const char* kp = sK + ql * KSTR + g * 16;
+            const char* vp = sV + (g * 4 + (ql >> 2)) * VSTR + (ql & 3) * 8;
+            bf16x8 kf[4][KS];
+#pragma unroll
+            for (int st = 0; st < 4; ++st)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) kf[st][ks] = *reinterpret_cast<const bf16x8*>(kp + st * 16 * KSTR + ks * 64);
+            auto all = [](int, int) -> bool { return true; };
+            static_for<0, 4>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                fetch_part(tc, nitem, nchunk, rk, rv);
+                if (t < nfull)
+                    attn_tile_pipe<DPK, DPV, 4, false, true>(kf, vp + t * ATT_KB * VSTR, kp + (t + 1) * ATT_KB * KSTR, qf, oacc, m_run, l_run, sc, all);
+            });
+            if (nst_last) {
+                const char* vt = vp + nfull * ATT_KB * VSTR;
+                const int rem = left - nfull * ATT_KB;
+                auto in_range = [&](int st, int r) -> bool { return st * 16 + g * 4 + r < rem; };
+                if (nst_last == 1)      attn_tile_pipe<DPK, DPV, 1, true, false>(kf, vt, nullptr, qf, oacc, m_run, l_run, sc, in_range);
+                else if (nst_last == 2) attn_tile_pipe<DPK, DPV, 2, true, false>(kf, vt, nullptr, qf, oacc, m_run, l_run, sc, in_range);
+                else if (nst_last == 3) attn_tile_pipe<DPK, DPV, 3, true, false>(kf, vt, nullptr, qf, oacc, m_run, l_run, sc, in_range);
+                else                    attn_tile_pipe<DPK, DPV, 4, true, false>(kf, vt, nullptr, qf, oacc, m_run, l_run, sc, in_range);
+            }
+            ++c;
+            __syncthreads();                    // every wave is done with this chunk
+            if (!last || item + G < n_items) park(rk, rv);
+            __syncthreads();
+        } while (c < nch);
+        l_run += __shfl_xor(l_run, 16, 64);
+        l_run += __shfl_xor(l_run, 32, 64);
+        const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+        const int qrow = qb * 128 + wave * 16 + ql;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const int d = dt * 16 + g * 4;
+            typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+            u32x2 u;
+            u.x = (uint32_t)f2bf(oacc[dt][0] * inv) | ((uint32_t)f2bf(oacc[dt][1] * inv) << 16);
+            u.y = (uint32_t)f2bf(oacc[dt][2] * inv) | ((uint32_t)f2bf(oacc[dt][3] * inv) << 16);
+            const bool ok = (int)(qrow < a.Sq) & (int)(d < a.hd);
+            __builtin_amdgcn_raw_buffer_store_b64(u, rso, ok ? (uint32_t)(qrow * (a.nh * a.hd) + d) * 2u : OOB, 0, 0);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {       // (a real move: see attn_resident_k)
+            u32x4 t = *reinterpret_cast<const u32x4*>(&qf_next[ks]), r;
+            asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
+                         : "=&v"(r.x), "=&v"(r.y), "=&v"(r.z), "=&v"(r.w) : "v"(t.x), "v"(t.y), "v"(t.z), "v"(t.w));
+            qf[ks] = *reinterpret_cast<const bf16x8*>(&r);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        load_q(item + 2 * G, qf_next);
+    }
+}
+
 #ifdef LICV_ATTN_TRACE
 extern "C" int licv_attn_debug_timestamps(void* dev_buffer) {
     long long* p = (long long*)dev_buffer;
@@ -740,6 +905,27 @@ extern "C" int licv_attn_fwd(const licv_attn_args* x, void* stream) {
             else                { if (mi == 6) RES_LAUNCH(96, 96, 6); else if (mi == 8) RES_LAUNCH(96, 96, 8); else RES_LAUNCH(96, 96, 10); }
 #undef RES_LAUNCH
 #undef RES_LAUNCH1
+            LICV_LAUNCH_CHECK();
+            return LICV_OK;
+        }
+    }
+    if (x->mask_mode == 0 && !g_attn_force_tiled && hd0 > 32 && hd0 <= 96 && x->Sk >= 256 && x->Sq >= 128 &&
+        x->Sq * x->q_rs * 2 < (1ll << 31) && x->Sk * x->kv_rs * 2 < (1ll << 31) && x->Sq * x->n_heads * x->head_dim * 2 < (1ll << 31)) {
+        // keys too long for the resident variant: the chunked one (128 queries per item, 256 keys per chunk)
+        const int dpk = hd0 <= 64 ? 64 : 96, dpv = hd0 <= 64 ? 64 : (hd0 <= 80 ? 80 : 96);
+        const int64_t lds = (int64_t)(ATT_CHUNK + 16) * (lds_stride(dpk) + lds_stride(dpv));
+        const int qblocks = (int)((x->Sq + 127) / 128);
+        const int64_t items = x->B * x->n_heads * qblocks;
+        if (items < (1ll << 30)) {
+            const dim3 cgrid((unsigned)(items < 256 ? items : 256)), cblock(512);
+            hipStream_t cst = (hipStream_t)stream;
+#define CHK_LAUNCH(DK, DV, MI) do { static bool attr_c_##DK##_##DV = false; \
+                if (!attr_c_##DK##_##DV) { (void)hipFuncSetAttribute((const void*)attn_chunked_k<DK, DV, MI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_c_##DK##_##DV = true; } \
+                attn_chunked_k<DK, DV, MI><<<cgrid, cblock, lds, cst>>>(p, (int)items, qblocks); } while (0)
+            if (dpk == 64)      CHK_LAUNCH(64, 64, 4);
+            else if (dpv == 80) CHK_LAUNCH(96, 80, 5);
+            else                CHK_LAUNCH(96, 96, 6);
+#undef CHK_LAUNCH
             LICV_LAUNCH_CHECK();
             return LICV_OK;
         }
