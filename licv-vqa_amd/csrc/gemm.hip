@@ -2046,7 +2046,6 @@ void pack_gate_up_k(const bf16_t* __restrict__ g, const bf16_t* __restrict__ u, 
 
 // experiments live in gemm_experiments.hip
 extern "C" int licv_gemm_exp_launch(int which, const GemmArgs* g);
-extern "C" int licv_gemm_exp_splitk_producer(const GemmArgs* g, void* workspace, int t256m, int t256n, int splits, int per32);
 extern "C" int licv_gemm_exp_knob(int knob, int value);
 extern "C" int licv_gemm_exp_debug_timestamps(void* dev_buffer);
 

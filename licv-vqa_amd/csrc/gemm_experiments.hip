@@ -926,11 +926,3 @@ extern "C" int licv_gemm_exp_launch(int which, const GemmArgs* g) {
     return 1;
 }
 
-// split-K producer on the round-1 ping-pong kernel (select 6 only: A/B against gemm_bf16_lean_k<1>)
-extern "C" int licv_gemm_exp_splitk_producer(const GemmArgs* g, void* workspace, int t256m, int t256n, int splits, int per32) {
-    static bool attr5 = false;
-    if (!attr5) { (void)hipFuncSetAttribute((const void*)gemm_bf16_pingpong_k<5>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_STAGES * RING_STAGE_BYTES); attr5 = true; }
-    gemm_bf16_pingpong_k<5><<<dim3(t256m * t256n, splits), dim3(512), RING_STAGES * RING_STAGE_BYTES, g->stream>>>(
-        (const bf16_t*)g->A, g->lda, (const bf16_t*)g->W, g->ldw, workspace, 0, g->M, g->N, g->K, t256m, t256n, g->ep, 0, per32);
-    return 1;
-}
