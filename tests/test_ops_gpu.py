@@ -752,3 +752,36 @@ def test_add_rmsnorm_and_hook_with_pre_added_branch_match_the_residual_epilogue(
     h3 = h0.clone()
     x3 = o.add_rmsnorm_(h3, br, lnw, 1e-6, row_gate=gate, scale=0.37)
     assert torch.equal(h3, h_ref) and torch.equal(x3, x_ref)
+
+
+def test_gelu_epilogue_rounds_like_the_exact_function_on_every_bf16_input():
+    """The erf-GELU epilogue (hf:idefics/vision.py CLIP MLP, `gelu`) sees a bf16 value (bf16(acc + bias)) and its result is rounded to
+    bf16: so it can be checked on ALL 65280 finite bf16 inputs.  x is fed through a GEMM whose weight picks column 0 (acc = x exactly):
+    the small-tile kernel (scalar form of the function) and the 4-wave flow kernel (packed form) must agree bit for bit, and equal
+    bf16(exact GELU(x)) for every x >= -6.5 but at most two inputs (|GELU| < 2.2e-10 below that: absolute bar)."""
+    from licv import _lib
+    bits = torch.arange(65536, dtype=torch.int32).to(torch.int16)
+    vals = bits.view(torch.bfloat16)
+    vals = vals[torch.isfinite(vals.float())]
+    n = vals.numel()
+    M = (n + 511) // 512 * 512
+    a = torch.zeros(M, 256, dtype=torch.bfloat16)
+    a[:n, 0] = vals
+    w = torch.zeros(256, 256, dtype=torch.bfloat16)
+    w[:, 0] = 1.0
+    outs = []
+    try:
+        for sel in (1, 60):
+            _lib.lib().licv_gemm_select(sel)
+            outs.append(ops().linear(a.to(DEV), w.to(DEV), act="gelu").cpu()[:n])
+    finally:
+        _lib.lib().licv_gemm_select(0)
+    assert torch.equal(outs[0], outs[1])
+    got = outs[1][:, 0]
+    assert all(torch.equal(outs[1][:, j], got) for j in (1, 17, 255))
+    ref = torch.nn.functional.gelu(vals.double()).float().to(torch.bfloat16)
+    near = vals.float() >= -6.5
+    same = got.view(torch.int16) == ref.view(torch.int16)
+    assert int((~same & near).sum()) <= 2, vals[~same & near].tolist()
+    assert float((got.float() - ref.float())[near].abs().max()) <= 2.0 ** -7          # (the few misses are one ulp off)
+    assert float(got[~near].float().abs().max()) <= 2.5e-10
