@@ -847,11 +847,12 @@ void gemm_bf16_flow64_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t*
     bf16x8 fa0[8], fw0[8], fa1[8], fw1[8];
     // accumulator (i, j) += W fragment j (x) A fragment i; M = 8 i + j is a compile-time constant at every call
 #define F64_MFMA(M, w, a) asm volatile("v_mfma_f32_16x16x32_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" :: "v"(w), "v"(a), "i"(4 * (M)), "i"(4 * (M) + 3))
-    // read accumulator (i, j) into four floats and clear it (the next tile's first MFMA then accumulates onto zero)
+    // ... the first MFMA of an output tile onto accumulator (i, j): C = 0, so the epilogue does not have to clear the 256 registers it reads
+#define F64_MFMA0(M, w, a) asm volatile("v_mfma_f32_16x16x32_bf16 a[%c2:%c3], %0, %1, 0" :: "v"(w), "v"(a), "i"(4 * (M)), "i"(4 * (M) + 3))
+    // read accumulator (i, j) into four floats (the next tile's first MFMA onto it takes C = 0: nothing to clear)
     auto take = [&](auto m_c, float (&v)[4]) {
         constexpr int R = 4 * decltype(m_c)::value;
-        asm volatile("v_accvgpr_read_b32 %0, a[%c4]\n\tv_accvgpr_read_b32 %1, a[%c5]\n\tv_accvgpr_read_b32 %2, a[%c6]\n\tv_accvgpr_read_b32 %3, a[%c7]\n\t"
-                     "v_accvgpr_write_b32 a[%c4], 0\n\tv_accvgpr_write_b32 a[%c5], 0\n\tv_accvgpr_write_b32 a[%c6], 0\n\tv_accvgpr_write_b32 a[%c7], 0"
+        asm volatile("v_accvgpr_read_b32 %0, a[%c4]\n\tv_accvgpr_read_b32 %1, a[%c5]\n\tv_accvgpr_read_b32 %2, a[%c6]\n\tv_accvgpr_read_b32 %3, a[%c7]"
                      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "i"(R), "i"(R + 1), "i"(R + 2), "i"(R + 3));
     };
 
@@ -908,7 +909,7 @@ void gemm_bf16_flow64_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t*
                 }
                 if constexpr (m == 15) F64_M0(lds_base + pW2);
                 if constexpr (m >= 16 && m < 40 && (m - 16) % 3 == 0) piece_w(std::integral_constant<int, (m - 16) / 3>{}, kb);
-                F64_MFMA(m, fw0[j], fa0[i]);
+                if constexpr (FIRST) F64_MFMA0(m, fw0[j], fa0[i]); else F64_MFMA(m, fw0[j], fa0[i]);
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
@@ -1062,12 +1063,7 @@ void gemm_bf16_flow64_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t*
                 });
             }
         } else {
-            // a wave past N (the last tile column when N % 256 == 128): nothing to store, but its accumulators start the next tile too
-            static_for<0, 64>([&](auto mc) {
-                constexpr int R = 4 * decltype(mc)::value;
-                asm volatile("v_accvgpr_write_b32 a[%c0], 0\n\tv_accvgpr_write_b32 a[%c1], 0\n\tv_accvgpr_write_b32 a[%c2], 0\n\tv_accvgpr_write_b32 a[%c3], 0"
-                             :: "i"(R), "i"(R + 1), "i"(R + 2), "i"(R + 3));
-            });
+            // a wave past N (the last tile column when N % 256 == 128): nothing to store (its accumulators restart from C = 0 with the next tile)
         }
         asm volatile("s_nop 1" ::: "memory");                // accumulator writes (v_accvgpr_write) ahead of the next inline-asm MFMA
         __builtin_amdgcn_sched_barrier(0);
@@ -1080,6 +1076,7 @@ void gemm_bf16_flow64_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t*
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the spare pieces issued after the last tile's K tile nt - 2 land in LDS: not after the workgroup is gone
 #undef F64_MFMA
+#undef F64_MFMA0
 #undef F64_M0
 #undef F64_PIECE
 #undef F64_BIAS1
@@ -1214,11 +1211,11 @@ void gemm_fp8_flow64_k(const char* __restrict__ A, int64_t lda, const char* __re
     i32x8 fa[8], fw[8];
     // accumulator (i, j) += W fragment j (x) A fragment i; M = 8 i + j is a compile-time constant at every call
 #define F64_MFMA(M, w, a) asm volatile("v_mfma_f32_16x16x128_f8f6f4 a[%c2:%c3], %0, %1, a[%c2:%c3]" :: "v"(w), "v"(a), "i"(4 * (M)), "i"(4 * (M) + 3))
-    // read accumulator (i, j) into four floats and clear it (the next tile's first MFMA then accumulates onto zero)
+#define F64_MFMA0(M, w, a) asm volatile("v_mfma_f32_16x16x128_f8f6f4 a[%c2:%c3], %0, %1, 0" :: "v"(w), "v"(a), "i"(4 * (M)), "i"(4 * (M) + 3))
+    // read accumulator (i, j) into four floats (the next tile's first MFMA onto it takes C = 0: nothing to clear)
     auto take = [&](auto m_c, float (&v)[4]) {
         constexpr int R = 4 * decltype(m_c)::value;
-        asm volatile("v_accvgpr_read_b32 %0, a[%c4]\n\tv_accvgpr_read_b32 %1, a[%c5]\n\tv_accvgpr_read_b32 %2, a[%c6]\n\tv_accvgpr_read_b32 %3, a[%c7]\n\t"
-                     "v_accvgpr_write_b32 a[%c4], 0\n\tv_accvgpr_write_b32 a[%c5], 0\n\tv_accvgpr_write_b32 a[%c6], 0\n\tv_accvgpr_write_b32 a[%c7], 0"
+        asm volatile("v_accvgpr_read_b32 %0, a[%c4]\n\tv_accvgpr_read_b32 %1, a[%c5]\n\tv_accvgpr_read_b32 %2, a[%c6]\n\tv_accvgpr_read_b32 %3, a[%c7]"
                      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "i"(R), "i"(R + 1), "i"(R + 2), "i"(R + 3));
     };
 
@@ -1276,7 +1273,7 @@ void gemm_fp8_flow64_k(const char* __restrict__ A, int64_t lda, const char* __re
             constexpr int i = m >> 3, j = m & 7;
             if constexpr (m == 0) F64_M0(lds_base + pW2);
             if constexpr (m >= 2 && m < 26 && (m - 2) % 3 == 0) piece_w(std::integral_constant<int, (m - 2) / 3>{}, kb);
-            F64_MFMA(m, fw[j], fa[i]);
+            if constexpr (FIRST) F64_MFMA0(m, fw[j], fa[i]); else F64_MFMA(m, fw[j], fa[i]);
             __builtin_amdgcn_sched_barrier(0);
         });
         // ---- step 1, rows 4-7: rendezvous (K tile g + 1 published, every wave done with the LDS of K tile g), re-reads, pieces of
@@ -1289,7 +1286,7 @@ void gemm_fp8_flow64_k(const char* __restrict__ A, int64_t lda, const char* __re
                 constexpr int i = m >> 3, j = m & 7;
                 if constexpr (m == 35) F64_M0(lds_base + pW);        // the pair of K tile g's W units, free since the rendezvous
                 if constexpr (m >= 36 && m < 60 && (m - 36) % 3 == 0) piece_a(std::integral_constant<int, (m - 36) / 3>{}, kb);
-                F64_MFMA(m, fw[j], fa[i]);
+                if constexpr (FIRST) F64_MFMA0(m, fw[j], fa[i]); else F64_MFMA(m, fw[j], fa[i]);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (m == 33) {
                     // in flight, oldest first: W(g+1), A(g+1), [the previous epilogue's stores and bias / scale loads,] W(g+2): retire K tile g + 1
@@ -1441,12 +1438,7 @@ void gemm_fp8_flow64_k(const char* __restrict__ A, int64_t lda, const char* __re
                 });
             }
         } else {
-            // a wave past N (the last tile column when N % 256 == 128): nothing to store, but its accumulators start the next tile too
-            static_for<0, 64>([&](auto mc) {
-                constexpr int R = 4 * decltype(mc)::value;
-                asm volatile("v_accvgpr_write_b32 a[%c0], 0\n\tv_accvgpr_write_b32 a[%c1], 0\n\tv_accvgpr_write_b32 a[%c2], 0\n\tv_accvgpr_write_b32 a[%c3], 0"
-                             :: "i"(R), "i"(R + 1), "i"(R + 2), "i"(R + 3));
-            });
+            // a wave past N (the last tile column when N % 256 == 128): nothing to store (its accumulators restart from C = 0 with the next tile)
         }
         asm volatile("s_nop 1" ::: "memory");                // accumulator writes (v_accvgpr_write) ahead of the next inline-asm MFMA
         __builtin_amdgcn_sched_barrier(0);
@@ -1459,6 +1451,7 @@ void gemm_fp8_flow64_k(const char* __restrict__ A, int64_t lda, const char* __re
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the spare pieces issued after the last tile's K tile nt - 2 land in LDS: not after the workgroup is gone
 #undef F64_MFMA
+#undef F64_MFMA0
 #undef F64_M0
 #undef F64_PIECE
 #undef F8_BS1
