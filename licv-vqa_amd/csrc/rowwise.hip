@@ -552,6 +552,49 @@ void quantize_rows_fp8_k(const void* __restrict__ x, uint8_t* __restrict__ q, fl
     }
 }
 
+// The same quantiser for bf16 rows of up to 16384 elements (dim % 8 == 0), the row held in registers: every 16-byte load of the row
+// is issued before the first value is used (buffer loads, out-of-range chunks read as zero), ONE pass over memory.  The two-sweep
+// kernel above keeps one 8-byte load per lane in flight (28 dependent round trips for a 14336-wide SwiGLU output row): as the
+// last separate quantiser calls of the fp8 step (attention outputs, SwiGLU / GELU outputs) it was 13 % of the Idefics2 32-shot step.
+template <int NCH>      // chunks of 512 elements
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK)
+void quantize_rows_fp8_wide_k(const bf16_t* __restrict__ x, uint8_t* __restrict__ q, float* __restrict__ scale, int64_t rows, int dim,
+                              int64_t ld_x, int64_t ld_q) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(x + row * ld_x), 0, (int)(dim * 2), 0x00020000);   // past the row: zeros
+    u32x4_r raw[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) raw[c] = __builtin_amdgcn_raw_buffer_load_b128(rs, (uint32_t)((c * 64 + lane) * 16), 0, 0);
+    float amax = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            amax = fmaxf(amax, fabsf(__uint_as_float(raw[c][e] << 16)));
+            amax = fmaxf(amax, fabsf(__uint_as_float(raw[c][e] & 0xffff0000u)));
+        }
+    amax = wave_max(amax);
+    const float sc = fmaxf(amax, 1e-12f) / 448.0f;
+    if (lane == 0) scale[row] = sc;
+    uint8_t* qrow = q + row * ld_q;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int i = (c * 64 + lane) * 8;
+        if (i < dim) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[2 * e] = __uint_as_float(raw[c][e] << 16); v[2 * e + 1] = __uint_as_float(raw[c][e] & 0xffff0000u); }
+            int w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[0] / sc, v[1] / sc, 0, false);
+            w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[2] / sc, v[3] / sc, w0, true);
+            int w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[4] / sc, v[5] / sc, 0, false);
+            w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[6] / sc, v[7] / sc, w1, true);
+            *reinterpret_cast<int2*>(qrow + i) = int2{w0, w1};
+        }
+    }
+}
+
 // ViT embeddings + pre-LN: hf:idefics/vision.py:152-166 then :369
 template <int NCH>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK)
@@ -966,6 +1009,16 @@ extern "C" int licv_quantize_rows_fp8(const void* x, int x_dtype, void* q_fp8, f
     if (rows <= 0) return LICV_OK;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(row_blocks(rows)), block(64 * WAVES_PER_BLOCK);
+    if (x_dtype == LICV_BF16 && dim % 8 == 0 && dim <= 16384 && ld_x % 8 == 0 && ld_q % 8 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)q_fp8 & 7) == 0 &&
+        ld_x * 2 < (1ll << 31)) {
+        const int n8 = (int)((dim + 511) / 512);
+#define LAUNCH_QW(NC) quantize_rows_fp8_wide_k<NC><<<grid, block, 0, st>>>((const bf16_t*)x, (uint8_t*)q_fp8, scale, rows, (int)dim, ld_x, ld_q)
+        if (n8 <= 2) LAUNCH_QW(2); else if (n8 <= 3) LAUNCH_QW(3); else if (n8 <= 4) LAUNCH_QW(4); else if (n8 <= 8) LAUNCH_QW(8);
+        else if (n8 <= 9) LAUNCH_QW(9); else if (n8 <= 16) LAUNCH_QW(16); else if (n8 <= 24) LAUNCH_QW(24); else if (n8 <= 28) LAUNCH_QW(28); else LAUNCH_QW(32);
+#undef LAUNCH_QW
+        LICV_LAUNCH_CHECK();
+        return LICV_OK;
+    }
     if (x_dtype == LICV_F32) quantize_rows_fp8_k<LICV_F32><<<grid, block, 0, st>>>(x, (uint8_t*)q_fp8, scale, rows, (int)dim, ld_x, ld_q);
     else                     quantize_rows_fp8_k<LICV_BF16><<<grid, block, 0, st>>>(x, (uint8_t*)q_fp8, scale, rows, (int)dim, ld_x, ld_q);
     LICV_LAUNCH_CHECK();

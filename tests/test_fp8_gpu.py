@@ -19,7 +19,7 @@ def _ref_quant(x):
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
-@pytest.mark.parametrize("rows,K", [(5, 64), (300, 1152), (129, 4096), (7, 14336)])
+@pytest.mark.parametrize("rows,K", [(5, 64), (300, 1152), (129, 4096), (7, 14336), (33, 4352), (9, 16384), (3, 16392), (65, 520), (40, 1024)])
 def test_quantize_rows_matches_torch_cast(dt, rows, K):
     from licv import ops
     g = torch.Generator().manual_seed(rows + K)
@@ -30,6 +30,11 @@ def test_quantize_rows_matches_torch_cast(dt, rows, K):
     rq, rsc = _ref_quant(x)
     assert torch.equal(sc.cpu(), rsc)
     assert torch.equal(q.cpu(), rq)
+    if K % 16 == 0:                                               # rows inside a wider buffer (the one-pass kernel reads past no row end)
+        wide = torch.full((rows, K + 64), 1e4, dtype=dt)
+        wide[:, :K] = x
+        q2, sc2 = ops.quantize_fp8(wide.to(DEV)[:, :K])
+        assert torch.equal(sc2.cpu(), rsc) and torch.equal(q2.cpu(), rq)
 
 
 @pytest.mark.parametrize("M,N,K,epi", [(512, 256, 256, "none"), (1000, 3000, 1152, "bias_gelu"), (700, 512, 4096, "res16"),
