@@ -409,8 +409,7 @@ class Idefics2Engine:
                 x = ops.rmsnorm(h, L.in_ln, a.rms_eps, 1)
             xn = None
             qkv = self._tlin(x, L, "qkv_w")
-            ops.rotary_(qkv, w.cos, w.sin, pos, M, nh, hd, ldq, qd, 1)
-            ops.rotary_(qkv.view(-1)[qd:], w.cos, w.sin, pos, M, nkv, hd, ldq, kd, 1)
+            ops.rotary_(qkv, w.cos, w.sin, pos, M, nh + nkv, hd, ldq, 0, 1)       # Q heads | K heads are contiguous in the fused row: one launch
             if kv_cache is None:
                 o = ops.attention(qkv, qkv.view(-1)[qd:], qkv.view(-1)[qd + kd:], B, S, S, nh, nkv, hd, S * ldq, ldq, S * ldq, ldq,
                                   hd ** -0.5, 1, key_valid=key_valid)

@@ -256,8 +256,7 @@ class StudentPass2:
             rec = {"h_in": h}
             xn = ops.rmsnorm(h, L.in_ln, a.rms_eps, 1)
             qkv = ops.linear(xn, L.qkv_w)
-            ops.rotary_(qkv, w.cos, w.sin, pos, M, nh, hd, ldq, qd, 1)
-            ops.rotary_(qkv.view(-1)[qd:], w.cos, w.sin, pos, M, nkv, hd, ldq, kd, 1)
+            ops.rotary_(qkv, w.cos, w.sin, pos, M, nh + nkv, hd, ldq, 0, 1)       # Q heads | K heads contiguous in the fused row
             rec["qkv"] = qkv
             o = ops.attention(qkv, qkv.view(-1)[qd:], qkv.view(-1)[qd + kd:], B, S, S, nh, nkv, hd, S * ldq, ldq, S * ldq, ldq,
                               hd ** -0.5, 1, key_valid=key_valid)
@@ -319,8 +318,7 @@ class StudentPass2:
                                     dkv_bs=S * 2 * qd, dkv_rs=2 * qd, key_valid=st["key_valid"])
             ops.head_group_sum(dkv_heads, dqkv.view(-1)[qd:], M, nkv, rep, hd, 2 * qd, ldq)
             ops.head_group_sum(dkv_heads.view(-1)[qd:], dqkv.view(-1)[qd + kd:], M, nkv, rep, hd, 2 * qd, ldq)
-            ops.rotary_(dqkv, w.cos, tw.neg_sin, st["pos"], M, nh, hd, ldq, qd, 1)           # inverse rotation of dQ and dK
-            ops.rotary_(dqkv.view(-1)[qd:], w.cos, tw.neg_sin, st["pos"], M, nkv, hd, ldq, kd, 1)
+            ops.rotary_(dqkv, w.cos, tw.neg_sin, st["pos"], M, nh + nkv, hd, ldq, 0, 1)      # inverse rotation of dQ and dK
             d_x = ops.linear(dqkv, T["qkv_T"])
             ops.rmsnorm_bwd(rec["h_in"], L.in_ln, d_x, dh, a.rms_eps, accumulate=True)
         return grad_v
