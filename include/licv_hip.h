@@ -134,6 +134,25 @@ int64_t licv_workspace_size(int64_t M, int64_t N, int64_t K);
 int licv_gemm_bf16_splitk(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
                           int64_t M, int64_t N, int64_t K, const licv_gemm_epilogue* e, int splits,
                           void* workspace, int64_t workspace_bytes, void* stream);
+/* The producer half alone, for a plain epilogue whose consumer is a row kernel (decode steps and the 32-token student pass of
+ * ref:inference.py:300-321 / ref:icv_src/icv_module.py:97-98, where a launch costs as much as the kernel): `splits` fp32 slices of
+ * A W^T are left in the workspace — slice sp of row m at workspace + sp * slice_elems + m * row_stride (floats) — and the consumer
+ * (licv_add_rmsnorm_fwd_ws, licv_inject_renorm_pre_fwd_ws, licv_rotary_kv_append_ws) sums them in slice order and rounds to bf16
+ * itself: bit for bit the finalize kernel's output, one launch less per projection. */
+int licv_gemm_bf16_splitk_produce(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int64_t N, int64_t K, int splits,
+                                  void* workspace, int64_t workspace_bytes, int64_t* slice_elems, int64_t* row_stride, void* stream);
+/* licv_add_rmsnorm_fwd / licv_inject_renorm_pre_fwd / licv_rotary_kv_append with the bf16 operand (branch, branch, qkv) replaced by
+ * the split-K slices it would have been finalized from.  Bit-identical to finalize + the plain entry point (same per-lane sums).
+ * licv_rotary_kv_append_ws writes the rotated Q rows into qkv_bf16[:, 0:H] (the attention kernel's Q operand) and nothing else there. */
+int licv_add_rmsnorm_fwd_ws(void* h, int h_dtype, const float* ws, int splits, int64_t slice_elems, int64_t row_stride,
+                            const float* row_gate, int use_scale, float scale, const void* w_bf16, void* out_bf16,
+                            int64_t rows, int64_t dim, float eps, int flavour, void* stream);
+int licv_inject_renorm_pre_fwd_ws(const void* h, int h_dtype, const float* ws, int splits, int64_t slice_elems, int64_t row_stride,
+                                  const float* icv_row, const float* alpha, float* out, int64_t rows, int64_t hidden,
+                                  const void* norm_w, void* xn_out, float norm_eps, void* stream);
+int licv_rotary_kv_append_ws(const float* ws, int splits, int64_t slice_elems, int64_t row_stride, void* qkv_bf16,
+                             const void* cos_bf16, const void* sin_bf16, const int64_t* position_ids, int64_t batch, int64_t S,
+                             int64_t n_heads, int64_t head_dim, int64_t n_pos, void* cache_bf16, int64_t cache_max_len, int64_t past, void* stream);
 
 /* ---- fp8 path (BASELINE configs[4]: "fp8 weights on CDNA4 MFMA"; no reference counterpart — parity bar in DESIGN.md) ----
  * q[r,k] = e4m3(x[r,k] / scale[r]), scale[r] = amax(x[r,:]) / 448 (OCP e4m3fn, round to nearest even).  Weights are quantised
@@ -303,8 +322,9 @@ typedef struct {
     void* logits; int64_t ld_logits;                   /* (rows, ld_logits >= vocab_total) bf16 */
 } licv_idefics_text_call;
 /* Options of the runner: 0 = fold the decoder layers' two residual adds into the row kernels that follow (licv_add_rmsnorm_fwd,
- * licv_inject_renorm_pre_fwd) when M >= 512, so the o / down projections take the register-direct GEMM epilogue (default 1;
- * bit-identical either way, 0 is for A/B timing). */
+ * licv_inject_renorm_pre_fwd), so the o / down projections take the register-direct GEMM epilogue (default 1; bit-identical either
+ * way, 0 is for A/B timing).  1 = where the o / down / QKV projections run split-K (M < 512), let the row kernel behind each of
+ * them sum the slices (the *_ws entry points) instead of a finalize launch (default 1; bit-identical). */
 int licv_runner_option(int option, int value);
 int licv_idefics_text_forward(const licv_idefics_text_weights* w, const licv_idefics_text_call* c, void* stream);
 

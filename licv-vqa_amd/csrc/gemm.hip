@@ -2343,9 +2343,12 @@ extern "C" int64_t licv_workspace_size(int64_t M, int64_t N, int64_t K) {
     return sp > 1 ? nb : 0;
 }
 
-extern "C" int licv_gemm_bf16_splitk(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
-                                     int64_t M, int64_t N, int64_t K, const licv_gemm_epilogue* e, int splits,
-                                     void* workspace, int64_t workspace_bytes, void* stream) {
+// The split-K GEMM in two halves: the producer (fp32 slices into the workspace) and the finalize.  `finalize` false: the producer only —
+// the caller's next row kernel sums the slices itself (licv_*_ws entry points: one launch less per projection of a decode step); the
+// slice layout comes back through slice_elems / row_stride.
+static int splitk_run(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
+                      int64_t M, int64_t N, int64_t K, const licv_gemm_epilogue* e, int splits,
+                      void* workspace, int64_t workspace_bytes, void* stream, bool finalize, int64_t* slice_elems, int64_t* row_stride) {
     LICV_CHECK_ARG(A && W && C && e && workspace, "gemm_bf16_splitk: null pointer");
     LICV_CHECK_ARG(M > 0 && N > 0 && K > 0 && splits >= 2, "gemm_bf16_splitk: bad shape / splits");
     LICV_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0 && K % 8 == 0, "gemm_bf16_splitk: lda/ldw/K must be multiples of 8");
@@ -2376,10 +2379,11 @@ extern "C" int licv_gemm_bf16_splitk(const void* A, int64_t lda, const void* W, 
         const dim3 grid((unsigned)((N + 63) / 64), (unsigned)splits);
         const int mb = M <= 16 ? 1 : 2;
         const size_t lds = (size_t)(M + 1) * (per * 32 * 2 + 16);
-        unsigned* tickets = g_skinny_inlaunch ? skinny_tickets_for(sst, (int)grid.x) : nullptr;
+        unsigned* tickets = (g_skinny_inlaunch && finalize) ? skinny_tickets_for(sst, (int)grid.x) : nullptr;
+        if (slice_elems) { *slice_elems = 32 * np; *row_stride = np; }
         if (mb == 1) gemm_bf16_skinny_k<1><<<grid, 256, lds, sst>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, (float*)workspace, (int)M, (int)N, (int)K, per, np, tickets, C, ldc, eps);
         else         gemm_bf16_skinny_k<2><<<grid, 256, lds, sst>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, (float*)workspace, (int)M, (int)N, (int)K, per, np, tickets, C, ldc, eps);
-        if (!tickets) {
+        if (!tickets && finalize) {
             const int n_out = e->swiglu ? (int)(N / 2) : (int)N;
             const int64_t items = (int64_t)M * ((n_out + 3) / 4);
             skinny_finalize_k<<<dim3((unsigned)((items + 255) / 256)), dim3(256), 0, sst>>>((const float*)workspace, C, ldc, (int)M, (int)N, np, splits, eps, 32);
@@ -2415,11 +2419,32 @@ extern "C" int licv_gemm_bf16_splitk(const void* A, int64_t lda, const void* W, 
     }
     // the row-major finalize (4 consecutive columns per thread: coalesced 16-byte reads of every slice, same rounding points as the
     // staged epilogue); the first version walked the partials in the accumulator layout through an LDS image: ~8 us per extra split
-    const int n_out = e->swiglu ? (int)(N / 2) : (int)N;
-    const int64_t items = (int64_t)M * ((n_out + 3) / 4);
-    skinny_finalize_k<<<dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st>>>((const float*)workspace, C, ldc, (int)M, (int)N, npad, splits, ep, (int)mp);
+    if (slice_elems) { *slice_elems = mp * npad; *row_stride = npad; }
+    if (finalize) {
+        const int n_out = e->swiglu ? (int)(N / 2) : (int)N;
+        const int64_t items = (int64_t)M * ((n_out + 3) / 4);
+        skinny_finalize_k<<<dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st>>>((const float*)workspace, C, ldc, (int)M, (int)N, npad, splits, ep, (int)mp);
+    }
     LICV_LAUNCH_CHECK();
     return LICV_OK;
+}
+
+extern "C" int licv_gemm_bf16_splitk(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
+                                     int64_t M, int64_t N, int64_t K, const licv_gemm_epilogue* e, int splits,
+                                     void* workspace, int64_t workspace_bytes, void* stream) {
+    return splitk_run(A, lda, W, ldw, C, ldc, M, N, K, e, splits, workspace, workspace_bytes, stream, true, nullptr, nullptr);
+}
+
+// The producer half alone: `splits` fp32 slices of A W^T in the workspace, slice sp of row m at
+// workspace + sp * slice_elems + m * row_stride (floats); summed in slice order and rounded to bf16 they are the plain GEMM's output.
+extern "C" int licv_gemm_bf16_splitk_produce(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int64_t N, int64_t K,
+                                             int splits, void* workspace, int64_t workspace_bytes, int64_t* slice_elems,
+                                             int64_t* row_stride, void* stream) {
+    LICV_CHECK_ARG(slice_elems && row_stride, "gemm_bf16_splitk_produce: null pointer");
+    licv_gemm_epilogue e;
+    e.bias_bf16 = nullptr; e.row_gate = nullptr; e.residual = nullptr; e.residual_dtype = 0; e.ld_res = 0; e.act = 0; e.swiglu = 0;
+    e.use_scale = 0; e.scale = 0.f; e.out_dtype = LICV_BF16;
+    return splitk_run(A, lda, W, ldw, workspace, 4, M, N, K, &e, splits, workspace, workspace_bytes, stream, false, slice_elems, row_stride);
 }
 
 extern "C" int licv_gemm_fp8(const void* Aq, int64_t lda, const float* a_scale, const void* Wq, int64_t ldw, const float* w_scale,

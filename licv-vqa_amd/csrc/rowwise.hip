@@ -64,18 +64,59 @@ __device__ __forceinline__ void emit_row_fp8(const floatx4 (&y)[NCH], int dim, i
     }
 }
 
-template <int DT, int NCH, bool FUSE_NORM>
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK)
+// A branch that still lies in the workspace of a split-K GEMM (licv_gemm_bf16_splitk_produce): value (m, col) = bf16(slice 0 + slice 1 +
+// ... in slice order) — exactly what skinny_finalize_k would have written for a plain epilogue.  The WS forms of the row kernels below
+// run ONE ROW PER WORKGROUP (blockDim 256): all four waves sum the slices of the row into an LDS image of the bf16 branch (every load
+// of a thread in flight at once), then wave 0 alone runs the unchanged one-wave row algorithm with the image as its branch operand —
+// the same per-lane summation chains and the same butterfly, so the results are bit-identical to finalize + row kernel, one launch
+// instead of two (and no bf16 round trip of the branch through memory).
+struct WsSrc { const float* ws; int splits; int64_t slice; int64_t stride; };
+template <int NCH>
+__device__ __forceinline__ void ws_branch_to_lds(const WsSrc& s, int64_t row, int dim, bf16_t* img) {
+    constexpr int U = (NCH + 3) / 4;                                // 1024 columns per pass of the 256 threads
+    const float* p = s.ws + row * s.stride;
+    floatx4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int i = (u * 256 + (int)threadIdx.x) * 4, ii = i < dim ? i : 0;
+        v[u] = *reinterpret_cast<const floatx4*>(p + ii);
+    }
+    for (int sp = 1; sp < s.splits; ++sp) {
+        floatx4 t[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = (u * 256 + (int)threadIdx.x) * 4, ii = i < dim ? i : 0;
+            t[u] = *reinterpret_cast<const floatx4*>(p + (int64_t)sp * s.slice + ii);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] += t[u];                   // slice order, as the finalize kernel adds them
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int i = (u * 256 + (int)threadIdx.x) * 4;
+        if (i < dim) store4_bf16(img, i, v[u]);
+    }
+    __syncthreads();
+}
+
+template <int DT, int NCH, bool FUSE_NORM, bool WS = false>
+__global__ __launch_bounds__(WS ? 256 : 64 * WAVES_PER_BLOCK)
 void inject_renorm_fwd_k(const void* __restrict__ h, const float* __restrict__ icv, const float* __restrict__ alpha,
                          float* __restrict__ out, int64_t rows, int hidden,
                          const bf16_t* __restrict__ norm_w, bf16_t* __restrict__ xn, float eps,
                          const void* __restrict__ res, int res_dt, int norm_flavour, const bf16_t* __restrict__ pre = nullptr,
-                         Q8Out q8 = Q8Out{nullptr, nullptr}) {
+                         Q8Out q8 = Q8Out{nullptr, nullptr}, WsSrc wsrc = WsSrc{nullptr, 0, 0, 0}) {
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const int64_t row = WS ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const float a = alpha ? *alpha : 1.0f;
     const int64_t base = row * hidden;
+    __shared__ __attribute__((aligned(16))) bf16_t ws_img[WS ? NCH * 256 : 8];
+    if constexpr (WS) {                                    // `pre` = the branch summed from the split-K slices (see WsSrc)
+        ws_branch_to_lds<NCH>(wsrc, row, hidden, ws_img);
+        if (threadIdx.x >= 64) return;
+        pre = ws_img;
+    }
+    const float a = alpha ? *alpha : 1.0f;
     // Every load of a phase is issued before the first value is used: chunk indices past the row are clamped to the row's first
     // chunk and their values discarded by a select, not skipped by a branch.  (A guard `if (i < hidden) { load; use; }` per chunk
     // made each chunk its own basic block with a full vmcnt(0) wait: 16 dependent round trips per row — 11 us of the 12 a 24-row
@@ -90,7 +131,7 @@ void inject_renorm_fwd_k(const void* __restrict__ h, const float* __restrict__ i
     for (int c = 0; c < NCH; ++c) {
         const int i = (c * 64 + lane) * 4, ii = i < hidden ? i : 0;
         hvv[c] = RowIO<DT>::load4(h, base + ii);
-        bvv[c] = RowIO<LICV_BF16>::load4(pre_p, base + ii);
+        bvv[c] = RowIO<LICV_BF16>::load4(pre_p, (WS ? 0 : base) + ii);
         vvv[c] = *reinterpret_cast<const floatx4*>(icv + ii);
     }
 #pragma unroll
@@ -285,15 +326,21 @@ void rmsnorm_fwd_k(const void* __restrict__ x, const bf16_t* __restrict__ w, bf1
 
 // h += branch (in place, in the stream's dtype: a bf16 stream rounds the sum — the o-projection's residual epilogue, folded in here so
 // that GEMM writes its bf16 branch through the register-direct epilogue), then the RMSNorm of the new h.
-template <int DT, int NCH>
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK)
+template <int DT, int NCH, bool WS = false>
+__global__ __launch_bounds__(WS ? 256 : 64 * WAVES_PER_BLOCK)
 void add_rmsnorm_fwd_k(void* __restrict__ h, const bf16_t* __restrict__ branch, const bf16_t* __restrict__ w, bf16_t* __restrict__ out,
                        int64_t rows, int dim, float eps, int flavour, const float* __restrict__ row_gate, int use_scale, float scale,
-                       Q8Out q8 = Q8Out{nullptr, nullptr}) {
+                       Q8Out q8 = Q8Out{nullptr, nullptr}, WsSrc wsrc = WsSrc{nullptr, 0, 0, 0}) {
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const int64_t row = WS ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int64_t base = row * dim;
+    __shared__ __attribute__((aligned(16))) bf16_t ws_img[WS ? NCH * 256 : 8];
+    if constexpr (WS) {                                    // the branch summed from the split-K slices (see WsSrc)
+        ws_branch_to_lds<NCH>(wsrc, row, dim, ws_img);
+        if (threadIdx.x >= 64) return;
+        branch = ws_img;
+    }
     const bool closed = row_gate && row_gate[row] == 0.0f;           // gated cross-attention: a token that attends no image adds nothing
     floatx4 v[NCH], bvv[NCH], wv[NCH];                             // all loads first, no per-chunk branch (see inject_renorm_fwd_k)
     float ss = 0.f;
@@ -301,7 +348,7 @@ void add_rmsnorm_fwd_k(void* __restrict__ h, const bf16_t* __restrict__ branch, 
     for (int c = 0; c < NCH; ++c) {
         const int i = (c * 64 + lane) * 4, ii = i < dim ? i : 0;
         v[c] = RowIO<DT>::load4(h, base + ii);
-        bvv[c] = RowIO<LICV_BF16>::load4(branch, base + ii);
+        bvv[c] = RowIO<LICV_BF16>::load4(branch, (WS ? 0 : base) + ii);
         wv[c] = RowIO<LICV_BF16>::load4(w, ii);
     }
 #pragma unroll
@@ -718,6 +765,57 @@ void rotary_kv_append_k(bf16_t* __restrict__ qkv, const bf16_t* __restrict__ cos
     for (int64_t i = threadIdx.x; i < H / 8; i += blockDim.x) vdst[i] = vsrc[i];
 }
 
+// The same from the split-K slices of the QKV projection (see WsSrc): q / k / v = bf16(sum of the slices), rotated Q written to `qkv`
+// (the attention kernel's Q operand), K and V straight into the cache — the projection's finalize launch and the bf16 round trip of
+// its output are gone.  One thread per item (a 4 + 4 element rotary pair, or 4 V elements): grid (rows, ceil(3 * n_heads * head_dim / 8 / 256)).
+__global__ __launch_bounds__(256)
+void rotary_kv_append_ws_k(WsSrc src, bf16_t* __restrict__ qkv, const bf16_t* __restrict__ cosT, const bf16_t* __restrict__ sinT,
+                           const int64_t* __restrict__ pos, int64_t S, int n_heads, int head_dim, int64_t H, int64_t n_pos,
+                           bf16_t* __restrict__ cache, int64_t max_len, int64_t past) {
+    const int64_t row = blockIdx.x;                       // b * S + s
+    const int64_t b = row / S, sq = row - b * S;
+    const int half = head_dim >> 1, qper = half >> 2;
+    const int n_rot = 2 * n_heads * qper, n_v = (int)(H >> 2);
+    const int idx = blockIdx.y * 256 + threadIdx.x;
+    if (idx >= n_rot + n_v) return;
+    bf16_t* crow = cache + (b * max_len + past + sq) * 2 * H;
+    const float* wrow = src.ws + row * src.stride;
+    auto sum4 = [&](int64_t col) -> floatx4 {
+        floatx4 v = *reinterpret_cast<const floatx4*>(wrow + col);
+        for (int sp = 1; sp < src.splits; ++sp) v += *reinterpret_cast<const floatx4*>(wrow + (int64_t)sp * src.slice + col);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = rbf(v[j]);
+        return v;
+    };
+    if (idx >= n_rot) {                                   // V: copy
+        const int64_t i = (int64_t)(idx - n_rot) * 4;
+        store4_bf16(crow + H, i, sum4(2 * H + i));
+        return;
+    }
+    int64_t p = pos[row];
+    p = p < 0 ? 0 : (p >= n_pos ? n_pos - 1 : p);
+    const int g = idx % qper, hd = (idx / qper) % n_heads, t = idx / (qper * n_heads);
+    const int i = g * 4;
+    const int64_t col = t * H + (int64_t)hd * head_dim;
+    floatx4 lo = *reinterpret_cast<const floatx4*>(wrow + col + i), hi = *reinterpret_cast<const floatx4*>(wrow + col + i + half);
+    for (int sp = 1; sp < src.splits; ++sp) {
+        lo += *reinterpret_cast<const floatx4*>(wrow + (int64_t)sp * src.slice + col + i);
+        hi += *reinterpret_cast<const floatx4*>(wrow + (int64_t)sp * src.slice + col + i + half);
+    }
+    const floatx4 c = RowIO<LICV_BF16>::load4(cosT, p * head_dim + i);
+    const floatx4 s = RowIO<LICV_BF16>::load4(sinT, p * head_dim + i);
+    floatx4 olo, ohi;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float l = rbf(lo[j]), h = rbf(hi[j]);
+        olo[j] = rbf(l * c[j]) + rbf(-h * s[j]);
+        ohi[j] = rbf(h * c[j]) + rbf(l * s[j]);
+    }
+    bf16_t* dst = t == 0 ? qkv + row * 3 * H + (int64_t)hd * head_dim : crow + (int64_t)hd * head_dim;
+    store4_bf16(dst, i, olo);
+    store4_bf16(dst, i + half, ohi);
+}
+
 // ------------------------------------------------------------------------------------------------
 // gathers / layout
 // ------------------------------------------------------------------------------------------------
@@ -875,6 +973,33 @@ static int inject_fwd_impl(const void* h, int h_dtype, const float* icv_row, con
     return LICV_OK;
 }
 
+// ... with the branch still in the workspace of its split-K GEMM (licv_gemm_bf16_splitk_produce): see WsSrc.  One workgroup per row.
+static int check_ws(const char* who, const float* ws, int splits, int64_t slice_elems, int64_t row_stride, int64_t dim) {
+    LICV_CHECK_ARG(ws && splits >= 1 && slice_elems > 0 && row_stride >= dim, "%s: bad split-K workspace description", who);
+    LICV_CHECK_ARG(((uintptr_t)ws & 15) == 0 && slice_elems % 4 == 0 && row_stride % 4 == 0, "%s: workspace slices must be 16-byte aligned", who);
+    return LICV_OK;
+}
+extern "C" int licv_inject_renorm_pre_fwd_ws(const void* h, int h_dtype, const float* ws, int splits, int64_t slice_elems, int64_t row_stride,
+                                             const float* icv_row, const float* alpha, float* out, int64_t rows, int64_t hidden,
+                                             const void* norm_w, void* xn_out, float norm_eps, void* stream) {
+    LICV_CHECK_ARG(h && icv_row && out && norm_w && xn_out, "inject_renorm_pre_fwd_ws: null pointer");
+    LICV_CHECK_ARG(hidden > 0 && hidden % 4 == 0, "inject_renorm_pre_fwd_ws: hidden (%lld) must be a positive multiple of 4", (long long)hidden);
+    LICV_CHECK_ARG(h_dtype == LICV_BF16 || h_dtype == LICV_F32, "inject_renorm_pre_fwd_ws: bad dtype %d", h_dtype);
+    { const int rc = check_ws("inject_renorm_pre_fwd_ws", ws, splits, slice_elems, row_stride, hidden); if (rc != LICV_OK) return rc; }
+    if (rows <= 0) return LICV_OK;
+    const int64_t dim_ = hidden;
+    const int nch = pick_nch(hidden);
+    LICV_CHECK_ARG(nch > 0, "inject_renorm_pre_fwd_ws: hidden %lld unsupported", (long long)hidden);
+    hipStream_t st = (hipStream_t)stream;
+    const WsSrc src{ws, splits, slice_elems, row_stride};
+#define LAUNCH_INJW(DTV) inject_renorm_fwd_k<DTV, N, true, true><<<dim3((unsigned)rows), dim3(256), 0, st>>>( \
+        h, icv_row, alpha, out, rows, (int)hidden, (const bf16_t*)norm_w, (bf16_t*)xn_out, norm_eps, nullptr, 0, 0, nullptr, Q8Out{nullptr, nullptr}, src)
+    if (h_dtype == LICV_F32) { DISPATCH_NCH(nch, LAUNCH_INJW(LICV_F32)); } else { DISPATCH_NCH(nch, LAUNCH_INJW(LICV_BF16)); }
+#undef LAUNCH_INJW
+    LICV_LAUNCH_CHECK();
+    return LICV_OK;
+}
+
 static inline int bwd_blocks(int64_t rows) { int b = row_blocks(rows); return b > 128 ? 128 : (b < 1 ? 1 : b); }
 extern "C" int64_t licv_inject_bwd_partials(int64_t rows) { return (int64_t)bwd_blocks(rows) * WAVES_PER_BLOCK; }
 
@@ -942,6 +1067,28 @@ extern "C" int licv_add_rmsnorm_fwd(void* h, int h_dtype, const void* branch_bf1
 }
 
 // ---- norms that also (or only: out may be NULL) write the fp8 image of their rows; contiguous rows of `dim` elements
+extern "C" int licv_add_rmsnorm_fwd_ws(void* h, int h_dtype, const float* ws, int splits, int64_t slice_elems, int64_t row_stride,
+                                       const float* row_gate, int use_scale, float scale, const void* w, void* out,
+                                       int64_t rows, int64_t dim, float eps, int flavour, void* stream) {
+    LICV_CHECK_ARG(h && w && out, "add_rmsnorm_fwd_ws: null pointer");
+    LICV_CHECK_ARG(dim > 0 && dim % 4 == 0, "add_rmsnorm_fwd_ws: dim (%lld) must be a multiple of 4", (long long)dim);
+    LICV_CHECK_ARG(h_dtype == LICV_BF16 || h_dtype == LICV_F32, "add_rmsnorm_fwd_ws: bad dtype %d", h_dtype);
+    LICV_CHECK_ARG(flavour == 0 || flavour == 1, "add_rmsnorm_fwd_ws: bad flavour %d", flavour);
+    { const int rc = check_ws("add_rmsnorm_fwd_ws", ws, splits, slice_elems, row_stride, dim); if (rc != LICV_OK) return rc; }
+    if (rows <= 0) return LICV_OK;
+    const int64_t dim_ = dim;
+    const int nch = pick_nch(dim);
+    LICV_CHECK_ARG(nch > 0, "add_rmsnorm_fwd_ws: dim %lld unsupported", (long long)dim);
+    hipStream_t st = (hipStream_t)stream;
+    const WsSrc src{ws, splits, slice_elems, row_stride};
+#define LAUNCH_ARMSW(DTV) add_rmsnorm_fwd_k<DTV, N, true><<<dim3((unsigned)rows), dim3(256), 0, st>>>(h, nullptr, (const bf16_t*)w, (bf16_t*)out, rows, (int)dim, eps, flavour, \
+        row_gate, use_scale, scale, Q8Out{nullptr, nullptr}, src)
+    if (h_dtype == LICV_F32) { DISPATCH_NCH(nch, LAUNCH_ARMSW(LICV_F32)); } else { DISPATCH_NCH(nch, LAUNCH_ARMSW(LICV_BF16)); }
+#undef LAUNCH_ARMSW
+    LICV_LAUNCH_CHECK();
+    return LICV_OK;
+}
+
 extern "C" int licv_rmsnorm_fwd_q8(const void* x, int x_dtype, const void* w, void* out, void* q_fp8, float* q_scale, int64_t rows, int64_t dim,
                                    float eps, int flavour, void* stream) {
     LICV_CHECK_ARG(x && w && q_fp8 && q_scale, "rmsnorm_fwd_q8: null pointer");
@@ -1100,6 +1247,25 @@ extern "C" int licv_rotary_kv_append(void* qkv, const void* cosT, const void* si
     if (batch <= 0) return LICV_OK;
     rotary_kv_append_k<<<(unsigned)(batch * S), 256, 0, (hipStream_t)stream>>>((bf16_t*)qkv, (const bf16_t*)cosT, (const bf16_t*)sinT,
         position_ids, S, (int)n_heads, (int)head_dim, n_heads * head_dim, n_pos, (bf16_t*)cache, cache_max_len, past);
+    LICV_LAUNCH_CHECK();
+    return LICV_OK;
+}
+
+extern "C" int licv_rotary_kv_append_ws(const float* ws, int splits, int64_t slice_elems, int64_t row_stride, void* qkv,
+                                        const void* cosT, const void* sinT, const int64_t* position_ids, int64_t batch, int64_t S,
+                                        int64_t n_heads, int64_t head_dim, int64_t n_pos, void* cache, int64_t cache_max_len, int64_t past,
+                                        void* stream) {
+    LICV_CHECK_ARG(qkv && cosT && sinT && position_ids && cache, "rotary_kv_append_ws: null pointer");
+    LICV_CHECK_ARG(head_dim > 0 && head_dim % 8 == 0 && n_heads > 0 && n_pos > 0, "rotary_kv_append_ws: head_dim (%lld) must be a multiple of 8", (long long)head_dim);
+    LICV_CHECK_ARG(past >= 0 && S > 0 && past + S <= cache_max_len, "rotary_kv_append_ws: %lld + %lld tokens do not fit a cache of %lld", (long long)past, (long long)S, (long long)cache_max_len);
+    LICV_CHECK_ARG(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)cache & 15) == 0, "rotary_kv_append_ws: misaligned pointer");
+    const int64_t H = n_heads * head_dim;
+    { const int rc = check_ws("rotary_kv_append_ws", ws, splits, slice_elems, row_stride, 3 * H); if (rc != LICV_OK) return rc; }
+    if (batch <= 0) return LICV_OK;
+    const int64_t items = 2 * n_heads * (head_dim / 8) + H / 4;
+    rotary_kv_append_ws_k<<<dim3((unsigned)(batch * S), (unsigned)((items + 255) / 256)), 256, 0, (hipStream_t)stream>>>(
+        WsSrc{ws, splits, slice_elems, row_stride}, (bf16_t*)qkv, (const bf16_t*)cosT, (const bf16_t*)sinT,
+        position_ids, S, (int)n_heads, (int)head_dim, H, n_pos, (bf16_t*)cache, cache_max_len, past);
     LICV_LAUNCH_CHECK();
     return LICV_OK;
 }

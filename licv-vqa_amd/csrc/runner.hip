@@ -35,12 +35,33 @@ int linear(const Ctx& x, const void* A, int64_t M, const void* W, int64_t N, int
     }
     return licv_gemm_bf16(A, K, W, K, C, ldc, M, N, K, &ep, x.stream);
 }
+
+// A projection whose bf16 output (a branch, or the fused Q|K|V rows) is consumed by a row kernel.  Where the plan splits K and the
+// option allows it, only the producer half runs and the slices stay in the workspace for that row kernel to sum (`src.ws` set);
+// otherwise the GEMM writes C as usual.  The workspace is free again once the consumer has run — before the next GEMM on the stream.
+struct Slices { const float* ws = nullptr; int splits = 0; int64_t slice = 0, stride = 0; };
+int g_sum_in_rows = 1;
+int linear_to_rows(const Ctx& x, const void* A, int64_t M, const void* W, int64_t N, int64_t K, void* C, Slices* src) {
+    *src = Slices{};
+    int splits = 1; int64_t ws = 0;
+    RUN(licv_gemm_splitk_plan(M, N, K, &splits, &ws));
+    if (splits > 1 && g_sum_in_rows) {
+        if (ws > x.c->workspace_bytes) return licv_set_error(LICV_E_BADARG, "idefics_text_forward: workspace %lld B < %lld B needed by a %lld x %lld x %lld split-K GEMM",
+                                                             (long long)x.c->workspace_bytes, (long long)ws, (long long)M, (long long)N, (long long)K);
+        RUN(licv_gemm_bf16_splitk_produce(A, K, W, K, M, N, K, splits, x.c->workspace, x.c->workspace_bytes, &src->slice, &src->stride, x.stream));
+        src->ws = (const float*)x.c->workspace; src->splits = splits;
+        return LICV_OK;
+    }
+    return linear(x, A, M, W, N, K, C, N, LICV_BF16);
+}
 }  // namespace
 
 static int g_fold_residual = 1;
 // option 0: fold the decoder layers' residual adds into the row kernels that follow them (default 1; 0 for A/B timing)
+// option 1: at M < 512, split-K projections leave their slices for the row kernel behind them to sum (default 1; 0 for A/B timing)
 extern "C" int licv_runner_option(int option, int value) {
     if (option == 0) { g_fold_residual = value; return LICV_OK; }
+    if (option == 1) { g_sum_in_rows = value; return LICV_OK; }
     return licv_set_error(LICV_E_BADARG, "runner_option: unknown option %d", option);
 }
 
@@ -61,7 +82,8 @@ extern "C" int licv_idefics_text_forward(const licv_idefics_text_weights* w, con
 
     RUN(licv_embed_gather(c->input_ids, w->embed, w->embed_extra, c->h16, M, H, w->vocab, w->n_extra_vocab, stream));
     bool xn_valid = false;                                 // c->xn holds RMSNorm(h) for the next block (made by the fused hook kernel)
-    bool pending = false; float pending_scale = 0.f;       // a cross layer's MLP branch waits in c->q for the next norm to add it
+    bool pending = false; float pending_scale = 0.f;       // a cross layer's MLP branch waits in c->q (or as split-K slices) for the next norm to add it
+    Slices pending_src;
     auto next_norm = [&](int64_t l) -> const void* {
         if (l + 1 >= w->n_layers) return w->final_ln;
         if ((l + 1) % w->cross_interval == 0) return w->xat[(l + 1) / w->cross_interval].in_ln;
@@ -89,11 +111,13 @@ extern "C" int licv_idefics_text_forward(const licv_idefics_text_weights* w, con
             a.o = c->o; a.B = B; a.Sq = S; a.Sk = Nk; a.n_heads = nh; a.n_kv_heads = nh; a.head_dim = hd;
             a.scale = att_scale; a.mask_mode = 3; a.key_valid = nullptr; a.img_mask = c->img_mask; a.n_img = c->n_img; a.img_len = w->img_len;
             RUN(licv_attn_fwd(&a, stream));
-            if (M >= 512 && g_fold_residual) {             // both gated residual adds folded into the norms that follow (see below)
-                RUN(linear(x, c->o, M, X.o_w, H, H, c->q, H, LICV_BF16));
-                RUN(licv_add_rmsnorm_fwd(x.h, x.h_dt, c->q, c->gate, 1, X.gate_attn, X.post_ln, c->x, M, H, w->rms_eps, 0, stream));
+            if (g_fold_residual) {                         // both gated residual adds folded into the norms that follow (see below)
+                Slices os;
+                RUN(linear_to_rows(x, c->o, M, X.o_w, H, H, c->q, &os));
+                if (os.ws) RUN(licv_add_rmsnorm_fwd_ws(x.h, x.h_dt, os.ws, os.splits, os.slice, os.stride, c->gate, 1, X.gate_attn, X.post_ln, c->x, M, H, w->rms_eps, 0, stream));
+                else RUN(licv_add_rmsnorm_fwd(x.h, x.h_dt, c->q, c->gate, 1, X.gate_attn, X.post_ln, c->x, M, H, w->rms_eps, 0, stream));
                 RUN(linear(x, c->x, M, X.gu_w, 2 * I, H, c->act, I, LICV_BF16, nullptr, 0, nullptr, nullptr, 1));
-                RUN(linear(x, c->act, M, X.down_w, H, I, c->q, H, LICV_BF16));
+                RUN(linear_to_rows(x, c->act, M, X.down_w, H, I, c->q, &pending_src));
                 pending_scale = X.gate_dense; pending = true;     // added by the decoder layer's input norm
             } else {
                 RUN(linear(x, c->o, M, X.o_w, H, H, x.h, H, x.h_dt, x.h, x.h_dt, c->gate, &X.gate_attn));
@@ -105,11 +129,15 @@ extern "C" int licv_idefics_text_forward(const licv_idefics_text_weights* w, con
         const licv_idefics_dec_w& D = w->dec[l];           // decoder layer (hf:idefics/modeling_idefics.py:645-675), hooked on its output
         const void* xin = c->xn;
         if (pending) {                                     // the cross layer's MLP branch (in c->q): h += bf16(gate_dense * branch), then the input norm
-            RUN(licv_add_rmsnorm_fwd(x.h, x.h_dt, c->q, nullptr, 1, pending_scale, D.in_ln, c->x, M, H, w->rms_eps, 0, stream));
+            if (pending_src.ws) RUN(licv_add_rmsnorm_fwd_ws(x.h, x.h_dt, pending_src.ws, pending_src.splits, pending_src.slice, pending_src.stride, nullptr, 1, pending_scale,
+                                                            D.in_ln, c->x, M, H, w->rms_eps, 0, stream));
+            else RUN(licv_add_rmsnorm_fwd(x.h, x.h_dt, c->q, nullptr, 1, pending_scale, D.in_ln, c->x, M, H, w->rms_eps, 0, stream));
             xin = c->x; pending = false;
         } else if (!xn_valid) { RUN(licv_rmsnorm_fwd(x.h, x.h_dt, D.in_ln, c->x, M, H, 1, H, H, w->rms_eps, 0, stream)); xin = c->x; }
         xn_valid = false;
-        RUN(linear(x, xin, M, D.qkv_w, 3 * H, H, c->qkv, 3 * H, LICV_BF16));
+        Slices qs;                                         // decode steps: the QKV slices go straight into rotary + cache append
+        if (c->kv_cache && M < 512) RUN(linear_to_rows(x, xin, M, D.qkv_w, 3 * H, H, c->qkv, &qs));
+        else RUN(linear(x, xin, M, D.qkv_w, 3 * H, H, c->qkv, 3 * H, LICV_BF16));
         if (!c->kv_cache) RUN(licv_rotary_fwd(c->qkv, w->cos, w->sin, c->position_ids, M, nh, hd, 3 * H, H, 2, w->rope_len, stream));
         licv_attn_args a;
         a.q = c->qkv; a.q_bs = S * 3 * H; a.q_rs = 3 * H;
@@ -120,7 +148,9 @@ extern "C" int licv_idefics_text_forward(const licv_idefics_text_weights* w, con
         } else {
             void* cache = c->kv_cache[l];
             // rotary (Q in place, K on its way into the cache) and the append in one launch
-            RUN(licv_rotary_kv_append(c->qkv, w->cos, w->sin, c->position_ids, B, S, nh, hd, w->rope_len, cache, c->cache_max_len, c->past, stream));
+            if (qs.ws) RUN(licv_rotary_kv_append_ws(qs.ws, qs.splits, qs.slice, qs.stride, c->qkv, w->cos, w->sin, c->position_ids, B, S, nh, hd, w->rope_len,
+                                                    cache, c->cache_max_len, c->past, stream));
+            else RUN(licv_rotary_kv_append(c->qkv, w->cos, w->sin, c->position_ids, B, S, nh, hd, w->rope_len, cache, c->cache_max_len, c->past, stream));
             a.k = cache; a.v = (const char*)cache + H * 2; a.kv_bs = c->cache_max_len * 2 * H; a.kv_rs = 2 * H; a.Sk = c->Sk;
         }
         RUN(licv_attn_fwd(&a, stream));
@@ -133,8 +163,10 @@ extern "C" int licv_idefics_text_forward(const licv_idefics_text_weights* w, con
             RUN(linear(x, c->o, M, D.o_w, H, H, c->q, H, LICV_BF16));
             RUN(licv_add_rmsnorm_fwd(x.h, x.h_dt, c->q, nullptr, 0, 0.f, D.post_ln, c->x, M, H, w->rms_eps, 0, stream));
         } else {
-            RUN(linear(x, c->o, M, D.o_w, H, H, x.h, H, x.h_dt, x.h, x.h_dt));
-            RUN(licv_rmsnorm_fwd(x.h, x.h_dt, D.post_ln, c->x, M, H, 1, H, H, w->rms_eps, 0, stream));
+            Slices os;
+            RUN(linear_to_rows(x, c->o, M, D.o_w, H, H, c->q, &os));
+            if (os.ws) RUN(licv_add_rmsnorm_fwd_ws(x.h, x.h_dt, os.ws, os.splits, os.slice, os.stride, nullptr, 0, 0.f, D.post_ln, c->x, M, H, w->rms_eps, 0, stream));
+            else RUN(licv_add_rmsnorm_fwd(x.h, x.h_dt, c->q, nullptr, 0, 0.f, D.post_ln, c->x, M, H, w->rms_eps, 0, stream));
         }
         RUN(linear(x, c->x, M, D.gu_w, 2 * I, H, c->act, I, LICV_BF16, nullptr, 0, nullptr, nullptr, 1));
         if (fold && slot >= 0) {
@@ -145,12 +177,17 @@ extern "C" int licv_idefics_text_forward(const licv_idefics_text_weights* w, con
             xn_valid = true;
             continue;
         }
-        RUN(linear(x, c->act, M, D.down_w, H, I, x.h, H, x.h_dt, x.h, x.h_dt));
         if (slot >= 0) {                                   // the hook (ref:icv_src/icv_model/icv_intervention.py:61-86) fused with the next RMSNorm
-            RUN(licv_inject_renorm_fwd(x.h, x.h_dt, c->icv + (int64_t)slot * H, c->alpha ? c->alpha + slot : nullptr, (float*)c->h32, M, H,
-                                       next_norm(l), c->xn, w->rms_eps, stream));
+            Slices ds;
+            RUN(linear_to_rows(x, c->act, M, D.down_w, H, I, c->q, &ds));
+            if (ds.ws) RUN(licv_inject_renorm_pre_fwd_ws(x.h, x.h_dt, ds.ws, ds.splits, ds.slice, ds.stride, c->icv + (int64_t)slot * H,
+                                                         c->alpha ? c->alpha + slot : nullptr, (float*)c->h32, M, H, next_norm(l), c->xn, w->rms_eps, stream));
+            else RUN(licv_inject_renorm_pre_fwd(x.h, x.h_dt, c->q, c->icv + (int64_t)slot * H, c->alpha ? c->alpha + slot : nullptr, (float*)c->h32, M, H,
+                                                next_norm(l), c->xn, w->rms_eps, stream));
             x.h = c->h32; x.h_dt = LICV_F32;               // the fp32 ICV promotes the stream
             xn_valid = true;
+        } else {
+            RUN(linear(x, c->act, M, D.down_w, H, I, x.h, H, x.h_dt, x.h, x.h_dt));
         }
     }
     const void* xf = c->xn;

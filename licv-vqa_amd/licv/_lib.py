@@ -85,6 +85,10 @@ def lib() -> C.CDLL:
             "licv_gemm_fp8": [P, I64, P, P, I64, P, P, I64, I64, I64, I64, P, P],
             "licv_gemm_splitk_plan": [I64, I64, I64, P, P],
             "licv_gemm_bf16_splitk": [P, I64, P, I64, P, I64, I64, I64, I64, P, I, P, I64, P],
+            "licv_gemm_bf16_splitk_produce": [P, I64, P, I64, I64, I64, I64, I, P, I64, P, P, P],
+            "licv_add_rmsnorm_fwd_ws": [P, I, P, I, I64, I64, P, I, F, P, P, I64, I64, F, I, P],
+            "licv_inject_renorm_pre_fwd_ws": [P, I, P, I, I64, I64, P, P, P, I64, I64, P, P, F, P],
+            "licv_rotary_kv_append_ws": [P, I, I64, I64, P, P, P, P, I64, I64, I64, I64, I64, P, I64, I64, P],
             "licv_probe_mfma_loop": [P, I, I, P],
             "licv_probe_permlane16_swap": [P, P],
             "licv_probe_weight_stream": [P, I64, I64, I64, I, I, I, P, P],

@@ -256,6 +256,76 @@ def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     return out if ret is None else ret
 
 
+class Slices:
+    """The fp32 split-K slices of a plain projection, left in the workspace for the row kernel behind it (licv_gemm_bf16_splitk_produce)."""
+    def __init__(self, ws, splits, slice_elems, row_stride, rows, cols):
+        self.ws, self.splits, self.slice_elems, self.row_stride, self.rows, self.cols = ws, splits, slice_elems, row_stride, rows, cols
+
+    def args(self):
+        return _p(self.ws), self.splits, self.slice_elems, self.row_stride
+
+
+def linear_produce(a: torch.Tensor, w: torch.Tensor) -> Optional[Slices]:
+    """The producer half of the split-K form of a @ w.T (None when the plan does not split the shape): the consumer — add_rmsnorm_ws_,
+    inject_renorm_ws, rotary_kv_append — sums the slices itself, bit for bit what linear() would have written as bf16."""
+    assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and w.is_contiguous() and a.is_contiguous()
+    N, K = w.shape
+    M = a.numel() // K
+    splits, ws_bytes = _splitk_plan(M, N, K) if SPLITK else (1, 0)
+    if splits <= 1:
+        return None
+    ws = _workspace(a.device, ws_bytes)
+    se, rs = C.c_int64(0), C.c_int64(0)
+    _timed("gemm", 2.0 * M * N * K, lambda: check(_lib.lib().licv_gemm_bf16_splitk_produce(
+        _p(a), K, _p(w), K, M, N, K, splits, _p(ws), ws.numel(), C.byref(se), C.byref(rs), _stream(a))), label=(M, N, K))
+    return Slices(ws, splits, se.value, rs.value, M, N)
+
+
+def add_rmsnorm_ws_(h: torch.Tensor, branch: Slices, w: torch.Tensor, eps: float, flavour: int = 0,
+                    row_gate: Optional[torch.Tensor] = None, scale: Optional[float] = None) -> torch.Tensor:
+    """add_rmsnorm_ with the branch still in split-K slices."""
+    dim = h.shape[-1]
+    rows = h.numel() // dim
+    assert h.is_contiguous() and branch.rows == rows and branch.cols == dim
+    _bf16c(w, "w")
+    out = torch.empty(h.shape, dtype=torch.bfloat16, device=h.device)
+    check(_lib.lib().licv_add_rmsnorm_fwd_ws(_p(h), _dt(h), *branch.args(), _p(row_gate), 0 if scale is None else 1,
+                                             0.0 if scale is None else float(scale), _p(w), _p(out), rows, dim, float(eps), flavour, _stream(h)))
+    return out
+
+
+def inject_renorm_ws(h: torch.Tensor, pre: Slices, icv_row: torch.Tensor, alpha: Optional[torch.Tensor], norm_weight: torch.Tensor,
+                     norm_eps: float = 1e-6, out: Optional[torch.Tensor] = None):
+    """inject_renorm(h, ..., pre=branch) with the branch still in split-K slices; returns (fp32 h', bf16 RMSNorm(h'))."""
+    H = h.shape[-1]
+    rows = h.numel() // H
+    assert h.is_contiguous() and icv_row.dtype == torch.float32 and icv_row.numel() == H and pre.rows == rows and pre.cols == H
+    _bf16c(norm_weight, "norm_weight")
+    if out is None:
+        out = torch.empty(h.shape, dtype=torch.float32, device=h.device)
+    xn = torch.empty(h.shape, dtype=torch.bfloat16, device=h.device)
+    check(_lib.lib().licv_inject_renorm_pre_fwd_ws(_p(h), _dt(h), *pre.args(), _p(icv_row), _p(alpha), _p(out), rows, H,
+                                                   _p(norm_weight), _p(xn), float(norm_eps), _stream(h)))
+    return out, xn
+
+
+def rotary_kv_append(qkv, cos: torch.Tensor, sin: torch.Tensor, position_ids: torch.Tensor, batch: int, S: int, n_heads: int,
+                     head_dim: int, cache: torch.Tensor, past: int, q_out: Optional[torch.Tensor] = None):
+    """Rotary on the Q | K heads of a fused QKV projection and the append of K | V to cache (batch, max_len, 2H) at `past`.
+    qkv: the (batch * S, 3H) bf16 rows (Q rotated in place), or the projection's split-K Slices (rotated Q written to q_out[:, :H])."""
+    H = n_heads * head_dim
+    assert cache.dtype == torch.bfloat16 and cache.is_contiguous() and cache.shape[0] == batch and cache.shape[2] == 2 * H
+    if isinstance(qkv, Slices):
+        assert q_out is not None and q_out.dtype == torch.bfloat16 and q_out.is_contiguous() and q_out.numel() == batch * S * 3 * H
+        check(_lib.lib().licv_rotary_kv_append_ws(*qkv.args(), _p(q_out), _p(cos), _p(sin), _p(position_ids), batch, S, n_heads, head_dim,
+                                                  cos.shape[0], _p(cache), cache.shape[1], past, _stream(cache)))
+        return q_out
+    assert qkv.dtype == torch.bfloat16 and qkv.is_contiguous() and qkv.numel() == batch * S * 3 * H
+    check(_lib.lib().licv_rotary_kv_append(_p(qkv), _p(cos), _p(sin), _p(position_ids), batch, S, n_heads, head_dim,
+                                           cos.shape[0], _p(cache), cache.shape[1], past, _stream(cache)))
+    return qkv
+
+
 def quantize_fp8(x: torch.Tensor):
     """Per-row dynamic quantisation to OCP e4m3: returns (q uint8 (rows, K), scale fp32 (rows,))."""
     assert x.dim() == 2 and x.stride(1) == 1

@@ -785,3 +785,56 @@ def test_gelu_epilogue_rounds_like_the_exact_function_on_every_bf16_input():
     assert int((~same & near).sum()) <= 2, vals[~same & near].tolist()
     assert float((got.float() - ref.float())[near].abs().max()) <= 2.0 ** -7          # (the few misses are one ulp off)
     assert float(got[~near].float().abs().max()) <= 2.5e-10
+
+
+@pytest.mark.parametrize("M,N,K", [(24, 4096, 4096), (24, 4096, 11008), (8, 4096, 4096), (256, 4096, 4096), (256, 4096, 11008),
+                                   (32, 1024, 2048), (3, 256, 352), (24, 8192, 1024)])
+def test_row_kernels_sum_split_k_slices_like_the_finalize_kernel(M, N, K):
+    """Decode steps / the 32-token student pass: the o and down projections leave their split-K slices in the workspace and the row
+    kernel behind them (residual add + RMSNorm; residual add + hook + next RMSNorm) sums them — bit for bit finalize + the plain kernel."""
+    from licv import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(torch.bfloat16).to(DEV)
+    wn = (1 + 0.1 * torch.randn(N, generator=g)).to(torch.bfloat16).to(DEV)
+    icv = (torch.randn(N, generator=g) * 0.1).to(DEV)
+    alpha = torch.tensor([0.6], device=DEV)
+    gate = (torch.rand(M, generator=g) > 0.3).float().to(DEV)
+    branch = ops.linear(a, w)
+    assert ops.linear_produce(a, w) is not None, "the plan must split this shape"
+    for dt in (torch.bfloat16, torch.float32):
+        h = (torch.randn(M, N, generator=g) * 2).to(dt).to(DEV)
+        for kw in ({}, dict(row_gate=gate, scale=0.37)):
+            h1, h2 = h.clone(), h.clone()
+            x1 = ops.add_rmsnorm_(h1, branch, wn, 1e-6, **kw)
+            x2 = ops.add_rmsnorm_ws_(h2, ops.linear_produce(a, w), wn, 1e-6, **kw)
+            assert torch.equal(h1, h2) and torch.equal(x1, x2), (dt, kw)
+        for al in (None, alpha):
+            o1, n1 = ops.inject_renorm(h, icv, al, norm_weight=wn, norm_eps=1e-6, pre=branch)
+            o2, n2 = ops.inject_renorm_ws(h, ops.linear_produce(a, w), icv, al, wn, 1e-6)
+            assert torch.equal(o1, o2) and torch.equal(n1, n2), (dt, al)
+
+
+@pytest.mark.parametrize("B,S,nh,hd,K", [(8, 3, 8, 128, 2048), (24, 1, 32, 128, 4096), (2, 1, 2, 128, 256), (1, 5, 4, 64, 512)])
+def test_rotary_and_cache_append_from_split_k_slices(B, S, nh, hd, K):
+    """The decode step's fused QKV projection: rotary on Q | K and the K | V append read the split-K slices directly."""
+    from licv import ops
+    H = nh * hd
+    M = B * S
+    g = torch.Generator().manual_seed(B * 100 + S)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(3 * H, K, generator=g) * K ** -0.5).to(torch.bfloat16).to(DEV)
+    n_pos, max_len, past = 64, 16, 7
+    ang = torch.rand(n_pos, hd, generator=g) * 6.28
+    cos, sin = ang.cos().to(torch.bfloat16).to(DEV), ang.sin().to(torch.bfloat16).to(DEV)
+    pos = torch.randint(0, n_pos, (M,), generator=g).to(DEV)
+    qkv = ops.linear(a, w)
+    sl = ops.linear_produce(a, w)
+    assert sl is not None
+    c1 = torch.zeros(B, max_len, 2 * H, dtype=torch.bfloat16, device=DEV)
+    c2 = torch.zeros_like(c1)
+    q1 = ops.rotary_kv_append(qkv.clone(), cos, sin, pos, B, S, nh, hd, c1, past)
+    q2 = ops.rotary_kv_append(sl, cos, sin, pos, B, S, nh, hd, c2, past, q_out=torch.zeros_like(qkv))
+    assert torch.equal(c1, c2)
+    assert torch.equal(q1[:, :H], q2[:, :H]) and not q2[:, H:].any()
+    assert c1[:, past:past + S].abs().sum() > 0 and not c1[:, :past].any() and not c1[:, past + S:].any()

@@ -1,15 +1,17 @@
 #!/usr/bin/env python3
-"""Reduce the rocprofv3 counter CSVs of tools/attn_pmc.sh to one table: per-launch average of every counter for attn_resident_k."""
+"""Reduce the rocprofv3 counter CSVs of tools/attn_pmc.sh / tools/mid_pmc.sh to one table: per-launch average of every counter for one
+kernel (argv[2]: a substring of its name, default attn_resident_k)."""
 import csv
 import glob
 import sys
 from collections import defaultdict
 
 out = sys.argv[1]
+KERNEL = sys.argv[2] if len(sys.argv) > 2 else "attn_resident_k"
 acc, cnt = defaultdict(float), defaultdict(int)
 for f in sorted(glob.glob(f"{out}/p*/**/*counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(f)):
-        if "attn_resident_k" not in r["Kernel_Name"]:
+        if KERNEL not in r["Kernel_Name"]:
             continue
         acc[r["Counter_Name"]] += float(r["Counter_Value"])
         cnt[r["Counter_Name"]] += 1
@@ -17,7 +19,7 @@ for f in sorted(glob.glob(f"{out}/p*/**/*counter_collection.csv", recursive=True
 disp = defaultdict(set)
 for f in sorted(glob.glob(f"{out}/p*/**/*counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(f)):
-        if "attn_resident_k" in r["Kernel_Name"]:
+        if KERNEL in r["Kernel_Name"]:
             disp[r["Counter_Name"]].add((f, r["Dispatch_Id"]))
 print(f"{'counter':28s} {'per launch':>16s}  launches")
 for k in sorted(acc):
@@ -25,7 +27,7 @@ for k in sorted(acc):
     print(f"{k:28s} {acc[k] / n:16.0f}  {n}")
 for f in glob.glob(f"{out}/trace/**/*kernel_stats.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "attn_resident_k" in r["Name"]:
+        if KERNEL in r["Name"]:
             print(f"kernel-trace: calls {r['Calls']} average {float(r['AverageNs']) / 1e3:.1f} us (min {float(r['MinNs']) / 1e3:.1f}, max {float(r['MaxNs']) / 1e3:.1f})")
 w = acc.get("SQ_WAVE_CYCLES", 0)
 if w:
