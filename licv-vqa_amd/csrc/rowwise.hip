@@ -111,11 +111,6 @@ void inject_renorm_fwd_k(const void* __restrict__ h, const float* __restrict__ i
     if (row >= rows) return;
     const int64_t base = row * hidden;
     __shared__ __attribute__((aligned(16))) bf16_t ws_img[WS ? NCH * 256 : 8];
-    if constexpr (WS) {                                    // `pre` = the branch summed from the split-K slices (see WsSrc)
-        ws_branch_to_lds<NCH>(wsrc, row, hidden, ws_img);
-        if (threadIdx.x >= 64) return;
-        pre = ws_img;
-    }
     const float a = alpha ? *alpha : 1.0f;
     // Every load of a phase is issued before the first value is used: chunk indices past the row are clamped to the row's first
     // chunk and their values discarded by a select, not skipped by a branch.  (A guard `if (i < hidden) { load; use; }` per chunk
@@ -125,14 +120,23 @@ void inject_renorm_fwd_k(const void* __restrict__ h, const float* __restrict__ i
     // `h` when absent and dropped by a select — no branch per chunk either.
     floatx4 x[NCH], hvv[NCH], bvv[NCH], vvv[NCH];
     float ss = 0.f, hh = 0.f;
-    const bool has_pre = pre != nullptr;
+    const bool has_pre = WS || pre != nullptr;
     const void* pre_p = has_pre ? (const void*)pre : h;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int i = (c * 64 + lane) * 4, ii = i < hidden ? i : 0;
         hvv[c] = RowIO<DT>::load4(h, base + ii);
-        bvv[c] = RowIO<LICV_BF16>::load4(pre_p, (WS ? 0 : base) + ii);
         vvv[c] = *reinterpret_cast<const floatx4*>(icv + ii);
+    }
+    if constexpr (WS) {                                    // `pre` = the branch summed from the split-K slices (see WsSrc); the loads above are in flight meanwhile
+        ws_branch_to_lds<NCH>(wsrc, row, hidden, ws_img);
+        if (threadIdx.x >= 64) return;
+        pre_p = ws_img;
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int i = (c * 64 + lane) * 4, ii = i < hidden ? i : 0;
+        bvv[c] = RowIO<LICV_BF16>::load4(pre_p, (WS ? 0 : base) + ii);
     }
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -336,11 +340,6 @@ void add_rmsnorm_fwd_k(void* __restrict__ h, const bf16_t* __restrict__ branch, 
     if (row >= rows) return;
     const int64_t base = row * dim;
     __shared__ __attribute__((aligned(16))) bf16_t ws_img[WS ? NCH * 256 : 8];
-    if constexpr (WS) {                                    // the branch summed from the split-K slices (see WsSrc)
-        ws_branch_to_lds<NCH>(wsrc, row, dim, ws_img);
-        if (threadIdx.x >= 64) return;
-        branch = ws_img;
-    }
     const bool closed = row_gate && row_gate[row] == 0.0f;           // gated cross-attention: a token that attends no image adds nothing
     floatx4 v[NCH], bvv[NCH], wv[NCH];                             // all loads first, no per-chunk branch (see inject_renorm_fwd_k)
     float ss = 0.f;
@@ -348,8 +347,17 @@ void add_rmsnorm_fwd_k(void* __restrict__ h, const bf16_t* __restrict__ branch, 
     for (int c = 0; c < NCH; ++c) {
         const int i = (c * 64 + lane) * 4, ii = i < dim ? i : 0;
         v[c] = RowIO<DT>::load4(h, base + ii);
-        bvv[c] = RowIO<LICV_BF16>::load4(branch, (WS ? 0 : base) + ii);
         wv[c] = RowIO<LICV_BF16>::load4(w, ii);
+    }
+    if constexpr (WS) {                                    // the branch summed from the split-K slices (see WsSrc); the loads above are in flight meanwhile
+        ws_branch_to_lds<NCH>(wsrc, row, dim, ws_img);
+        if (threadIdx.x >= 64) return;
+        branch = ws_img;
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int i = (c * 64 + lane) * 4, ii = i < dim ? i : 0;
+        bvv[c] = RowIO<LICV_BF16>::load4(branch, (WS ? 0 : base) + ii);
     }
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
