@@ -2055,7 +2055,7 @@ static int g_skinny_inlaunch = 0;   // knob 7: 1 = the skinny kernel reduces ove
                                     // 4096 x 4096: 16.9 vs 18.3), see tools/stream_bench.py; kept as a tested alternative
 static int g_pp_group = 0;      // experiment knob: tile-rows per XCD patch group (0 = heuristic)
 static int g_splitk_enabled = 1;
-static int g_big_tiles = 160;   // knob 6: fewest 256 x 256 tiles for which the 256-tile kernels are taken (see route_256)
+static int g_big_tiles = 136;   // knob 6: fewest 256 x 256 tiles for which the 256-tile kernels are taken (see route_256)
 static int g_force_splits = 0;  // knob 5 (A/B timing only): split count of the 128-tile route, 0 = the plan's own choice
 static int g_flow_default = 1;  // auto mode takes the flow kernels where they are eligible (knob 2 of licv_gemm_experiment; 0 = staged epilogues only)
 // A/B timing knobs:
@@ -2136,11 +2136,16 @@ extern "C" int licv_gemm_flow_available(void) { return (flow_scratch_free() ? 1 
 // Which tile size a dense GEMM takes.  The 256 x 256 kernels (flow64 / quad64) need enough tiles to fill the 256 CUs: below
 // g_big_tiles of them (the vision tower on a few images: 2056 rows = 9 tile rows; Idefics2's 1-shot text stack) the 128 x 128
 // route — the mid kernel, two workgroups per CU, split-K where the tiles are still too few — is faster.  knob 6 moves the bar.
+// Measured with the flow64 kernel (tools/route_bench.py, N = 4096, K = 4096 / 1280, us 256-tile | 128-tile): 112 tiles 91 | 66, 128: 83 | 68,
+// 144: 85 | 98, 192: 86 | 102, 256: 100 | 135 - one partial round of 256-tiles costs about the same whatever its fill, so from ~136
+// tiles on it is ahead; 272: 162 | 147, 288: 162 | 149, 320: 161 | 153, 384: 165 | 185 - a second round that is less than a third
+// full loses to the 128-tiles (two workgroups per CU even the tail out).
 static bool route_256(int64_t M, int64_t N, int64_t K) {
     if (K % BK != 0 || K < 128 || M < 512 || N < 256) return false;
     const int64_t t = ((M + 255) / 256) * ((N + 255) / 256);
-    // ... and those tiles must fill whole rounds of 256 reasonably (288 tiles = 1.13 rounds run as two: the 128-tile route wins)
-    return t >= g_big_tiles && (t >= 768 || 20 * t >= 13 * ((t + 255) / 256 * 256));
+    if (t < g_big_tiles) return false;
+    if (t <= 256 || t >= 768) return true;
+    return 20 * t >= 13 * ((t + 255) / 256 * 256);
 }
 
 extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
@@ -2189,7 +2194,7 @@ extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
     }
     const int fk = g_force_kernel;
     const bool can256 = (K % BK == 0) && K >= 128;
-    const bool big = route_256(M, N, K);
+    bool big = route_256(M, N, K);
     const bool lean_ok = lda * 510 < (1ll << 31) && ldw * 510 < (1ll << 31);     // 32-bit lane offsets of the DMA sources
     const int tiles_m = (int)((M + 255) / 256), tiles_n = (int)((N + 255) / 256);
     // tile-rows per XCD patch: 8 (a 32-CU XCD then works on an 8 x 4 patch); with <= 6 tile-columns an 8-row group is 40-48
@@ -2208,6 +2213,12 @@ extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
     const bool flow_ok = can256 && M >= 512 && N >= 256 && N % 64 == 0 && e->out_dtype == LICV_BF16 && (!e->residual || flow_res) && !e->row_gate &&
                          !e->use_scale && (int64_t)(M + 256) * ldc * 2 < (1ll << 31) && ldc % 8 == 0 && lean_ok &&
                          (!e->bias_bf16 || ((uintptr_t)e->bias_bf16 & 3) == 0);
+    // ... except behind a bf16-residual epilogue, where the 128-tile kernel pays its staged epilogue (LDS image, residual rows read back)
+    // per tile: SigLIP's out / fc2 projections at 16 x 972 patches (305 tiles) 74 | 65 us and 204 | 188 us (128-tile | 256-tile)
+    if (!big && flow_res && can256 && M >= 512 && N >= 256 && N % 128 == 0 && K >= 256) {
+        const int64_t t = ((M + 255) / 256) * ((N + 255) / 256);
+        big = t > 256 && t < 768;
+    }
     const bool use256 = (fk == 1 || fk == 70) ? false : (fk == 0 ? big : can256);
     const bool flow_auto = g_flow_default != 0;
     // flow64: the same epilogue families without the residual one, waves of 128 columns, at least four 64-deep K tiles
