@@ -202,6 +202,8 @@ int licv_probe_permlane16_swap(void* out_u32_128, void* stream);
  * shape = bytes per row per instruction: 0 16 rows x 64 B (MFMA fragment order), 1 8 x 128 B, 2 2 x 512 B, 3 1 x 1 KB; depth = 16-byte
  * loads per lane in flight per register set (4, 8 or 16) */
 int licv_probe_weight_stream(const void* W, int64_t ldw, int64_t N, int64_t K, int splits, int shape, int depth, void* sink_u32, void* stream);
+/* the same stream as LDS-DMA pieces (8 rows x 128 B per instruction), `depth` (4 / 8 / 16 / 32 / 48) pieces outstanding per wave */
+int licv_probe_lds_dma_stream(const void* W, int64_t ldw, int64_t N, int64_t K, int splits, int depth, void* stream);
 /* timing instrumentation: when non-NULL, wave 0 of every workgroup of the default kernel stores 5 wall_clock64() stamps
  * (start, pipeline filled, main loop done, output image in LDS, end) at dev_buffer[8 * blockIdx.x ...] (int64) */
 int licv_gemm_debug_timestamps(void* dev_buffer);

@@ -1477,8 +1477,12 @@ void gemm_fp8_flow64_k(const char* __restrict__ A, int64_t lda, const char* __re
 // ------------------------------------------------------------------------------------------------
 #define MID_PAIR 16384
 #define MID_LDS (5 * MID_PAIR)
-template <int SPLITK>
-__global__ __launch_bounds__(256, 2)
+#define MID_LDS_DEEP (9 * MID_PAIR)
+// D = K tiles in flight ahead of the one being multiplied.  2: the ring of five pairs above (80 KiB, two workgroups per CU).  4: nine
+// pairs (144 KiB, one workgroup per CU): the W pieces of K tile t + D are issued D - 0.5 K tiles before their rendezvous instead of
+// 1.5 - an experiment (licv_gemm_experiment knob 10), bit-identical and no faster: see mid_deep().
+template <int SPLITK, int ABL = 0, int D = 2>      // ABL (timing only, wrong results): 1 = the A pieces are never issued, 2 = the W pieces
+__global__ __launch_bounds__(256, 2)      // (also for D = 4, one workgroup per CU by LDS: with 512 registers allowed the allocator moves the accumulators through AGPRs with copies around every loop)
 void gemm_bf16_mid_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw,
                      void* __restrict__ C, int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n, GemmEpi ep, int per) {
     extern __shared__ __attribute__((aligned(16))) char smem[];     // 5 pairs x 16 KiB
@@ -1509,7 +1513,9 @@ void gemm_bf16_mid_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __
         offW[q] = min(row, N - 1 - n0) * (int)ldw * 2 + chunk * 16;
     }
     const int lds_base = __builtin_amdgcn_readfirstlane((int)(uintptr_t)ring_w) + wave * 4096;
-    auto nx = [](int pair) { const int n = pair + MID_PAIR; return n >= MID_LDS ? n - MID_LDS : n; };
+    constexpr int RING = (2 * D + 1) * MID_PAIR;           // K tile g: W pair at 2 g mod (2 D + 1), A pair at 2 g + 1; A(t + D) takes W(t)'s pair
+    auto nx = [](int pair) { const int n = pair + MID_PAIR; return n >= RING ? n - RING : n; };
+    auto pv = [](int pair) { return pair == 0 ? RING - MID_PAIR : pair - MID_PAIR; };
 #define MID_M0(ADDR) asm volatile("s_mov_b32 m0, %0" :: "s"(ADDR) : "memory")
 #define MID_PIECE(VOFF, RSRC, KB) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds\n\ts_add_u32 m0, m0, 0x400" :: "v"(VOFF), "s"(RSRC), "s"(KB) : "memory", "scc")
 
@@ -1524,24 +1530,19 @@ void gemm_bf16_mid_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __
     const int rdW0 = fo0 + wn * 8192, rdW1 = fo1 + wn * 8192, rdA0 = fo0 + wm * 8192, rdA1 = fo1 + wm * 8192;
     bf16x8 fa0[4], fw0[4], fa1[4], fw1[4];
 
-    // prologue: K tiles 0 and 1 (pairs 0-3)
-    MID_M0(lds_base);
-    asm volatile("s_nop 0" ::: "memory");
+    // prologue: K tiles 0 .. D - 1 (pairs 0 .. 2 D - 1)
+    static_for<0, D>([&](auto gc) {
+        constexpr int gk = decltype(gc)::value;
+        MID_M0(lds_base + 2 * gk * MID_PAIR);
+        asm volatile("s_nop 0" ::: "memory");
 #pragma unroll
-    for (int q = 0; q < 4; ++q) MID_PIECE(offW[q], rW, 0);
-    MID_M0(lds_base + MID_PAIR);
-    asm volatile("s_nop 0" ::: "memory");
+        for (int q = 0; q < 4; ++q) { const int vo = offW[q]; const auto r = rW; MID_PIECE(vo, r, gk * 128); }   // (locals: asm operands alone do not capture)
+        MID_M0(lds_base + (2 * gk + 1) * MID_PAIR);
+        asm volatile("s_nop 0" ::: "memory");
 #pragma unroll
-    for (int q = 0; q < 4; ++q) MID_PIECE(offA[q], rA, 0);
-    MID_M0(lds_base + 2 * MID_PAIR);
-    asm volatile("s_nop 0" ::: "memory");
-#pragma unroll
-    for (int q = 0; q < 4; ++q) MID_PIECE(offW[q], rW, 128);
-    MID_M0(lds_base + 3 * MID_PAIR);
-    asm volatile("s_nop 0" ::: "memory");
-#pragma unroll
-    for (int q = 0; q < 4; ++q) MID_PIECE(offA[q], rA, 128);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");         // my pieces of K tile 0 have landed
+        for (int q = 0; q < 4; ++q) { const int vo = offA[q]; const auto r = rA; MID_PIECE(vo, r, gk * 128); }
+    });
+    asm volatile("s_waitcnt vmcnt(%0)" :: "i"(8 * (D - 1)) : "memory");         // my pieces of K tile 0 have landed
     __builtin_amdgcn_s_barrier();                            // K tile 0 published
 #pragma unroll
     for (int j = 0; j < 4; ++j) fw0[j] = *(lds_fptr)(ring + rdW0 + j * 2048);
@@ -1549,12 +1550,12 @@ void gemm_bf16_mid_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __
     for (int i = 0; i < 4; ++i) fa0[i] = *(lds_fptr)(ring + MID_PAIR + rdA0 + i * 2048);
 
     int pW = 0;                                              // ring position of the W pair of the K tile being multiplied
-    // One K tile.  STEADY (t + 2 < nt): pieces of K tile t + 2 and reads of K tile t + 1 exist: one straight instruction stream.
+    // One K tile.  STEADY (t + D < nt): pieces of K tile t + D and reads of K tile t + 1 exist: one straight instruction stream.
     auto ktile = [&](int t, auto steady_c) {
         constexpr bool STEADY = decltype(steady_c)::value;
-        const bool more1 = STEADY || t + 1 < nt, more2 = STEADY || t + 2 < nt;
-        const int kb = (t + 2) * 128;
-        const int pA = nx(pW), pW1 = nx(pA), pA1 = nx(pW1), pW2 = nx(pA1);     // pairs of t (A), t + 1 (W, A), t + 2 (W; its A pair is pW)
+        const bool more1 = STEADY || t + 1 < nt, more2 = STEADY || t + D < nt;
+        const int kb = (t + D) * 128;
+        const int pA = nx(pW), pW1 = nx(pA), pA1 = nx(pW1), pW2 = pv(pW);      // pairs of t (A), t + 1 (W, A), t + D (W: the pair before pW; its A pair is pW)
         // ---- step 0: MFMAs on set 0; reads of (t, second half) into set 1; pieces of the W pair of K tile t + 2
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
@@ -1570,7 +1571,7 @@ void gemm_bf16_mid_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __
                     else fa1[m - 4] = *(lds_fptr)(pa + (m - 4) * 2048);
                 }
                 if constexpr (m >= 8 && m < 16 && (m & 1) == 0) {
-                    if (more2) MID_PIECE(offW[(m - 8) >> 1], rW, kb);
+                    if (more2 && !(ABL & 2)) MID_PIECE(offW[(m - 8) >> 1], rW, kb);
                 }
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw0[j], fa0[i], acc[i][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
@@ -1594,13 +1595,16 @@ void gemm_bf16_mid_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __
                 }
                 if constexpr (m == 7) { if (more2) MID_M0(lds_base + pW); }      // the pair of K tile t's W units, freed by this step's barrier
                 if constexpr (m >= 8 && m < 16 && (m & 1) == 0) {
-                    if (more2) MID_PIECE(offA[(m - 8) >> 1], rA, kb);
+                    if (more2 && !(ABL & 1)) MID_PIECE(offA[(m - 8) >> 1], rA, kb);
                 }
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw1[j], fa1[i], acc[i][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (m == 1) {
                     // in flight, oldest first: W(t+1), A(t+1), W(t+2) [if it exists]: retire K tile t + 1
-                    if (more2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    // in flight, oldest first: W, A of t + 1 .. t + D - 1, W(t + D): retire K tile t + 1 = leave 4 (2 D - 3) pieces
+                    if (more2 && ABL != 2) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(4 * (2 * D - 3)) : "memory");   // (ABL 2: only A pieces are in flight here)
+                    else if (D == 4 && nt - 1 - t >= 3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // the tail: K tiles t + 1 .. nt - 1 in flight, whole
+                    else if (D == 4 && nt - 1 - t == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
@@ -1610,7 +1614,7 @@ void gemm_bf16_mid_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __
         pW = pW1;
     };
     int t = 0;
-    for (; t + 2 < nt; ++t) ktile(t, std::true_type{});
+    for (; t + D < nt; ++t) ktile(t, std::true_type{});
     for (; t < nt; ++t) ktile(t, std::false_type{});
 #undef MID_M0
 #undef MID_PIECE
@@ -2057,6 +2061,15 @@ static int g_pp_group = 0;      // experiment knob: tile-rows per XCD patch grou
 static int g_splitk_enabled = 1;
 static int g_big_tiles = 136;   // knob 6: fewest 256 x 256 tiles for which the 256-tile kernels are taken (see route_256)
 static int g_force_splits = 0;  // knob 5 (A/B timing only): split count of the 128-tile route, 0 = the plan's own choice
+static int g_mid_depth = 0;     // knob 10: 4 = the 128-tile mid kernel keeps FOUR K tiles in flight (nine-pair ring) wherever every range has 4 K tiles
+// Measured (tools/mid_depth.py, M = 256, cold): bit-identical and within +-5 % of the five-pair ring on every shape with <= 256
+// workgroups, 13-15 % slower where two workgroups per CU were possible (22016 / 32002 columns): the K-tile period of a lone
+// workgroup is not the latency of its pieces.  Kept as an experiment, off by default.
+static bool mid_deep(int64_t M, int64_t min_ktiles) {
+    (void)M;
+    return g_mid_depth == 4 && min_ktiles >= 4;
+}
+static int g_mid_ablate = 0;    // knob 9 (timing only, WRONG RESULTS): the 128-tile mid kernel without its A pieces (1) / W pieces (2)
 static int g_flow_default = 1;  // auto mode takes the flow kernels where they are eligible (knob 2 of licv_gemm_experiment; 0 = staged epilogues only)
 // A/B timing knobs:
 //   knob 0: (experiments' ping-pong kernel) per-XCD first-round start stagger, percent of an eighth of the estimated tile time
@@ -2065,6 +2078,8 @@ static int g_flow_default = 1;  // auto mode takes the flow kernels where they a
 //   batch-independence tests switch split-K off for every caller, the native layer runner included)
 //   knob 7: 1 = the skinny kernel reduces over its splits in its own launch (default 0: a separate finalize launch)
 //   knob 8: 0 = fp8 GEMMs never take the 4-wave kernel on the 128-deep MFMA
+//   knob 9: timing-only ablation of the mid kernel's operand stream (1 = no A pieces, 2 = no W pieces; results are wrong)
+//   knob 10: 4 = the mid kernel keeps four K tiles in flight (nine-pair ring) wherever it fits; anything else = the five-pair ring
 extern "C" int licv_gemm_experiment(int knob, int value) {
     if (knob == 0) return licv_gemm_exp_knob(0, value);
     else if (knob == 1) g_pp_group = value; else if (knob == 2) g_flow_default = value;
@@ -2073,6 +2088,8 @@ extern "C" int licv_gemm_experiment(int knob, int value) {
     else if (knob == 6) g_big_tiles = value;
     else if (knob == 7) g_skinny_inlaunch = value;
     else if (knob == 8) g_fp8_flow64 = value;
+    else if (knob == 9) g_mid_ablate = value;
+    else if (knob == 10) g_mid_depth = value;
     else return licv_set_error(LICV_E_BADARG, "gemm_experiment: unknown knob %d", knob);
     return LICV_OK;
 }
@@ -2266,6 +2283,17 @@ extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
         if (fk != 1 && K % 64 == 0 && K >= 128 && lean_ok) {
             static bool amid = false;
             if (!amid) { (void)hipFuncSetAttribute((const void*)gemm_bf16_mid_k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, MID_LDS); amid = true; }
+            if (g_mid_ablate == 1 || g_mid_ablate == 2) {                 // knob 9: timing-only ablations of the operand stream
+                if (g_mid_ablate == 1) { (void)hipFuncSetAttribute((const void*)gemm_bf16_mid_k<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, MID_LDS);
+                    gemm_bf16_mid_k<0, 1><<<dim3(t128m * t128n), dim3(256), MID_LDS, (hipStream_t)stream>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, t128m, t128n, ep, 0); }
+                else { (void)hipFuncSetAttribute((const void*)gemm_bf16_mid_k<0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, MID_LDS);
+                    gemm_bf16_mid_k<0, 2><<<dim3(t128m * t128n), dim3(256), MID_LDS, (hipStream_t)stream>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, t128m, t128n, ep, 0); }
+            } else if (mid_deep(M, K / 64)) {
+                static bool adeep = false;
+                if (!adeep) { (void)hipFuncSetAttribute((const void*)gemm_bf16_mid_k<0, 0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, MID_LDS_DEEP); adeep = true; }
+                gemm_bf16_mid_k<0, 0, 4><<<dim3(t128m * t128n), dim3(256), MID_LDS_DEEP, (hipStream_t)stream>>>(
+                    (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, t128m, t128n, ep, 0);
+            } else
             gemm_bf16_mid_k<0><<<dim3(t128m * t128n), dim3(256), MID_LDS, (hipStream_t)stream>>>(
                 (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, t128m, t128n, ep, 0);
         } else
@@ -2422,6 +2450,12 @@ static int splitk_run(const void* A, int64_t lda, const void* W, int64_t ldw, vo
     hipStream_t st = (hipStream_t)stream;
     if (g_force_kernel != 1 && K % 64 == 0 && nkt - (splits - 1) * per >= 2 && lda * 510 < (1ll << 31) && ldw * 510 < (1ll << 31)) {
         // the mid kernel as the producer (every split at least two K tiles deep)
+        if (mid_deep(M, nkt - (splits - 1) * per)) {           // (the last range is the shortest)
+            static bool adeep = false;
+            if (!adeep) { (void)hipFuncSetAttribute((const void*)gemm_bf16_mid_k<1, 0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, MID_LDS_DEEP); adeep = true; }
+            gemm_bf16_mid_k<1, 0, 4><<<dim3(tiles_m * tiles_n, splits), dim3(256), MID_LDS_DEEP, st>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw,
+                workspace, 0, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, per);
+        } else
         gemm_bf16_mid_k<1><<<dim3(tiles_m * tiles_n, splits), dim3(256), MID_LDS, st>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw,
             workspace, 0, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, per);
     } else {

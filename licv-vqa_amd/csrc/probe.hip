@@ -103,3 +103,44 @@ extern "C" int licv_probe_weight_stream(const void* W, int64_t ldw, int64_t N, i
     LICV_LAUNCH_CHECK();
     return LICV_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// The same stream through LDS-DMA (`buffer_load_dwordx4 ... lds`, 8 rows x 128 B per instruction = the GEMM kernels' pieces): how
+// many pieces per wave does the hardware keep in flight?  Each wave owns 16 rows x a K range and keeps DEPTH pieces outstanding
+// (issue one, `s_waitcnt vmcnt(DEPTH - 1)`); the LDS destination cycles through the wave's 32 KiB (nothing reads it).
+// ------------------------------------------------------------------------------------------------
+template <int DEPTH>
+__global__ __launch_bounds__(256)
+void lds_dma_probe_k(const bf16_t* __restrict__ W, int64_t ldw, int N, int K, int kr) {
+    extern __shared__ __attribute__((aligned(16))) char dsm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n0 = blockIdx.x * 64 + wave * 16;
+    const int k0 = blockIdx.y * kr;
+    const int n_instr = 16 * kr * 2 / 1024;                              // 8 rows x 128 B each: two per 64-element K step of the 16 rows
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (int64_t)n0 * ldw + k0), 0, 0xFFFFFFFF, 0x00020000);
+    const int lds_base = __builtin_amdgcn_readfirstlane((int)(uintptr_t)(__attribute__((address_space(3))) char*)dsm) + wave * 32768;
+    const int row_off = (lane >> 3) * (int)ldw * 2 + (lane & 7) * 16;
+    for (int i = 0; i < n_instr; ++i) {
+        const int kpos = i >> 1, half = i & 1;
+        const int voff = row_off + half * 8 * (int)ldw * 2 + kpos * 128;
+        const int m0 = lds_base + (i & 31) * 1024;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_waitcnt vmcnt(%3)"
+                     :: "s"(m0), "v"(voff), "s"(rs), "i"(DEPTH - 1) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+extern "C" int licv_probe_lds_dma_stream(const void* W, int64_t ldw, int64_t N, int64_t K, int splits, int depth, void* stream) {
+    LICV_CHECK_ARG(W && N % 64 == 0 && splits > 0 && K % (splits * 512) == 0, "probe_lds_dma_stream: N %% 64, K %% (splits * 512) must be 0");
+    LICV_CHECK_ARG((int64_t)16 * ldw * 2 + K * 2 < (1ll << 31), "probe_lds_dma_stream: offsets exceed 32 bits");
+    const dim3 grid((unsigned)(N / 64), (unsigned)splits);
+    const int kr = (int)(K / splits);
+    hipStream_t st = (hipStream_t)stream;
+#define DMA_LAUNCH(D) do { (void)hipFuncSetAttribute((const void*)lds_dma_probe_k<D>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); \
+        lds_dma_probe_k<D><<<grid, 256, 131072, st>>>((const bf16_t*)W, ldw, (int)N, (int)K, kr); } while (0)
+    if (depth <= 4) DMA_LAUNCH(4); else if (depth <= 8) DMA_LAUNCH(8); else if (depth <= 16) DMA_LAUNCH(16); else if (depth <= 32) DMA_LAUNCH(32); else DMA_LAUNCH(48);
+#undef DMA_LAUNCH
+    LICV_LAUNCH_CHECK();
+    return LICV_OK;
+}

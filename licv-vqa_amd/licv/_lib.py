@@ -92,6 +92,7 @@ def lib() -> C.CDLL:
             "licv_probe_mfma_loop": [P, I, I, P],
             "licv_probe_permlane16_swap": [P, P],
             "licv_probe_weight_stream": [P, I64, I64, I64, I, I, I, P, P],
+            "licv_probe_lds_dma_stream": [P, I64, I64, I64, I, I, P],
             "licv_idefics_image_attention_mask": [P, P, I64, I64, I64, I64, I64, P],
             "licv_idefics2_patch_front": [P, P, P, P, P, P, I64, I64, I64, I64, I64, P],
             "licv_merge_image_rows": [P, P, P, P, P, I64, I64, I64, I64, P],

@@ -11,6 +11,11 @@ from licv import _lib, ops
 M, N, K = (int(v) for v in sys.argv[1:4])
 rounds = int(sys.argv[4]) if len(sys.argv) > 4 else 2
 _lib.lib().licv_gemm_select(int(sys.argv[5]) if len(sys.argv) > 5 else 0)
+import os
+if os.environ.get("LICV_MID_DEPTH"):
+    _lib.lib().licv_gemm_experiment(10, int(os.environ["LICV_MID_DEPTH"]))
+if os.environ.get("LICV_ONE_PASS"):
+    _lib.lib().licv_gemm_experiment(4, 0)
 g = torch.Generator(device="cuda").manual_seed(1)
 nbuf = max(2, -(-640 * 2 ** 20 // (N * K * 2)))
 a = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
