@@ -838,3 +838,33 @@ def test_rotary_and_cache_append_from_split_k_slices(B, S, nh, hd, K):
     assert torch.equal(c1, c2)
     assert torch.equal(q1[:, :H], q2[:, :H]) and not q2[:, H:].any()
     assert c1[:, past:past + S].abs().sum() > 0 and not c1[:, :past].any() and not c1[:, past + S:].any()
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(256, 4096, 4096, "plain"), (256, 1536, 1280, "bias_gelu"), (200, 640, 2048, "res32"), (130, 4096, 11008, "plain"),
+                                       (1376, 4096, 4096, "plain")])
+def test_mid_kernel_with_four_k_tiles_in_flight_is_bit_identical(M, N, K, epi):
+    """The nine-pair ring variant of the 128-tile kernel (licv_gemm_experiment knob 10 = 4; an experiment, off by default) multiplies
+    the same K tiles in the same order: same bits as the five-pair ring, in one pass and as the split-K producer."""
+    from licv import _lib, ops
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(torch.bfloat16).to(DEV)
+    kw = {}
+    if epi == "bias_gelu":
+        kw = dict(bias=torch.randn(N, generator=g).to(torch.bfloat16).to(DEV), act="gelu")
+    elif epi == "res32":
+        kw = dict(residual=torch.randn(M, N, generator=g).to(DEV))
+    lib = _lib.lib()
+    try:
+        lib.licv_gemm_select(70)                                 # the mid kernel at any M
+        for one_pass in (False, True):
+            ops.set_splitk(not one_pass)
+            ref = ops.linear(a, w, **{k: (v.clone() if k == "residual" else v) for k, v in kw.items()}).clone()
+            lib.licv_gemm_experiment(10, 4)
+            out = ops.linear(a, w, **{k: (v.clone() if k == "residual" else v) for k, v in kw.items()})
+            lib.licv_gemm_experiment(10, 0)
+            assert torch.equal(ref, out), f"one_pass={one_pass}"
+    finally:
+        lib.licv_gemm_experiment(10, 0)
+        lib.licv_gemm_select(0)
+        ops.set_splitk(True)
