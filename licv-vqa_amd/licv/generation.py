@@ -199,17 +199,20 @@ def _decode(model, a, input_ids: torch.Tensor, attention_mask: torch.Tensor, max
         m_len = torch.cat([gen_len, torch.full_like(top_ix, cur + 1 - P)], 1)
         best = torch.topk(m_sc, k=nb)[1]
         finished, fin_scores, is_fin, gen_len = gather(m_seq, best), gather(m_sc, best), gather(m_fin, best), gather(m_len, best)
-        # reorder the per-beam model state
-        flat_src = (beam_src + torch.arange(B, device=dev)[:, None] * nb).reshape(-1)
-        model.reorder(flat_src)
         cur += 1
         # early-stop heuristic (early_stopping=False form): can a running beam still beat the worst finished one?
         best_run = run_scores[:, :1] / (float(cur - P) ** length_penalty)
         worst_fin = torch.where(is_fin, fin_scores.min(dim=1, keepdim=True)[0], torch.full_like(fin_scores, -1.0e9))
         improve = improve & torch.any(best_run > worst_fin, dim=-1, keepdim=True)
-        unfinished = bool(improve.any()) and not (bool(is_fin.all()) and early_stopping is True) and not bool(hits.all())
-        if not unfinished:
+        # one device -> host read per step (the loop's only synchronisation point)
+        unfinished_t = improve.any() & ~hits.all()
+        if early_stopping is True:
+            unfinished_t = unfinished_t & ~is_fin.all()
+        if not bool(unfinished_t):
             break
+        # reorder the per-beam model state (after the exit test: the last step's reorder would feed no further forward)
+        flat_src = (beam_src + torch.arange(B, device=dev)[:, None] * nb).reshape(-1)
+        model.reorder(flat_src)
         am = torch.cat([am, torch.ones((B * nb, 1), dtype=am.dtype, device=dev)], 1)
         logits = model.step(running[:, :, cur - 1].reshape(B * nb, 1), am)
     out = finished[:, 0, :]
