@@ -2165,6 +2165,20 @@ static bool route_256(int64_t M, int64_t N, int64_t K) {
     return 20 * t >= 13 * ((t + 255) / 256 * 256);
 }
 
+// The 256-tile kernels address C (and a residual) with 32-bit byte offsets from the tensor's base, which caps a launch at 2 GiB of
+// output: SigLIP's fc1 at 264 images x 972 patches is 256608 x 4352 bf16 = 2.2 GB, and used to fall back to the 8-wave / staged kernels
+// for that one projection (fp8: 2.9 ms against ~1.1 ms).  Taller outputs run as row blocks (multiples of 256 rows) instead - the same
+// tiles, the same arithmetic per tile: bit-identical.  Returns the rows per block, or 0 when one launch does.
+static int64_t rows_per_launch(int64_t M, int64_t ldc, int out_dtype, const licv_gemm_epilogue* e) {
+    int64_t row_bytes = ldc * (out_dtype == LICV_F32 ? 4 : 2);
+    if (e->residual) { const int64_t rb = e->ld_res * (e->residual_dtype == LICV_F32 ? 4 : 2); if (rb > row_bytes) row_bytes = rb; }
+    if ((M + 256) * row_bytes < (1ll << 31)) return 0;
+    const int64_t cap = (((1ll << 31) - 1) / row_bytes - 256) / 256 * 256;
+    if (cap < 512) return 0;
+    const int64_t blocks = (M + cap - 1) / cap;
+    return ((M + blocks - 1) / blocks + 255) / 256 * 256;             // even blocks (<= cap: cap is itself a multiple of 256)
+}
+
 extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
                               int64_t M, int64_t N, int64_t K, const licv_gemm_epilogue* e, void* stream) {
     LICV_CHECK_ARG(A && W && C && e, "gemm_bf16: null pointer");
@@ -2180,6 +2194,17 @@ extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
     LICV_CHECK_ARG(!e->residual || (e->ld_res % 4 == 0 && ((uintptr_t)e->residual & 15) == 0), "gemm_bf16: residual misaligned");
     LICV_CHECK_ARG(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), "gemm_bf16: dimension too large");
     if (M == 0) return LICV_OK;
+    if (const int64_t rows = rows_per_launch(M, ldc, e->out_dtype, e)) {
+        for (int64_t m0 = 0; m0 < M; m0 += rows) {
+            licv_gemm_epilogue eb = *e;
+            if (e->residual) eb.residual = (const char*)e->residual + m0 * e->ld_res * (e->residual_dtype == LICV_F32 ? 4 : 2);
+            if (e->row_gate) eb.row_gate = e->row_gate + m0;
+            const int rc = licv_gemm_bf16((const char*)A + m0 * lda * 2, lda, W, ldw, (char*)C + m0 * ldc * (e->out_dtype == LICV_F32 ? 4 : 2), ldc,
+                                          M - m0 < rows ? M - m0 : rows, N, K, &eb, stream);
+            if (rc != LICV_OK) return rc;
+        }
+        return LICV_OK;
+    }
     GemmEpi ep;
     ep.bias = (const bf16_t*)e->bias_bf16; ep.row_gate = e->row_gate; ep.residual = e->residual;
     ep.residual_dtype = e->residual_dtype; ep.ld_res = e->ld_res; ep.act = e->act; ep.swiglu = e->swiglu;
@@ -2504,6 +2529,17 @@ extern "C" int licv_gemm_fp8(const void* Aq, int64_t lda, const float* a_scale, 
     LICV_CHECK_ARG(!e->swiglu || (N % 32 == 0 && !e->bias_bf16 && !e->act), "gemm_fp8: swiglu needs N %% 32 == 0, no bias/act");
     LICV_CHECK_ARG(!e->residual || (e->ld_res % 4 == 0 && ((uintptr_t)e->residual & 15) == 0), "gemm_fp8: residual misaligned");
     LICV_CHECK_ARG(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), "gemm_fp8: dimension too large");
+    if (const int64_t rows = rows_per_launch(M, ldc, e->out_dtype, e)) {
+        for (int64_t m0 = 0; m0 < M; m0 += rows) {
+            licv_gemm_epilogue eb = *e;
+            if (e->residual) eb.residual = (const char*)e->residual + m0 * e->ld_res * (e->residual_dtype == LICV_F32 ? 4 : 2);
+            if (e->row_gate) eb.row_gate = e->row_gate + m0;
+            const int rc = licv_gemm_fp8((const char*)Aq + m0 * lda, lda, a_scale + m0, Wq, ldw, w_scale, (char*)C + m0 * ldc * (e->out_dtype == LICV_F32 ? 4 : 2), ldc,
+                                         M - m0 < rows ? M - m0 : rows, N, K, &eb, stream);
+            if (rc != LICV_OK) return rc;
+        }
+        return LICV_OK;
+    }
     GemmEpi ep;
     ep.bias = (const bf16_t*)e->bias_bf16; ep.row_gate = e->row_gate; ep.residual = e->residual;
     ep.residual_dtype = e->residual_dtype; ep.ld_res = e->ld_res; ep.act = e->act; ep.swiglu = e->swiglu;

@@ -230,3 +230,29 @@ def test_fullsize_idefics2_fp8_32shot_properties():
     cos = torch.nn.functional.cosine_similarity(a, b, dim=-1)
     print(f"\n  F3 idefics2-8b 32-shot, fp8 text stack vs bf16 engine at full depth: relative L2 {rel:.3f}, cosine min {float(cos.min()):.4f} mean {float(cos.mean()):.4f}")
     assert rel <= F3_REL and float(cos.min()) >= F3_COS                                                  # F3
+
+
+@pytest.mark.parametrize("fp8", [False, True])
+def test_outputs_past_two_gib_run_as_row_blocks_on_the_same_kernels(fp8):
+    """SigLIP's fc1 at 264 images x 972 patches writes 256608 x 4352 bf16 = 2.2 GB, past the 32-bit byte offsets of the 256-tile
+    kernels: the entry points run such a GEMM as row blocks.  Rows from the start, from both sides of the block seam and from the end
+    must equal the same projection computed on those rows alone (every kernel gives the same bits)."""
+    from licv import ops
+    M, N, K = 256608, 4352, 1152
+    g = torch.Generator(device="cuda").manual_seed(5)
+    a = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(torch.bfloat16)
+    bias = torch.randn(N, device="cuda", generator=g).to(torch.bfloat16)
+    seam = (M // 2 + 255) // 256 * 256
+    picks = [slice(0, 700), slice(seam - 300, seam + 300), slice(M - 700, M)]
+    if fp8:
+        aq, asc = ops.quantize_fp8(a)
+        wq, wsc = ops.quantize_fp8(w)
+        out = ops.linear_fp8(aq, asc, wq, wsc, bias=bias, act="gelu_tanh")
+        for sl in picks:
+            assert torch.equal(out[sl], ops.linear_fp8(aq[sl].contiguous(), asc[sl].contiguous(), wq, wsc, bias=bias, act="gelu_tanh"))
+    else:
+        out = ops.linear(a, w, bias=bias, act="gelu_tanh")
+        for sl in picks:
+            assert torch.equal(out[sl], ops.linear(a[sl].contiguous(), w, bias=bias, act="gelu_tanh"))
+    assert out.shape == (M, N) and out.numel() * 2 > 2 ** 31
