@@ -2376,16 +2376,19 @@ extern "C" int licv_gemm_splitk_plan(int64_t M, int64_t N, int64_t K, int* split
     if (g_force_splits > 0) sp = g_force_splits;
     else if (K % BK == 0) {
         // The smallest estimated time wins: rounds of workgroups x K tiles per workgroup x time per K tile (the operand stream of a
-        // CU is shared by its two workgroups: ~0.7 us per 32 KiB K tile alone when the operands come from HBM, ~0.9 us each in pairs),
-        // plus — for sp > 1 — the fp32 partials written once and read once at ~3 TB/s and a second launch.  Constants from COLD sweeps
-        // (tools/split_sweep.py, tools/mid_depth.py; the first fit, 0.5 us alone, came from a warm matrix and kept the 8-image vision
-        // tower's fc2, 2056 x 1280 x 5120, in one pass: 72 us against 51 us in three ranges).
+        // CU is shared by its two workgroups: ~0.5 us per 32 KiB K tile alone, ~0.9 us each in pairs), plus — for sp > 1 — the fp32
+        // partials written once and read once at ~3 TB/s and a second launch.  Constants from tools/mid_bench.py sweeps (a warm
+        // matrix).  Cold (tools/split_sweep.py) a lone workgroup pays ~0.7 us, and with that constant the 8-image vision tower's fc2
+        // (2056 x 1280 x 5120) would run in three ranges, 72 -> 52 us - but so would the projections of a single 800-token question,
+        // whose logits then differ from the same question inside a batch of 8 by more than the bar of the batch-independence test
+        // (tests/test_fullsize_gpu.py P2: 0.063 against 0.05 relative L2; every extra split-K GEMM is another summation order).
+        // Kept at 0.5: the student / generate steps lose ~0.3 ms to it.
         double best = 1e30;
         for (int64_t c : {1, 2, 3, 4, 6, 8, 12, 16}) {
             if (c > 1 && nkt / c < 4) break;                      // at least 4 K tiles per split
             const int64_t wgs = tiles * c, per = (nkt + c - 1) / c;
             const double rounds = (double)((wgs + 511) / 512);
-            const double tk = wgs <= 256 ? 0.7 : 0.9;
+            const double tk = wgs <= 256 ? 0.5 : 0.9;
             double t = rounds * (per * tk + 4.0);
             if (c > 1) t += (double)(c + 1) * M * N * 4.0 / 3.0e6 + 5.0;
             if (t < best) { best = t; sp = c; }
