@@ -2377,12 +2377,7 @@ extern "C" int licv_gemm_splitk_plan(int64_t M, int64_t N, int64_t K, int* split
     else if (K % BK == 0) {
         // The smallest estimated time wins: rounds of workgroups x K tiles per workgroup x time per K tile (the operand stream of a
         // CU is shared by its two workgroups: ~0.5 us per 32 KiB K tile alone, ~0.9 us each in pairs), plus — for sp > 1 — the fp32
-        // partials written once and read once at ~3 TB/s and a second launch.  Constants from tools/mid_bench.py sweeps (a warm
-        // matrix).  Cold (tools/split_sweep.py) a lone workgroup pays ~0.7 us, and with that constant the 8-image vision tower's fc2
-        // (2056 x 1280 x 5120) would run in three ranges, 72 -> 52 us - but so would the projections of a single 800-token question,
-        // whose logits then differ from the same question inside a batch of 8 by more than the bar of the batch-independence test
-        // (tests/test_fullsize_gpu.py P2: 0.063 against 0.05 relative L2; every extra split-K GEMM is another summation order).
-        // Kept at 0.5: the student / generate steps lose ~0.3 ms to it.
+        // partials written once and read once at ~3 TB/s and a second launch.  Constants from tools/mid_bench.py sweeps.
         double best = 1e30;
         for (int64_t c : {1, 2, 3, 4, 6, 8, 12, 16}) {
             if (c > 1 && nkt / c < 4) break;                      // at least 4 K tiles per split
