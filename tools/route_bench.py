@@ -15,6 +15,10 @@ SHAPES = [(15552, 1152, 1152, "res"), (15552, 1152, 4352, "res"), (15552, 3456, 
           (8224, 1280, 5120, "res"), (11000, 1280, 1280, "res"), (11000, 1280, 5120, "res")]
 if len(sys.argv) > 1 and sys.argv[1] == "sweep":         # 256-tile counts around one round of the 256 CUs
     SHAPES = [(m, 4096, k, "") for k in (4096, 1280) for m in (1792, 2048, 2304, 3072, 4096, 4352, 4608, 5120, 6144)]
+SELS = (0, 60, 70)
+if len(sys.argv) > 1 and sys.argv[1] == "duo":           # the 128 x 256 "duo" experiment kernel (select 50) on the under-filled shapes
+    SELS = (0, 50)
+    SHAPES = [(1376, 4096, 4096, ""), (1376, 4096, 14336, ""), (1376, 6144, 4096, ""), (1024, 4096, 4096, ""), (2056, 1280, 5120, "res"), (2056, 1280, 1280, "res"), (4112, 1280, 5120, "res"), (4352, 4096, 4096, ""), (256, 12288, 4096, ""), (256, 22016, 4096, "")]
 lib = _lib.lib()
 g = torch.Generator(device="cuda").manual_seed(1)
 for (M, N, K, epi) in SHAPES:
@@ -27,7 +31,7 @@ for (M, N, K, epi) in SHAPES:
     out = torch.empty(M, n_out, device="cuda", dtype=torch.bfloat16)
     kw = dict(res=dict(bias=bias, residual=res), bias=dict(bias=bias), gelu=dict(bias=bias, act="gelu"), swiglu=dict(swiglu=True)).get(epi, {})
     t, ref = {}, None
-    for sel in (0, 60, 70):
+    for sel in SELS:
         lib.licv_gemm_select(sel)
         run = lambda i: ops.linear(As[i], Ws[i], out=out, **kw)
         for i in range(nbuf): run(i)
