@@ -20,7 +20,10 @@
 extern "C" {
 #endif
 
-#define LICV_ABI_VERSION 1
+/* Bumped whenever an entry point is added, removed or changes its arguments; licv/_lib.py holds the same constant and refuses a
+ * library that answers anything else.  1 = round 1; 2 = rounds 2-3 (fp8, split-K slices, runner, front-end, backward, image input);
+ * 3 = round 4 (lab library split off; weight-streaming GEMM; beam scoring; decode-step fusion). */
+#define LICV_ABI_VERSION 3
 
 enum { LICV_BF16 = 0, LICV_F32 = 1 };
 enum { LICV_OK = 0, LICV_E_BADARG = -1, LICV_E_UNSUPPORTED = -2, LICV_E_HIP = -3 };
@@ -184,26 +187,17 @@ int licv_gemm_fp8(const void* Aq, int64_t lda, const float* a_scale, const void*
  * single-barrier 256 x 256 kernel; 6 the round-1 ping-pong kernel; 8 persistent ping-pong; 20 flow wherever eligible; 21 pair kernel
  * (two K stages per phase); 22 lean ping-pong everywhere (23-27: its ordering / diagnostic builds); 30-37 four-wave kernel and its
  * timing builds; 40-42 four-wave kernel on 64-deep K tiles; 50 two workgroups per CU on 128 x 256 tiles.  All full-result variants are
- * bit-identical (tests/test_ops_gpu.py). */
+ * bit-identical (tests/test_ops_gpu.py).  Values that name a kernel of the lab library (2-8, 10-13, 21, 30-37, 50: csrc/lab/, built
+ * into liblicv_hip_lab.so for tests and tools only) make licv_gemm_bf16 return LICV_E_UNSUPPORTED unless that library is loaded. */
 int licv_gemm_select(int which);
-/* A/B switch for the persistent kernel's per-XCD start stagger (default on). */
-int licv_gemm_stagger(int on);
+/* Called by liblicv_hip_lab.so when it is loaded: registers the experiments' launcher / knob / timestamp entry points (or NULLs). */
+int licv_lab_register(void* launch, void* knob, void* timestamps);
 /* Knobs: 0 per-XCD start stagger of the round-1 ping-pong kernel in percent (off); 1 tile-rows per XCD patch (0 = heuristic);
  * 2 = 0: never take the flow kernel in auto mode; 4 = 0: licv_gemm_splitk_plan always answers "one pass" (split-K off for every
  * caller, the native layer runner included: the batch-independence tests compare bit for bit). */
 int licv_gemm_experiment(int knob, int value);
 /* 1 if the flow kernel may be dispatched (its code objects use no scratch memory: its counted waits rely on that), else 0 */
 int licv_gemm_flow_available(void);
-/* roofline probe: `blocks` workgroups of 4 waves each issue iters*8 register-only v_mfma_f32_16x16x32_bf16 (16384 FLOP each) */
-int licv_probe_mfma_loop(void* sink_f32, int blocks, int iters, void* stream);
-/* semantics probe: one wave writes {a', b'} = v_permlane16_swap(a = lane, b = 100 + lane) to out[2*lane], out[2*lane+1] (uint32) */
-int licv_probe_permlane16_swap(void* out_u32_128, void* stream);
-/* roofline probe: stream a cold [N, K] bf16 matrix with 4-wave workgroups (16 rows x K/splits per wave) doing nothing with the data;
- * shape = bytes per row per instruction: 0 16 rows x 64 B (MFMA fragment order), 1 8 x 128 B, 2 2 x 512 B, 3 1 x 1 KB; depth = 16-byte
- * loads per lane in flight per register set (4, 8 or 16) */
-int licv_probe_weight_stream(const void* W, int64_t ldw, int64_t N, int64_t K, int splits, int shape, int depth, void* sink_u32, void* stream);
-/* the same stream as LDS-DMA pieces (8 rows x 128 B per instruction), `depth` (4 / 8 / 16 / 32 / 48) pieces outstanding per wave */
-int licv_probe_lds_dma_stream(const void* W, int64_t ldw, int64_t N, int64_t K, int splits, int depth, void* stream);
 /* timing instrumentation: when non-NULL, wave 0 of every workgroup of the default kernel stores 5 wall_clock64() stamps
  * (start, pipeline filled, main loop done, output image in LDS, end) at dev_buffer[8 * blockIdx.x ...] (int64) */
 int licv_gemm_debug_timestamps(void* dev_buffer);
@@ -258,10 +252,13 @@ int licv_swiglu(const void* gu_bf16, void* out_bf16, int64_t rows, int64_t inter
 
 /* ---- backward of the student pass (ref:icv_src/icv_module.py:97-98: hooked forward WITH grad; the LMM is frozen, so
  * only d loss / d hidden-state is propagated; dense-layer input grads reuse licv_gemm_bf16 on transposed weights) ---- */
-/* RMSNorm backward (Idefics flavour forward): dx (+)= rs*(g - xhat*mean(g*xhat)), g = bf16(dy*w); rows addressed as forward */
+/* RMSNorm backward: dx (+)= rs*(g - xhat*mean(g*xhat)); rows addressed as forward.  g = bf16(dy*w) wherever the forward multiplied
+ * the weight into bf16 rows (flavour 0 = Idefics, hf:idefics/modeling_idefics.py:342-350: always; flavour 1 = Mistral,
+ * hf:mistral/modeling_mistral.py:182-199: only on a bf16 stream - on the fp32 stream behind a hook the product and its gradient are
+ * fp32, g = dy*w unrounded) */
 int licv_rmsnorm_bwd(const void* x, int x_dtype, const void* w_bf16, const void* dy, int dy_dtype, void* dx, int dx_dtype,
                      int64_t rows, int64_t dim, int64_t inner, int64_t ld_x, int64_t ld_dy, int64_t ld_dx, float eps,
-                     int accumulate, void* stream);
+                     int accumulate, int flavour, void* stream);
 /* SwiGLU backward on the unfused (rows, 2I) [gate | up] buffer */
 int licv_swiglu_bwd(const void* gu_bf16, const void* dact_bf16, void* dgu_bf16, int64_t rows, int64_t inter, void* stream);
 /* grad entering a residual branch: out = bf16(bf16(dh)*scale), rows with row_gate == 0 zeroed (row_gate may be NULL) */

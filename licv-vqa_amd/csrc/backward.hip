@@ -27,13 +27,16 @@ __device__ __forceinline__ void st4(void* p, int dt, int64_t i, floatx4 v) {
 // ------------------------------------------------------------------------------------------------
 // RMSNorm backward (hf:idefics/modeling_idefics.py:342-350 forward: y = w * bf16(x * rsqrt(mean(x^2)+eps))).
 // g = bf16(dy * w); dx = rs * (g - xhat * mean(g * xhat));  dx is ADDED to `dx_acc` when accumulate != 0.
+// round_g = 0: g stays fp32 - the Mistral flavour on an fp32 stream (hf:mistral/modeling_mistral.py:182-199 returns
+// weight * x.to(input_dtype): with the fp32 stream behind a hook the product, and so its gradient, is fp32; the Idefics flavour casts
+// to the weight's bf16 BEFORE the product whatever the stream's dtype).
 // Rows addressed like the forward kernel (inner / ld) so the per-head q norm works in place.
 // ------------------------------------------------------------------------------------------------
 template <int NCH>
 __global__ __launch_bounds__(64 * BW_WAVES)
 void rmsnorm_bwd_k(const void* __restrict__ x, int x_dt, const bf16_t* __restrict__ w, const void* __restrict__ dy, int dy_dt,
                    void* __restrict__ dx, int dx_dt, int64_t rows, int dim, int64_t inner, int64_t ld_x, int64_t ld_dy,
-                   int64_t ld_dx, float eps, int accumulate) {
+                   int64_t ld_dx, float eps, int accumulate, int round_g) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * BW_WAVES + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -49,7 +52,7 @@ void rmsnorm_bwd_k(const void* __restrict__ x, int x_dt, const bf16_t* __restric
             const floatx4 d = ld4(dy, dy_dt, yb + i);
             const floatx4 wv = ld4(w, LICV_BF16, i);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { ss += xv[c][j] * xv[c][j]; gv[c][j] = rbf(d[j] * wv[j]); }
+            for (int j = 0; j < 4; ++j) { ss += xv[c][j] * xv[c][j]; const float gw = d[j] * wv[j]; gv[c][j] = round_g ? rbf(gw) : gw; }
         }
     }
     ss = wave_sum(ss);
@@ -308,15 +311,17 @@ static inline int flat_grid(int64_t total) { int64_t b = (total + 255) / 256; re
 
 extern "C" int licv_rmsnorm_bwd(const void* x, int x_dtype, const void* w_bf16, const void* dy, int dy_dtype, void* dx, int dx_dtype,
                                 int64_t rows, int64_t dim, int64_t inner, int64_t ld_x, int64_t ld_dy, int64_t ld_dx, float eps,
-                                int accumulate, void* stream) {
+                                int accumulate, int flavour, void* stream) {
     LICV_CHECK_ARG(x && w_bf16 && dy && dx, "rmsnorm_bwd: null pointer");
+    LICV_CHECK_ARG(flavour == 0 || flavour == 1, "rmsnorm_bwd: flavour must be 0 (Idefics) or 1 (Mistral)");
+    const int round_g = (flavour == 1 && x_dtype == LICV_F32) ? 0 : 1;
     LICV_CHECK_ARG(dim > 0 && dim % 4 == 0 && inner >= 1 && ld_x % 4 == 0 && ld_dy % 4 == 0 && ld_dx % 4 == 0, "rmsnorm_bwd: dims must be multiples of 4");
     if (rows <= 0) return LICV_OK;
     const int nch = nch_for(dim);
     LICV_CHECK_ARG(nch > 0 && nch <= 16, "rmsnorm_bwd: row length %lld unsupported", (long long)dim);
     const dim3 grid((unsigned)((rows + BW_WAVES - 1) / BW_WAVES)), block(64 * BW_WAVES);
     hipStream_t st = (hipStream_t)stream;
-#define L(NC) rmsnorm_bwd_k<NC><<<grid, block, 0, st>>>(x, x_dtype, (const bf16_t*)w_bf16, dy, dy_dtype, dx, dx_dtype, rows, (int)dim, inner, ld_x, ld_dy, ld_dx, eps, accumulate)
+#define L(NC) rmsnorm_bwd_k<NC><<<grid, block, 0, st>>>(x, x_dtype, (const bf16_t*)w_bf16, dy, dy_dtype, dx, dx_dtype, rows, (int)dim, inner, ld_x, ld_dy, ld_dx, eps, accumulate, round_g)
     switch (nch) { case 1: L(1); break; case 2: L(2); break; case 4: L(4); break; case 8: L(8); break; default: L(16); break; }
 #undef L
     LICV_LAUNCH_CHECK();

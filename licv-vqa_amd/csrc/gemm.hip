@@ -2041,16 +2041,25 @@ void pack_gate_up_k(const bf16_t* __restrict__ g, const bf16_t* __restrict__ u, 
     }
 }
 
-// experiments live in gemm_experiments.hip
-extern "C" int licv_gemm_exp_launch(int which, const GemmArgs* g);
-extern "C" int licv_gemm_exp_knob(int knob, int value);
-extern "C" int licv_gemm_exp_debug_timestamps(void* dev_buffer);
+// The experiments (csrc/lab/gemm_experiments.hip) are NOT part of this library: they are built into liblicv_hip_lab.so, which only
+// tests and tools load, and which registers its three entry points here when it is loaded (licv_lab_register, include/licv_hip_lab.h).
+// Without the lab library a licv_gemm_select() value that names one of its kernels is an error, never a silent fallback.
+typedef int (*lab_launch_fn)(int which, const GemmArgs* g);
+typedef int (*lab_knob_fn)(int knob, int value);
+typedef int (*lab_ts_fn)(void* dev_buffer);
+static lab_launch_fn g_lab_launch = nullptr;
+static lab_knob_fn g_lab_knob = nullptr;
+static lab_ts_fn g_lab_ts = nullptr;
+extern "C" int licv_lab_register(void* launch, void* knob, void* timestamps) {
+    g_lab_launch = (lab_launch_fn)launch; g_lab_knob = (lab_knob_fn)knob; g_lab_ts = (lab_ts_fn)timestamps;
+    return LICV_OK;
+}
 
 // timing-only instrumentation (tools/gemm_phases.py, gemm_segments.py, gemm_series.py): a device buffer the diagnostic builds
 // (gemm_bf16_lean_k<0, 7 | 8 | 9>, the experiments' ping-pong kernel) write their stamps to
 extern "C" int licv_gemm_debug_timestamps(void* dev_buffer) {
     const int rc = set_dbg_ts(dev_buffer);
-    return rc != LICV_OK ? rc : licv_gemm_exp_debug_timestamps(dev_buffer);
+    return (rc != LICV_OK || !g_lab_ts) ? rc : g_lab_ts(dev_buffer);
 }
 
 static int g_fp8_flow64 = 1;       // knob 8: 0 = fp8 GEMMs stay on the 8-wave kernel with the 32-deep fp8 MFMA (A/B, tests)
@@ -2081,7 +2090,7 @@ static int g_flow_default = 1;  // auto mode takes the flow kernels where they a
 //   knob 9: timing-only ablation of the mid kernel's operand stream (1 = no A pieces, 2 = no W pieces; results are wrong)
 //   knob 10: 4 = the mid kernel keeps four K tiles in flight (nine-pair ring) wherever it fits; anything else = the five-pair ring
 extern "C" int licv_gemm_experiment(int knob, int value) {
-    if (knob == 0) return licv_gemm_exp_knob(0, value);
+    if (knob == 0) return g_lab_knob ? g_lab_knob(0, value) : licv_set_error(LICV_E_UNSUPPORTED, "gemm_experiment: knob 0 belongs to liblicv_hip_lab.so, which is not loaded");
     else if (knob == 1) g_pp_group = value; else if (knob == 2) g_flow_default = value;
     else if (knob == 4) g_splitk_enabled = value;
     else if (knob == 5) g_force_splits = value;
@@ -2242,11 +2251,12 @@ extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
     // tile-rows per XCD patch: 8 (a 32-CU XCD then works on an 8 x 4 patch); with <= 6 tile-columns an 8-row group is 40-48
     // tiles and the patch straddles two groups -> 2-row groups keep it compact (measured +6 % at N = 1280, K = 5120)
     const int pp_group = g_pp_group > 0 ? g_pp_group : (tiles_n <= 6 ? 2 : 8);
-    // a kernel of gemm_experiments.hip, by number
+    // a kernel of the lab library (csrc/lab/gemm_experiments.hip), by number
     const bool product_sel = fk == 0 || fk == 1 || fk == 20 || (fk >= 22 && fk <= 27) || (fk >= 40 && fk <= 42) || fk == 60 || fk == 70;
     if (!product_sel && K % BK == 0) {
         GemmArgs ga{A, lda, W, ldw, C, ldc, (int)M, (int)N, (int)K, ep, (hipStream_t)stream, g_pp_group, g_num_cus};
-        if (licv_gemm_exp_launch(fk, &ga) == 1) { LICV_LAUNCH_CHECK(); return LICV_OK; }
+        if (!g_lab_launch) return licv_set_error(LICV_E_UNSUPPORTED, "gemm: licv_gemm_select(%d) names a kernel of liblicv_hip_lab.so, which is not loaded", fk);
+        if (g_lab_launch(fk, &ga) == 1) { LICV_LAUNCH_CHECK(); return LICV_OK; }
     }
     // flow kernels: epilogues that need only the accumulators (and a bias row), bf16 out, whole waves in or out of N
     // ... or a bf16 residual (EPI 5: the ViT out / fc2 projections, usually in place) with no activation, gate or scale

@@ -1,6 +1,7 @@
 // GEMM kernel variants that were built, measured and NOT adopted (DESIGN.md section 5 has the numbers): kept compiled and selectable
 // through licv_gemm_select() so that the kernels-agree test keeps them bit-identical to the product kernels and A/B timings can be
-// repeated.  Nothing on the product path launches anything in this file.
+// repeated.  This file is built into liblicv_hip_lab.so (tests and tools only), NOT into liblicv_hip.so: loading the lab library
+// registers licv_gemm_exp_launch / _knob / _debug_timestamps with the product library (licv_lab_register), see the end of the file.
 //   select 2-4        gemm_bf16_tile256_k   256 x 256 x 64, two 64 KiB stages, one barrier per K tile (round 1, first version) + ablations
 //   select 5          gemm_bf16_ring_k      5-slot ring of 32-deep stages, counted vmcnt, all waves in lockstep
 //   select 6,7,10-13  gemm_bf16_pingpong_k  round-1 default: two wave groups half a stage apart (+ timing-only ablations, stamps)
@@ -926,3 +927,9 @@ extern "C" int licv_gemm_exp_launch(int which, const GemmArgs* g) {
     return 1;
 }
 
+// registration with liblicv_hip.so at load time (the lab library links against it)
+extern "C" int licv_lab_register(void* launch, void* knob, void* timestamps);
+__attribute__((constructor)) static void lab_register() {
+    (void)licv_lab_register((void*)licv_gemm_exp_launch, (void*)licv_gemm_exp_knob, (void*)licv_gemm_exp_debug_timestamps);
+}
+extern "C" int licv_lab_loaded(void) { return 1; }

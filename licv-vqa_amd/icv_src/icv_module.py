@@ -76,9 +76,13 @@ class VQAICVModule(torch.nn.Module):
 
     def calculate_kl_divergence(self, stu_logits, tea_logits):
         """mean over rows of sum_v p*(log(p+eps)-log(q+eps)), times T^2 (ref :121-134).  Rows are given as 2-D
-        (rows, V) tensors; the per-row reduction over the vocabulary is one HIP kernel."""
+        (rows, V) tensors; the per-row reduction over the vocabulary is one HIP kernel.  Differentiable like the reference's
+        formula - in the student logits and, with ``learnable_t``, in the temperature - whenever autograd is recording
+        (the same node as forward() uses, with identity row indices)."""
         n, V = stu_logits.shape
         idx = torch.arange(n, device=stu_logits.device)
+        if torch.is_grad_enabled() and (stu_logits.requires_grad or self.temperature.requires_grad):
+            return self._kl_from_rows(stu_logits, tea_logits.detach(), idx, idx)
         rows = ops.kl_rows(stu_logits if stu_logits.stride(1) == 1 else stu_logits.contiguous(),
                            tea_logits if tea_logits.stride(1) == 1 else tea_logits.contiguous(),
                            idx, idx, V, self._temperature_value(), float(self.module_cfg.kl_eps))

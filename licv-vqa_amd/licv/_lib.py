@@ -14,9 +14,14 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("LICV_HIP_LIB", _HERE / "liblicv_hip.so"))
 HEADER = _HERE.parents[1] / "include" / "licv_hip.h"
 
+LAB_PATH = Path(os.environ.get("LICV_HIP_LAB_LIB", _HERE / "liblicv_hip_lab.so"))
+LAB_HEADER = _HERE.parents[1] / "include" / "licv_hip_lab.h"
+
 LICV_BF16, LICV_F32 = 0, 1
+ABI_VERSION = 3          # == LICV_ABI_VERSION of include/licv_hip.h this binding was written against (check_exports compares both)
 
 _lib = None
+_lab = None
 
 
 class LicvError(RuntimeError):
@@ -39,9 +44,9 @@ class AttnArgs(C.Structure):
                 ("key_valid", C.c_void_p), ("img_mask", C.c_void_p), ("n_img", C.c_int64), ("img_len", C.c_int64)]
 
 
-def declared_symbols():
-    """Every function name declared in include/licv_hip.h."""
-    text = HEADER.read_text()
+def declared_symbols(header: Path = HEADER):
+    """Every function name declared in include/licv_hip.h (or the given header)."""
+    text = header.read_text()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(licv_[a-z0-9_]+)\s*\(", text)))
 
@@ -53,7 +58,7 @@ def lib() -> C.CDLL:
             raise LicvError(
                 f"{LIB_PATH} not found: the L-ICV hot path has no CPU fallback. Build it with "
                 f"`python __graft_entry__.py` (hipcc --offload-arch=gfx950).")
-        _lib = C.CDLL(str(LIB_PATH))
+        _lib = C.CDLL(str(LIB_PATH), mode=C.RTLD_GLOBAL)          # global: liblicv_hip_lab.so resolves against it
         _lib.licv_last_error.restype = C.c_char_p
         _lib.licv_version.restype = C.c_int
         _lib.licv_inject_bwd_partials.restype = C.c_int64
@@ -89,17 +94,13 @@ def lib() -> C.CDLL:
             "licv_add_rmsnorm_fwd_ws": [P, I, P, I, I64, I64, P, I, F, P, P, I64, I64, F, I, P],
             "licv_inject_renorm_pre_fwd_ws": [P, I, P, I, I64, I64, P, P, P, I64, I64, P, P, F, P],
             "licv_rotary_kv_append_ws": [P, I, I64, I64, P, P, P, P, I64, I64, I64, I64, I64, P, I64, I64, P],
-            "licv_probe_mfma_loop": [P, I, I, P],
-            "licv_probe_permlane16_swap": [P, P],
-            "licv_probe_weight_stream": [P, I64, I64, I64, I, I, I, P, P],
-            "licv_probe_lds_dma_stream": [P, I64, I64, I64, I, I, P],
             "licv_idefics_image_attention_mask": [P, P, I64, I64, I64, I64, I64, P],
             "licv_idefics2_patch_front": [P, P, P, P, P, P, I64, I64, I64, I64, I64, P],
             "licv_merge_image_rows": [P, P, P, P, P, I64, I64, I64, I64, P],
             "licv_preprocess_images": [P, P, P, P, I64, I64, I64, C.c_double, P, P, P],
             "licv_gemm_flow_available": [],
             "licv_gemm_select": [I],
-            "licv_gemm_stagger": [I],
+            "licv_lab_register": [P, P, P],
             "licv_gemm_experiment": [I, I],
             "licv_gemm_debug_timestamps": [P],
             "licv_attn_select": [I],
@@ -109,7 +110,7 @@ def lib() -> C.CDLL:
             "licv_vit_embed_ln": [P, P, P, P, P, P, I64, I64, I64, F, P],
             "licv_tile_rows": [P, P, I64, I64, I64, P],
             "licv_swiglu": [P, P, I64, I64, P],
-            "licv_rmsnorm_bwd": [P, I, P, P, I, P, I, I64, I64, I64, I64, I64, I64, F, I, P],
+            "licv_rmsnorm_bwd": [P, I, P, P, I, P, I, I64, I64, I64, I64, I64, I64, F, I, I, P],
             "licv_swiglu_bwd": [P, P, P, I64, I64, P],
             "licv_branch_grad": [P, P, I64, I64, F, I, P, P],
             "licv_attn_bwd_small": [C.POINTER(AttnArgs), P, P, I64, I64, P, P, I64, I64, P],
@@ -125,15 +126,51 @@ def lib() -> C.CDLL:
     return _lib
 
 
+def lab() -> C.CDLL:
+    """liblicv_hip_lab.so: the experiment kernels and roofline probes (include/licv_hip_lab.h).  Tests and tools only - nothing under
+    licv/ calls this.  Loading it registers the experiments with the product library's licv_gemm_select dispatch."""
+    global _lab
+    if _lab is None:
+        lib()                                                   # the lab library links against the product library
+        if not LAB_PATH.exists():
+            raise LicvError(f"{LAB_PATH} not found: build it with `python __graft_entry__.py`")
+        _lab = C.CDLL(str(LAB_PATH), mode=C.RTLD_GLOBAL)
+        P, I64, I = C.c_void_p, C.c_int64, C.c_int
+        for name, args in {"licv_lab_loaded": [], "licv_gemm_stagger": [I], "licv_probe_mfma_loop": [P, I, I, P],
+                           "licv_probe_permlane16_swap": [P, P], "licv_probe_weight_stream": [P, I64, I64, I64, I, I, I, P, P],
+                           "licv_probe_lds_dma_stream": [P, I64, I64, I64, I, I, P]}.items():
+            fn = getattr(_lab, name)
+            fn.argtypes, fn.restype = args, C.c_int
+    return _lab
+
+
+def header_abi_version() -> int:
+    m = re.search(r"#define\s+LICV_ABI_VERSION\s+(\d+)", HEADER.read_text())
+    return int(m.group(1)) if m else -1
+
+
 def check_exports():
-    """The library exports every symbol the header declares (no compute calls)."""
+    """The library exports every symbol the header declares and answers the ABI version this binding was written against
+    (no compute calls)."""
     l = lib()
     missing = [s for s in declared_symbols() if not hasattr(l, s)]
     if missing:
         raise LicvError(f"liblicv_hip.so lacks symbols declared in licv_hip.h: {missing}")
-    if l.licv_version() < 1:
-        raise LicvError("bad ABI version")
+    got = l.licv_version()
+    if got != ABI_VERSION:
+        raise LicvError(f"liblicv_hip.so answers ABI version {got}, this binding (licv/_lib.py) was written against {ABI_VERSION}: rebuild "
+                        f"with `python __graft_entry__.py`")
+    if HEADER.exists() and header_abi_version() != ABI_VERSION:
+        raise LicvError(f"include/licv_hip.h declares LICV_ABI_VERSION {header_abi_version()}, licv/_lib.py expects {ABI_VERSION}")
     return True
+
+
+def check_lab_exports():
+    l = lab()
+    missing = [s for s in declared_symbols(LAB_HEADER) if not hasattr(l, s)]
+    if missing:
+        raise LicvError(f"liblicv_hip_lab.so lacks symbols declared in licv_hip_lab.h: {missing}")
+    return l.licv_lab_loaded() == 1
 
 
 def check(status: int):

@@ -41,7 +41,8 @@ class ImageFeeder:
                      for _ in range(self.depth)]
         self.stream = torch.cuda.Stream(device=self.device)
         self.done = [None] * self.depth                     # event of the batch that last used a slot
-        self.consumed = [None] * self.depth                 # event recorded by get(): the main stream is done reading the slot's output
+        self.consumed = [None] * self.depth                 # event after which the main stream no longer reads the slot's output
+        self.handed_out = [False] * self.depth              # get() returned views of the slot and release() has not been called since
         self.turn = 0
 
     # -------------------------------------------------------------------------------------------- host side
@@ -82,7 +83,14 @@ class ImageFeeder:
         if self.done[slot] is not None:
             self.done[slot].synchronize()                   # the H2D copy out of this pinned buffer has finished
         n, ragged = self._pack(slot, images)
-        main = torch.cuda.current_stream(self.device)
+        if self.handed_out[slot]:
+            # The slot's output was handed out by get() and never release()d: the forward that reads it was issued on the caller's
+            # stream some time between that get() and now, so an event recorded on that stream NOW is behind it.  (release() marks the
+            # exact point and keeps more overlap; this is the safe default for callers that never call it.)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self.consumed[slot] = ev
+            self.handed_out[slot] = False
         with torch.cuda.stream(self.stream):
             if self.consumed[slot] is not None:
                 self.stream.wait_event(self.consumed[slot])  # the step that read this slot's output has finished with it
@@ -98,14 +106,15 @@ class ImageFeeder:
             ev = torch.cuda.Event()
             ev.record(self.stream)
         self.done[slot] = ev
-        del main
         return slot, n
 
     # -------------------------------------------------------------------------------------------- device side
     def get(self, ticket: Tuple[int, int], batch: Optional[int] = None, per_row: Optional[int] = None):
         """The current stream waits for the ticket's batch; returns (pixel_values, pixel_attention_mask or None), shaped
         (batch, per_row, 3, H, W) / (batch, per_row, H, W) when both counts are given, else (n, 3, H, W) / (n, H, W).  The tensors
-        are views of the feeder's buffers: valid until `depth` further batches have been submitted."""
+        are views of the feeder's buffers: valid for every kernel issued on the current stream until `depth` further batches have
+        been submitted (the submit that reuses the slot orders its copy behind everything the current stream holds at that point;
+        release() marks an earlier point and so keeps more of the copy / compute overlap)."""
         slot, n = ticket
         cur = torch.cuda.current_stream(self.device)
         cur.wait_event(self.done[slot])
@@ -115,15 +124,15 @@ class ImageFeeder:
             assert batch * per_row == n
             pv = pv.view(batch, per_row, 3, self.H, self.W)
             m = m.view(batch, per_row, self.H, self.W) if m is not None else None
-        ev = torch.cuda.Event()
-        ev.record(cur)                                       # (re-recorded by release() when the reader is known to be later)
-        self.consumed[slot] = ev
+        self.handed_out[slot] = True                        # until release(): submit() then orders the slot's reuse behind the reader
         return pv, m
 
     def release(self, ticket: Tuple[int, int]):
         """Mark the point on the current stream after which the ticket's output is no longer read (call after the forward that
-        consumed it was issued); get() records a first such point itself, before the consumer has been issued."""
+        consumed it was issued).  Optional: without it the submit that reuses the slot takes the state of the current stream at ITS
+        call as that point (always safe, less overlap)."""
         slot, _ = ticket
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
         self.consumed[slot] = ev
+        self.handed_out[slot] = False

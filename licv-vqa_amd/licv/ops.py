@@ -532,14 +532,15 @@ def adamw_step_(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tens
 # ------------------------------------------------------------------------------------------ backward (student pass)
 def rmsnorm_bwd(x: torch.Tensor, w: torch.Tensor, dy: torch.Tensor, dx: torch.Tensor, eps: float, accumulate: bool,
                 inner: int = 1, ld_x: Optional[int] = None, ld_dy: Optional[int] = None, ld_dx: Optional[int] = None,
-                rows: Optional[int] = None, dim: Optional[int] = None):
+                rows: Optional[int] = None, dim: Optional[int] = None, flavour: int = 0):
+    """flavour as in rmsnorm(): 0 Idefics, 1 Mistral (decides whether d(w * xhat) is a bf16 or an fp32 product, see licv_hip.h)."""
     dim = x.shape[-1] if dim is None else dim
     rows = x.numel() // dim if rows is None else rows
     ld_x = dim * inner if ld_x is None else ld_x
     ld_dy = dim * inner if ld_dy is None else ld_dy
     ld_dx = dim * inner if ld_dx is None else ld_dx
     check(_lib.lib().licv_rmsnorm_bwd(_p(x), _dt(x), _p(w), _p(dy), _dt(dy), _p(dx), _dt(dx), rows, dim, inner, ld_x, ld_dy, ld_dx,
-                                      float(eps), 1 if accumulate else 0, _stream(x)))
+                                      float(eps), 1 if accumulate else 0, flavour, _stream(x)))
     return dx
 
 

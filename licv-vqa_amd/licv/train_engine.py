@@ -292,7 +292,7 @@ class StudentPass2:
         d_xf = torch.zeros((M, H), dtype=torch.bfloat16, device=dev)
         d_xf.index_copy_(0, st["logits_rows"], ops.linear(dlogits_rows, tw.head_T))
         dh = torch.empty((M, H), dtype=torch.float32, device=dev)
-        ops.rmsnorm_bwd(st["h_final"], w.final_ln, d_xf, dh, a.rms_eps, accumulate=False)
+        ops.rmsnorm_bwd(st["h_final"], w.final_ln, d_xf, dh, a.rms_eps, accumulate=False, flavour=1)
         for l in reversed(range(a.num_layers)):
             rec, L, T = st["layers"][l], w.text[l], tw.text[l]
             # MLP branch: hooked -> through the edit's backward, else straight
@@ -307,7 +307,7 @@ class StudentPass2:
             d_act = ops.linear(d_out, T["down_T"])
             d_gu = ops.swiglu_bwd(rec["gu"], d_act)
             d_x = ops.linear(d_gu, T["gu_T"])
-            ops.rmsnorm_bwd(rec["h_mid"], L.post_ln, d_x, dh, a.rms_eps, accumulate=True)
+            ops.rmsnorm_bwd(rec["h_mid"], L.post_ln, d_x, dh, a.rms_eps, accumulate=True, flavour=1)
             # attention branch (GQA): dK / dV per query head, then the group sum = backward of repeat_kv
             d_attn = ops.linear(ops.branch_grad(dh), T["o_T"])
             qkv = rec["qkv"]
@@ -320,5 +320,5 @@ class StudentPass2:
             ops.head_group_sum(dkv_heads.view(-1)[qd:], dqkv.view(-1)[qd + kd:], M, nkv, rep, hd, 2 * qd, ldq)
             ops.rotary_(dqkv, w.cos, tw.neg_sin, st["pos"], M, nh + nkv, hd, ldq, 0, 1)      # inverse rotation of dQ and dK
             d_x = ops.linear(dqkv, T["qkv_T"])
-            ops.rmsnorm_bwd(rec["h_in"], L.in_ln, d_x, dh, a.rms_eps, accumulate=True)
+            ops.rmsnorm_bwd(rec["h_in"], L.in_ln, d_x, dh, a.rms_eps, accumulate=True, flavour=1)
         return grad_v

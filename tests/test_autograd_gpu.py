@@ -180,3 +180,26 @@ def test_module_with_learnable_t_fills_temperature_grad_and_caches_the_host_valu
     with torch.no_grad():
         mod.temperature.mul_(0.5)
     assert mod._temperature_value() == 1.0
+
+
+def test_calculate_kl_divergence_is_differentiable_in_temperature_like_the_reference_formula(golden):
+    """The public method (ref:icv_src/icv_module.py:121-134) and the forward()'s row-index form give the same temperature gradient
+    with learnable_t; without grad recording the method stays the plain kernel call."""
+    from oracle import icv_ref as O
+    mod = _module(temp=2.0)
+    mod.temperature.requires_grad_(True)
+    g_ = torch.Generator().manual_seed(3)
+    stu = (torch.randn(11, 98, generator=g_) * 2).to(DEV)
+    tea = (torch.randn(11, 98, generator=g_) * 2).to(DEV)
+    s_in = stu.clone().requires_grad_(True)
+    kl = mod.calculate_kl_divergence(s_in, tea)
+    kl.backward()
+    t64 = torch.tensor(2.0, dtype=torch.float64, requires_grad=True)
+    s64 = stu.double().cpu().requires_grad_(True)
+    ref = O.kl_divergence(s64, tea.double().cpu(), t64, 1e-6)
+    ref.backward()
+    assert abs(float(kl) - float(ref)) <= 1e-4 * abs(float(ref))
+    assert abs(float(mod.temperature.grad) - float(t64.grad)) <= 2e-3 * abs(float(t64.grad)) + 1e-6
+    assert (s_in.grad.float().cpu() - s64.grad.float()).abs().max() <= 2 ** -7 * s64.grad.abs().max()
+    with torch.no_grad():
+        assert abs(float(mod.calculate_kl_divergence(stu, tea)) - float(ref)) <= 1e-4 * abs(float(ref))

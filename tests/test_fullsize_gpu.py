@@ -195,40 +195,50 @@ def test_fullsize_training_micro_batch_properties(full):
         assert log["grad_norm"] > 0 and log["kl_loss"] == log["loss"]
 
 
-def test_fullsize_idefics2_fp8_32shot_properties():
-    """BASELINE configs[4] shape: Idefics2-8B at FULL depth, 32 shots (33 images of 378 x 504 per question, S = 2900), text stack on
-    fp8 operands; two questions (the bench runs eight).  No reference has an fp8 mode, so at this size: F1 two runs are
-    bit-identical; F2 every logit is finite and the hook still preserves the norm of every token's MLP branch and promotes the
-    stream; F3 the fp8 logits stay within the quantisation-noise bar of the bf16 engine on the same weights (per-position cosine,
-    printed with the relative L2); F4 all four projections of every text layer carry fp8 weights."""
+@pytest.mark.parametrize("fp8_vision,B", [(False, 2), (True, 8)], ids=["fp8_text_bs2", "fp8_text_and_vision_bs8"])
+def test_fullsize_idefics2_fp8_32shot_properties(fp8_vision, B):
+    """BASELINE configs[4] shape: Idefics2-8B at FULL depth, 32 shots (33 images of 378 x 504 per question, S = 2900).
+    `fp8_text_and_vision_bs8` is the bench's own configuration (bench.py workload idefics2_8b_32shot_fp8_bs8: eight questions, text
+    stack AND SigLIP tower on fp8 operands); `fp8_text_bs2` keeps the vision side bf16 (shared by both engines) so that the text
+    stack's quantisation noise is seen alone.  No reference has an fp8 mode, so at this size: F1 two runs are bit-identical; F2 every
+    logit is finite and the hook still preserves the norm of every token's MLP branch and promotes the stream; F3 the fp8 logits stay
+    within the quantisation-noise bar of the bf16 engine on the same weights (per-position cosine, printed with the relative L2);
+    F4 all four projections of every text layer (and of every SigLIP layer) carry fp8 weights."""
     from licv.config import IDEFICS2_8B
     from licv.idefics2_engine import Idefics2Engine, Idefics2Weights
     from licv.synthetic import synth_idefics2_weights, synth_vqa_batch_idefics2
     arch = IDEFICS2_8B
     sd = trained_like_(synth_idefics2_weights(arch, seed=426, dtype=torch.bfloat16, device=DEV), arch.num_layers)
-    e8 = Idefics2Engine(Idefics2Weights(sd, arch, DEV, fp8_text=True))
+    e8 = Idefics2Engine(Idefics2Weights(sd, arch, DEV, fp8_text=True, fp8_vision=fp8_vision))
     e16 = Idefics2Engine(Idefics2Weights(sd, arch, DEV))
     del sd
     torch.cuda.empty_cache()
     assert all(set(L.q8) == {"qkv_w", "o_w", "gu_w", "down_w"} for L in e8.w.text)                     # F4
-    batch = synth_vqa_batch_idefics2(arch, 2, 2900, 33, 378, 504, seed=426, min_len=2800, dtype=torch.bfloat16, device=DEV, ragged=False)
+    if fp8_vision:
+        assert all(set(L.q8) == {"qkv_w", "out_w", "fc1_w", "fc2_w"} for L in e8.w.vit)
+    batch = synth_vqa_batch_idefics2(arch, B, 2900, 33, 378, 504, seed=426, min_len=2800, dtype=torch.bfloat16, device=DEV, ragged=False)
     icv, alpha = synth_icv(arch.num_layers, arch.hidden_size, seed=426, alpha=0.1, device=DEV)
     layers = list(range(arch.num_layers))
     scaled = alpha.unsqueeze(-1) * icv
-    img = e8.encode_images(batch["pixel_values"], batch["pixel_attention_mask"])                        # the vision side is bf16 in both
-    ins = dict(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], image_hidden_states=img)
+    if fp8_vision:                                                      # each engine runs its own tower from the pixels
+        ins8 = ins16 = dict(batch)
+    else:
+        img = e8.encode_images(batch["pixel_values"], batch["pixel_attention_mask"])                    # the vision side is bf16 in both
+        ins8 = ins16 = dict(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], image_hidden_states=img)
     cap = {}
-    lg8 = e8.forward(**ins, icv=scaled, hook_layers=layers, capture=cap).clone()
+    lg8 = e8.forward(**ins8, icv=scaled, hook_layers=layers, capture=cap).clone()
     assert torch.isfinite(lg8.float()).all()                                                              # F2
     assert all(t.dtype == torch.float32 for t in cap["layer_out"]) and cap["mlp_raw"][0].dtype == torch.bfloat16
     del cap
-    assert torch.equal(lg8, e8.forward(**ins, icv=scaled, hook_layers=layers))                           # F1
-    lg16 = e16.forward(**ins, icv=scaled, hook_layers=layers)
+    torch.cuda.empty_cache()
+    assert torch.equal(lg8, e8.forward(**ins8, icv=scaled, hook_layers=layers))                          # F1
+    lg16 = e16.forward(**ins16, icv=scaled, hook_layers=layers)
     valid = batch["attention_mask"].bool()
     a, b = lg16.float()[valid], lg8.float()[valid]
     rel = float((a - b).norm() / a.norm())
     cos = torch.nn.functional.cosine_similarity(a, b, dim=-1)
-    print(f"\n  F3 idefics2-8b 32-shot, fp8 text stack vs bf16 engine at full depth: relative L2 {rel:.3f}, cosine min {float(cos.min()):.4f} mean {float(cos.mean()):.4f}")
+    what = "fp8 text stack + fp8 SigLIP tower" if fp8_vision else "fp8 text stack"
+    print(f"\n  F3 idefics2-8b 32-shot, B = {B}, {what} vs bf16 engine at full depth: relative L2 {rel:.3f}, cosine min {float(cos.min()):.4f} mean {float(cos.mean()):.4f}")
     assert rel <= F3_REL and float(cos.min()) >= F3_COS                                                  # F3
 
 

@@ -1,0 +1,340 @@
+"""Full-WIDTH parity of the two paths the reference actually hooks (the toy-size fixtures g6 / g9 / g15 / g16 cannot see a
+K = 4096 / 11008 / 22016 accumulation, head_dim 128 x 32 heads, the 32002-wide head, the split-K dgrad route or the M = 24 decode
+kernels):
+
+  W5  the training signal — d loss / d icv and d loss / d alpha of ref:icv_src/icv_module.py:97-118 (hooked student forward with
+      grad, unhooked teacher, masked KL) through ICVTrainer.loss_and_backward (explicit HIP backward, csrc/backward.hip + the
+      transposed-weight dgrad GEMMs) against torch autograd through the CPU oracle in bf16 AND fp32.  Idefics-9B widths (H 4096,
+      I 11008, V 32002, 32 x 128 heads; 2 ViT layers, 2 perceiver blocks, 1 gated cross-attention layer, 4 decoder layers), B = 8,
+      student S = 32; and Idefics2-8B widths (Mistral 32q / 8kv x 128, I 14336, V 32003, hook on the `.mlp` branch; 4 text layers).
+  W6  hooked generate — ref:inference.py:300-321 with ref:config/inference.yaml:26-30 (3 beams, 5 new tokens, length_penalty 0)
+      at Idefics-9B widths truncated to 4 and to 8 decoder layers, B = 8, against oracle/generate_ref.py: token ids, and the
+      logits of every model call (prefill + each decode step) while both searches are in the same state.
+
+Bars.  Gradients and logits go through the three-part W-bar of tests/test_fullwidth_gpu.py (the engine may be no less accurate
+than the reference's own bf16 path, measured against the fp32 oracle):
+  (i)   max|hip - bf16_gold| <= max(1.5e-2 * scale, 1.5 * max|bf16_gold - f32_gold|)
+  (ii)  max|hip - f32_gold|  <= 1.5 * max|bf16_gold - f32_gold| + 1e-3 * scale
+  (iii) relative L2 |hip - f32_gold| / |f32_gold| <= 1.25 * the same figure of the bf16 oracle + 1e-4
+Token ids are integers: a row must be IDENTICAL to the oracle's bf16 decode whenever the oracle itself decides that row by more than
+its own bf16-vs-fp32 noise — operationally: the fp32 oracle returns the same row, and so do N_JITTER re-decodes of the bf16 oracle
+with every logit moved by uniform noise whose variance is that of the measured bf16-vs-fp32 logit deviation of that question (per
+unit of head-row norm: a logit's error is proportional to the norm of its head row) — the full-width form of the stability column
+of fixtures g11 / g15 (measured on the CPU: 4 of 8 rows decided at either depth).
+The number of decided rows is printed and must be positive.  A random-init head gives 32002 near-Gaussian logits whose top
+candidates sit closer together than bf16 noise (measured: 0 - 2 of 8 rows decided), so — as fixtures g15 / g16 scale the embedding
+and the head to get decisive prompts — the head rows get log-normal norms (exp(N(0, 1)), seeded): a peaked next-token
+distribution like a trained model's, same kernels, same widths.
+
+d loss / d alpha has only as many entries as hooked layers (4): its own bf16-vs-fp32 spread is a 4-sample estimate (measured 9.5e-3
+for one model, 6.0e-2 for the other).  d alpha_l = sigmoid'(a_l) <icv_l, d loss / d v_l> is a projection of the same per-layer
+gradient whose noise the 16384-entry d loss / d icv measures, so its bar takes the LARGER of its own spread and the icv gradient's
+relative spread (same factor 1.5 / 1.25).
+"""
+import time
+
+import pytest
+import torch
+
+from licv.config import IDEFICS2_8B, IDEFICS_9B
+from licv.synthetic import (synth_idefics2_weights, synth_idefics_weights, synth_vqa_batch, synth_vqa_batch_idefics2,
+                            trained_like_)
+from oracle import generate_ref as G
+from oracle import icv_ref as O
+from oracle import idefics2_ref as R2
+from oracle import idefics_ref as R
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+N_JITTER = 6
+
+
+def _wbar(hip, gold_bf16, gold_f32, what, report, rel_floor=None):
+    """rel_floor = (relative max spread, relative L2 spread) of a LARGER tensor carrying the same noise (see the module docstring):
+    the reference's own noise level is then taken as at least that."""
+    hip = hip.float().cpu().reshape(gold_bf16.shape)
+    gold_bf16, gold_f32 = gold_bf16.float(), gold_f32.float()
+    scale = float(gold_f32.abs().max())
+    e_gold, e_true = float((hip - gold_bf16).abs().max()), float((hip - gold_f32).abs().max())
+    spread = float((gold_bf16 - gold_f32).abs().max())
+    r_hip = float((hip - gold_f32).norm() / gold_f32.norm())
+    r_ref = float((gold_bf16 - gold_f32).norm() / gold_f32.norm())
+    if rel_floor is not None:
+        spread, r_ref = max(spread, rel_floor[0] * scale), max(r_ref, rel_floor[1])
+    cos = torch.nn.functional.cosine_similarity(hip.reshape(1, -1), gold_f32.reshape(1, -1)).item()
+    report.append(f"{what}: max |hip-bf16| {e_gold / scale:.2e} |hip-f32| {e_true / scale:.2e} oracle |bf16-f32| {spread / scale:.2e} of scale "
+                  f"{scale:.3g}; relative L2 vs f32: hip {r_hip:.2e}, oracle bf16 {r_ref:.2e}; cosine(hip, f32) {cos:.6f}")
+    assert e_gold <= max(1.5e-2 * scale, 1.5 * spread), f"{what}: |hip-bf16 gold| {e_gold:.3e} vs scale {scale:.3e}, spread {spread:.3e}"
+    assert e_true <= 1.5 * spread + 1e-3 * scale, f"{what}: |hip-f32 gold| {e_true:.3e} vs oracle spread {spread:.3e}"
+    assert r_hip <= 1.25 * r_ref + 1e-4, f"{what}: relative L2 vs f32 {r_hip:.3e} (hip) vs {r_ref:.3e} (oracle bf16)"
+
+
+def _rel_spread(gold_bf16, gold_f32):
+    d = gold_bf16.float() - gold_f32.float()
+    return float(d.abs().max() / gold_f32.float().abs().max()), float(d.norm() / gold_f32.float().norm())
+
+
+def _cpu(sd, dtype):
+    return {k: v.to("cpu", dtype) for k, v in sd.items()}
+
+
+MOD_CFG = dict(hard_loss_weight=0.0, only_hard_loss=False, kl_eps=1e-6, init_temperature=1.0, learnable_t=False, decay_ratio=-1,
+               decay_per_step=-1, min_tmeprature=1.0, alpha_lr=1e-2, icv_lr=1e-4, weight_decay=1e-3, warm_steps=0.1,
+               icv_encoder=dict(use_sigmoid=True, alpha_learnable=True, alpha_init_value=-2.0))     # sigmoid(-2) = 0.12: a live hook
+
+
+def _share_answers(stu, tea, pad, ans=4):
+    """The collator contract (ref:icv_src/icv_datamodule.py:73-130): student and teacher end in the same answer tokens; returns
+    (query_x_length, in_context_length) = the positions where the answers start."""
+    ls, lt = stu["attention_mask"].sum(1), tea["attention_mask"].sum(1)
+    for b in range(stu["input_ids"].shape[0]):
+        a = tea["input_ids"][b, int(lt[b]) - ans: int(lt[b])]
+        a = torch.where(a == pad, torch.full_like(a, 5), a)
+        tea["input_ids"][b, int(lt[b]) - ans: int(lt[b])] = a
+        stu["input_ids"][b, int(ls[b]) - ans: int(ls[b])] = a
+    return ls - ans, lt - ans
+
+
+# =========================================================================================================== W5
+def test_w5_idefics9b_widths_gradients_vs_oracle_autograd():
+    from icv_src.icv_module import VQAICVModule
+    from licv import ops
+    from licv.trainer import ICVTrainer
+    from lmm_icl_interface import IdeficsInterface
+    torch.set_num_threads(max(torch.get_num_threads(), 8))
+    nl = 4
+    arch = IDEFICS_9B.with_(v_layers=2, r_depth=2, num_layers=nl)
+    assert arch.num_cross_layers == 1
+    sd = trained_like_(synth_idefics_weights(arch, seed=951, dtype=torch.float32, device=DEV), nl)
+    iface = IdeficsInterface(state_dict=sd, arch=arch, device=DEV)
+    lmm_cfg = dict(intervention_layer=-1, layer_format="model.model.layers.<LAYER_NUM>", total_layers=nl, hidden_size=arch.hidden_size)
+    torch.manual_seed(952)
+    mod = VQAICVModule(iface, MOD_CFG, lmm_cfg).to(DEV)
+    with torch.no_grad():
+        mod.icv_encoder.icv.mul_(5.0)                                        # N(0, 0.05) x sigmoid(-2): a visible intervention
+    B = 8
+    stu = synth_vqa_batch(arch, B, 32, 1, seed=953, min_len=24, dtype=torch.float32)
+    tea = synth_vqa_batch(arch, B, 96, 3, seed=954, min_len=80, dtype=torch.float32)
+    qx, icl = _share_answers(stu, tea, arch.pad_token_id)
+    # the student's dgrad GEMMs at these widths: (256 x 4096 x 22016) d x = d gu . [gate|up] takes the split-K route
+    M = B * 32
+    plan = {k: ops._splitk_plan(M, n, kk)[0] for k, (n, kk) in dict(gu_T=(arch.hidden_size, 2 * arch.intermediate_size),
+            down_T=(arch.intermediate_size, arch.hidden_size), qkv_T=(arch.hidden_size, 3 * arch.hidden_size)).items()}
+    assert plan["gu_T"] > 1, f"the K = {2 * arch.intermediate_size} dgrad GEMM no longer takes the split-K route: {plan}"
+    tr = ICVTrainer(mod, total_steps=20, accumulate_grad_batches=1, grad_clip=1.0)
+    t0 = time.perf_counter()
+    kl = tr.loss_and_backward(stu, tea, qx, icl)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    got = dict(icv=mod.icv_encoder.icv.grad.detach().cpu().clone(), alpha=mod.icv_encoder.alpha.grad.detach().cpu().clone(), kl=float(kl))
+    layers = list(range(nl))
+    smask, tmask = O.get_mask(stu["input_ids"], qx, arch.pad_token_id), O.get_mask(tea["input_ids"], icl, arch.pad_token_id)
+    assert int(smask.sum()) == int(tmask.sum()) == 4 * B
+    gold, tm = {}, {}
+    for name, dt in (("bf16", torch.bfloat16), ("f32", torch.float32)):
+        s_ = _cpu(sd, dt)
+        cast = lambda d: {k: (v.to(dt) if v.is_floating_point() else v) for k, v in d.items()}
+        icv = mod.icv_encoder.icv.detach().cpu().clone().requires_grad_(True)
+        alpha = mod.icv_encoder.alpha.detach().cpu().clone().requires_grad_(True)
+        ta = time.perf_counter()
+        lg_s = R.forward(s_, arch, **cast(stu), icv=O.scale_icv(O.encoder_alpha(alpha, True), icv), hook_layers=layers)
+        with torch.no_grad():
+            lg_t = R.forward(s_, arch, **cast(tea))
+        ref_kl = O.kl_divergence(lg_s[smask], lg_t[tmask], 1.0, 1e-6)
+        ref_kl.backward()
+        tm[name] = time.perf_counter() - ta
+        gold[name] = dict(icv=icv.grad.clone(), alpha=alpha.grad.clone(), kl=float(ref_kl))
+        del s_, lg_s, lg_t
+    rep = [f"split-K plan of the dgrad GEMMs at M = {M}: {plan}; native fwd+bwd (cold) {t1 - t0:.2f}s, CPU oracle autograd bf16 {tm['bf16']:.1f}s "
+           f"fp32 {tm['f32']:.1f}s", f"KL: native {got['kl']:.5f} oracle bf16 {gold['bf16']['kl']:.5f} fp32 {gold['f32']['kl']:.5f}"]
+    print("\n  W5 " + "\n  W5 ".join(rep))
+    assert abs(got["kl"] - gold["f32"]["kl"]) <= 1.5 * abs(gold["bf16"]["kl"] - gold["f32"]["kl"]) + 0.05 * abs(gold["f32"]["kl"]) + 1e-3
+    rep = []
+    try:
+        _wbar(got["icv"], gold["bf16"]["icv"], gold["f32"]["icv"], "d loss / d icv (4 x 4096)", rep)
+        _wbar(got["alpha"], gold["bf16"]["alpha"], gold["f32"]["alpha"], "d loss / d alpha (4)", rep,
+              rel_floor=_rel_spread(gold["bf16"]["icv"], gold["f32"]["icv"]))
+    finally:
+        print("  W5 " + "\n  W5 ".join(rep))
+
+
+def test_w5_idefics2_8b_widths_gradients_vs_oracle_autograd():
+    from icv_src.icv_module import VQAICVModule
+    from licv import ops
+    from licv.trainer import ICVTrainer
+    from lmm_icl_interface import Idefics2Interface
+    torch.set_num_threads(max(torch.get_num_threads(), 8))
+    nl = 4
+    arch = IDEFICS2_8B.with_(v_layers=2, r_depth=2, num_layers=nl)
+    sd = trained_like_(synth_idefics2_weights(arch, seed=961, dtype=torch.float32, device=DEV), nl)
+    iface = Idefics2Interface(state_dict=sd, arch=arch, device=DEV)
+    lmm_cfg = dict(intervention_layer=-1, layer_format="model.model.text_model.layers.<LAYER_NUM>.mlp", total_layers=nl,
+                   hidden_size=arch.hidden_size)
+    torch.manual_seed(962)
+    mod = VQAICVModule(iface, MOD_CFG, lmm_cfg).to(DEV)
+    with torch.no_grad():
+        mod.icv_encoder.icv.mul_(5.0)
+    B, S = 8, 96                                                             # one 64-latent image + the question; Sq * Sk <= 16384
+    stu = synth_vqa_batch_idefics2(arch, B, S, 1, 98, 126, seed=963, min_len=88, dtype=torch.float32, ragged=True)
+    tea = synth_vqa_batch_idefics2(arch, B, 176, 2, 98, 126, seed=964, min_len=160, dtype=torch.float32, ragged=True)
+    qx, icl = _share_answers(stu, tea, arch.pad_token_id)
+    M = B * S
+    plan = {k: ops._splitk_plan(M, n, kk)[0] for k, (n, kk) in dict(gu_T=(arch.hidden_size, 2 * arch.intermediate_size),
+            down_T=(arch.intermediate_size, arch.hidden_size)).items()}
+    tr = ICVTrainer(mod, total_steps=20, accumulate_grad_batches=1, grad_clip=1.0)
+    kl = tr.loss_and_backward(stu, tea, qx, icl)
+    torch.cuda.synchronize()
+    got = dict(icv=mod.icv_encoder.icv.grad.detach().cpu().clone(), alpha=mod.icv_encoder.alpha.grad.detach().cpu().clone(), kl=float(kl))
+    layers = list(range(nl))
+    smask, tmask = O.get_mask(stu["input_ids"], qx, arch.pad_token_id), O.get_mask(tea["input_ids"], icl, arch.pad_token_id)
+    gold, tm = {}, {}
+    for name, dt in (("bf16", torch.bfloat16), ("f32", torch.float32)):
+        s_ = _cpu(sd, dt)
+        cast = lambda d: {k: (v.to(dt) if v.is_floating_point() else v) for k, v in d.items()}
+        icv = mod.icv_encoder.icv.detach().cpu().clone().requires_grad_(True)
+        alpha = mod.icv_encoder.alpha.detach().cpu().clone().requires_grad_(True)
+        ta = time.perf_counter()
+        with torch.autocast("cpu", dtype=torch.bfloat16, enabled=(dt == torch.bfloat16)):            # the reference's Idefics2 regime
+            lg_s = R2.forward(s_, arch, **cast(stu), icv=O.scale_icv(O.encoder_alpha(alpha, True), icv), hook_layers=layers)
+            with torch.no_grad():
+                lg_t = R2.forward(s_, arch, **cast(tea))
+            ref_kl = O.kl_divergence(lg_s[smask], lg_t[tmask], 1.0, 1e-6)
+        ref_kl.backward()
+        tm[name] = time.perf_counter() - ta
+        gold[name] = dict(icv=icv.grad.clone(), alpha=alpha.grad.clone(), kl=float(ref_kl))
+        del s_, lg_s, lg_t
+    print(f"\n  W5 idefics2: split-K plan at M = {M}: {plan}; CPU oracle autograd bf16 {tm['bf16']:.1f}s fp32 {tm['f32']:.1f}s; "
+          f"KL native {got['kl']:.5f} oracle bf16 {gold['bf16']['kl']:.5f} fp32 {gold['f32']['kl']:.5f}")
+    assert abs(got["kl"] - gold["f32"]["kl"]) <= 1.5 * abs(gold["bf16"]["kl"] - gold["f32"]["kl"]) + 0.05 * abs(gold["f32"]["kl"]) + 1e-3
+    rep = []
+    try:
+        _wbar(got["icv"], gold["bf16"]["icv"], gold["f32"]["icv"], "idefics2 d loss / d icv (4 x 4096)", rep)
+        _wbar(got["alpha"], gold["bf16"]["alpha"], gold["f32"]["alpha"], "idefics2 d loss / d alpha (4)", rep,
+              rel_floor=_rel_spread(gold["bf16"]["icv"], gold["f32"]["icv"]))
+    finally:
+        print("  W5 " + "\n  W5 ".join(rep))
+
+
+# =========================================================================================================== W6
+class _Recorder:
+    """Wraps the model side of a search (oracle or native): records the logits of every call, the ids fed to every step and every
+    beam reorder, optionally moving the logits by uniform noise (the stability re-decodes)."""
+
+    def __init__(self, inner, noise=None, gen=None):
+        self.inner, self.noise, self.gen = inner, noise, gen
+        self.logits, self.fed, self.order = [], [], []
+
+    def _out(self, lg):
+        lg = lg.float()
+        if self.noise is not None:                       # (B, V) amplitudes: every beam row of a question gets the question's envelope
+            n = self.noise.to(lg.device)
+            lg = lg + (torch.rand(lg.shape, generator=self.gen).to(lg.device) * 2 - 1) * n.repeat_interleave(lg.shape[0] // n.shape[0], 0)
+        self.logits.append(lg.cpu())
+        return lg
+
+    def prefill(self, ids, am):
+        return self._out(self.inner.prefill(ids, am))
+
+    def step(self, new_ids, am):
+        self.fed.append(new_ids.reshape(-1).cpu().clone())
+        return self._out(self.inner.step(new_ids, am))
+
+    def reorder(self, flat):
+        self.order.append(flat.reshape(-1).cpu().clone())
+        self.inner.reorder(flat)
+
+    def replicate(self, nb):
+        self.inner.replicate(nb)
+
+
+def _oracle_decode(sd, arch, batch, hooks, nb, noise=None, seed=0):
+    m = G._IdeficsModel(sd, arch, batch["pixel_values"], batch["image_attention_mask"], nb, hooks)
+    rec = _Recorder(m, noise, torch.Generator().manual_seed(seed))
+    with torch.no_grad():
+        ids = G._decode(rec, arch, batch["input_ids"], batch["attention_mask"], max_new_tokens=5, num_beams=nb, length_penalty=0.0,
+                        min_new_tokens=0)
+    return ids, rec
+
+
+def _same_row(a, b, q):
+    n = max(a.shape[1], b.shape[1])
+    pa = torch.nn.functional.pad(a[q], (0, n - a.shape[1]), value=-1)
+    pb = torch.nn.functional.pad(b[q], (0, n - b.shape[1]), value=-1)
+    return bool((pa == pb).all())
+
+
+@pytest.mark.parametrize("nl,side", [(4, "left"), (8, "right")], ids=["4_layers_left_padded", "8_layers_right_padded"])
+def test_w6_idefics9b_widths_hooked_beam_generate_vs_oracle(nl, side):
+    from licv import generation as NG
+    from licv.idefics_engine import IdeficsEngine, IdeficsWeights
+    torch.set_num_threads(max(torch.get_num_threads(), 8))
+    arch = IDEFICS_9B.with_(v_layers=1, r_depth=1, num_layers=nl)
+    sd = trained_like_(synth_idefics_weights(arch, seed=971 + nl, dtype=torch.bfloat16, device=DEV), nl)
+    # a peaked next-token distribution: log-normal head-row norms (module docstring)
+    row_scale = torch.exp(torch.randn(arch.vocab_size, generator=torch.Generator().manual_seed(974)))
+    sd["lm_head.weight"] = (sd["lm_head.weight"].float() * row_scale.to(DEV)[:, None]).to(torch.bfloat16)
+    eng = IdeficsEngine(IdeficsWeights(sd, arch, DEV))
+    B, nb = 8, 3
+    batch = synth_vqa_batch(arch, B, 32, 1, seed=972 + nl, min_len=24, dtype=torch.bfloat16, padding_side=side)
+    layers = list(range(nl))
+    icv = torch.randn(1, nl, arch.hidden_size, generator=torch.Generator().manual_seed(973)) * 0.05
+    hooks = dict(icv=icv, hook_layers=layers)
+    # ---- native search, model side wrapped by the recorder (same engine.forward / KV cache / runner as interface.generate)
+    dev_batch = {k: v.to(DEV) for k, v in batch.items()}
+    model = NG._IdeficsDecoder(eng, dev_batch["pixel_values"], dev_batch["image_attention_mask"], B, 32 + 5, dict(icv=icv.to(DEV), hook_layers=layers))
+    nrec = _Recorder(model)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        got = NG._decode(nrec, arch, dev_batch["input_ids"], dev_batch["attention_mask"], max_new_tokens=5, num_beams=nb, length_penalty=0.0,
+                         min_new_tokens=0).cpu()
+    t_native = time.perf_counter() - t0
+    plain = NG.generate(eng, **dev_batch, icv=icv.to(DEV), hook_layers=layers, max_new_tokens=5, num_beams=nb, length_penalty=0.0).cpu()
+    assert torch.equal(got, plain), "the recorded search differs from licv.generation.generate"
+    # ---- oracle: bf16 (the reference's regime), fp32, and the jittered bf16 re-decodes
+    s16 = _cpu(sd, torch.bfloat16)
+    t0 = time.perf_counter()
+    ids16, r16 = _oracle_decode(s16, arch, batch, hooks, nb)
+    t_oracle = time.perf_counter() - t0
+    s32 = {k: v.float() for k, v in s16.items()}
+    b32 = {k: (v.float() if v.is_floating_point() else v) for k, v in batch.items()}
+    ids32, r32 = _oracle_decode(s32, arch, b32, hooks, nb)
+    del s32
+    pre16, pre32 = r16.logits[0][::nb], r32.logits[0][::nb]                 # the oracle prefills B * nb identical rows, like HF
+    # per question: the oracle's own bf16-vs-fp32 logit noise per unit of head-row norm (rms over the vocabulary), spread back over the
+    # rows as the half-width of a uniform distribution of the same variance
+    wn = torch.cat([s16["lm_head.weight"], s16["lm_head.additional_fc.weight"]]).float().norm(dim=1)
+    envelope = ((pre16 - pre32) / wn[None]).pow(2).mean(dim=1, keepdim=True).sqrt() * wn[None] * 3 ** 0.5           # (B, V)
+    decided = torch.tensor([_same_row(ids16, ids32, q) for q in range(B)])
+    for j in range(N_JITTER):
+        idsj, _ = _oracle_decode(s16, arch, batch, hooks, nb, noise=envelope, seed=980 + j)
+        decided &= torch.tensor([_same_row(ids16, idsj, q) for q in range(B)])
+    same = torch.tensor([_same_row(got, ids16, q) for q in range(B)])
+    same32 = torch.tensor([_same_row(got, ids32, q) for q in range(B)])
+    print(f"\n  W6 {nl} layers, {side}-padded prompts, B = {B}, {nb} beams x 5 tokens: native {t_native:.2f}s, CPU oracle bf16 {t_oracle:.1f}s; "
+          f"rows identical to the bf16 oracle {int(same.sum())}/{B}, to the fp32 oracle {int(same32.sum())}/{B}; decided by more than the "
+          f"oracle's own noise (fp32 + {N_JITTER} jittered re-decodes agree) {int(decided.sum())}/{B}; bf16 and fp32 oracles agree on "
+          f"{sum(_same_row(ids16, ids32, q) for q in range(B))}/{B}")
+    assert int(decided.sum()) > 0, "no row of this batch is decided by more than the oracle's own bf16 noise: the id check would be vacuous"
+    assert bool(same[decided].all()), f"rows decided by more than bf16 noise differ: {(~same & decided).nonzero().flatten().tolist()}"
+    # ---- logits of every model call while the two searches are in the same state (same fed ids, same beam order so far)
+    rep = []
+    in_sync = torch.ones(B, dtype=torch.bool)
+    n_calls = min(len(nrec.logits), len(r16.logits), len(r32.logits))
+    try:
+        _wbar(nrec.logits[0], pre16, pre32, "prefill logits (last prompt position, 32002 wide)", rep)
+        for t in range(1, n_calls):
+            for q in range(B):
+                sl = slice(q * nb, (q + 1) * nb)
+                if in_sync[q]:
+                    ok = all(torch.equal(a.fed[t - 1][sl], nrec.fed[t - 1][sl]) for a in (r16, r32))
+                    # the native search reorders after its exit test, the oracle before: compare the orders that fed call t
+                    ok = ok and all(len(a.order) >= t and torch.equal(a.order[t - 1][sl], nrec.order[t - 1][sl]) for a in (r16, r32))
+                    in_sync[q] = ok
+            if not bool(in_sync.any()):
+                break
+            rows = in_sync.repeat_interleave(nb)
+            _wbar(nrec.logits[t][rows], r16.logits[t][rows], r32.logits[t][rows],
+                  f"decode step {t} logits ({int(in_sync.sum())} questions in the same search state, {int(rows.sum())} beam rows)", rep)
+    finally:
+        print("  W6 " + "\n  W6 ".join(rep))
+    assert len(rep) >= 3, "fewer than two decode steps could be compared"

@@ -90,3 +90,33 @@ def test_interface_feeder_feeds_the_forward(golden):
     a = iface(**kw, pixel_values=pv)["logits"]
     b = iface(**kw, pixel_values=T(ref).to(torch.bfloat16).view(2, 2, 3, side, side).to(DEV))["logits"]
     assert torch.equal(a, b)
+
+
+def test_feeder_without_release_cannot_overwrite_a_batch_that_is_still_being_read():
+    """get -> (slow reader on the main stream) -> submit x depth WITHOUT release(): the side stream's copy + preprocess kernel of the
+    batch that reuses the slot must wait for the reader (the safe default; release() only moves the point earlier)."""
+    import numpy as np
+    from licv.image_feeder import ImageFeeder
+    from licv import frontend
+    rng = np.random.default_rng(11)
+    H = W = 224
+    n = 64
+    f = ImageFeeder(DEV, n, H, W)
+    batches = [rng.integers(0, 256, (n, H, W, 3)).astype(np.uint8) for _ in range(4)]
+    want = [frontend.preprocess_images(T(b).to(DEV))[0] for b in batches]
+    spin = torch.randn(4096, 4096, device=DEV)
+    torch.cuda.synchronize()
+    t = f.submit(batches[0])
+    sums = []
+    for i in range(len(batches)):
+        pv, _ = f.get(t)
+        for _ in range(40):                              # keep the main stream busy for milliseconds BEFORE the reader is issued
+            spin = (spin @ spin).clamp_(-1, 1)
+        sums.append((pv.float() - want[i].float()).abs().max())          # the reader: issued late, long after get()
+        nxt = None
+        for j in range(f.depth):                         # within `depth` submits the slot being read is reused; never released
+            tj = f.submit(batches[(i + 1 + j) % len(batches)])
+            nxt = tj if j == 0 else nxt
+        t = nxt                                          # batch i + 1
+    torch.cuda.synchronize()
+    assert all(float(s) == 0.0 for s in sums), [float(s) for s in sums]

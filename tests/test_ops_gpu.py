@@ -242,6 +242,7 @@ def test_gemm_large_tile_kernels_match_general_kernel(variant, M, N, K):
     elif variant == "f32_out":
         kw = dict(out_dtype=torch.float32)
     outs = {}
+    _lib.lab()                                   # 2 / 6 / 8 / 21 / 30-36 / 50 live in liblicv_hip_lab.so (csrc/lab/): tests and tools only
     try:
         # 21: the pair kernel (two K stages per ping-pong phase); 30 / 34 / 36: the four-wave kernel (128 x 128 per wave, pieces in a
         # burst / spread / hand-issued); 40: the four-wave kernel on 64-deep K tiles (takes K % 64 == 0, else falls back); 50: the

@@ -23,6 +23,7 @@ def run():
     import torch
     from licv import _lib, ops
     lib = _lib.lib()
+    _lib.lab()          # experiment kernels (csrc/lab/) register themselves with licv_gemm_select
     M, N, K = SHAPE
     g = torch.Generator(device="cuda").manual_seed(3)
     a = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)

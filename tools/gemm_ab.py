@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--shapes", default="")
     args = ap.parse_args()
     lib = _lib.lib()
+    _lib.lab()          # experiment kernels (csrc/lab/) register themselves with licv_gemm_select
     shapes = SHAPES
     if args.shapes:
         shapes = [tuple(int(x) for x in s.split(",")) for s in args.shapes.split(";")]

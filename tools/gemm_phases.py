@@ -5,6 +5,7 @@ import sys, ctypes, torch
 sys.path.insert(0,'licv-vqa_amd'); sys.path.insert(0,'.')
 from licv import ops, _lib
 lib=_lib.lib()
+_lib.lab()          # experiment kernels (csrc/lab/) register themselves with licv_gemm_select
 cases=[(67848,5120,1280,'gelu'),(67848,1280,5120,'res16'),(67848,3840,1280,'bias'),(67848,1280,1280,'res16'),
        (6400,22016,4096,'swiglu'),(6400,4096,11008,'res32'),(6400,12288,4096,'none'),(6400,4096,4096,'res32')]
 SEL=6

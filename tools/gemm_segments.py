@@ -9,6 +9,8 @@ import torch
 from licv import _lib, ops
 
 lib = _lib.lib()
+
+_lib.lab()          # experiment kernels (csrc/lab/) register themselves with licv_gemm_select
 SEL = int(sys.argv[1]) if len(sys.argv) > 1 else 13        # 13: ping-pong kernel, 25: lean kernel (stamped builds)
 names = ["ds_read issue", "DMA issue", "vmcnt wait", "lgkmcnt wait", "barrier 1", "MFMA issue", "barrier 2"]
 for (M, N, K) in [(6400, 12288, 4096), (67848, 3840, 1280), (8192, 8192, 8192)]:

@@ -19,6 +19,7 @@ SHAPES = [(256, 12288, 4096, "plain"), (256, 4096, 4096, "res32"), (256, 22016, 
 SWEEP = len(sys.argv) > 1 and sys.argv[1] == "sweep"
 sels = ([60, 0] + [700 + c for c in (1, 2, 3, 4, 6, 8, 12, 16)]) if SWEEP else ([int(x) for x in sys.argv[1:]] or [1, 0])
 lib = _lib.lib()
+_lib.lab()          # experiment kernels (csrc/lab/) register themselves with licv_gemm_select
 g = torch.Generator(device="cuda").manual_seed(1)
 for (M, N, K, epi) in SHAPES:
     a = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)

@@ -2,7 +2,7 @@
 import sys, torch
 sys.path.insert(0,'licv-vqa_amd'); sys.path.insert(0,'.')
 from licv import _lib
-lib=_lib.lib()
+lib=_lib.lab()          # roofline probes live in liblicv_hip_lab.so
 sink=torch.zeros(4,device='cuda')
 st=torch.cuda.current_stream().cuda_stream
 def tm(fn,n=5):

@@ -20,6 +20,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "duo":           # the 128 x 256 "duo" e
     SELS = (0, 50)
     SHAPES = [(1376, 4096, 4096, ""), (1376, 4096, 14336, ""), (1376, 6144, 4096, ""), (1024, 4096, 4096, ""), (2056, 1280, 5120, "res"), (2056, 1280, 1280, "res"), (4112, 1280, 5120, "res"), (4352, 4096, 4096, ""), (256, 12288, 4096, ""), (256, 22016, 4096, "")]
 lib = _lib.lib()
+_lib.lab()          # experiment kernels (csrc/lab/) register themselves with licv_gemm_select
 g = torch.Generator(device="cuda").manual_seed(1)
 for (M, N, K, epi) in SHAPES:
     nbuf = max(2, -(-300 * 2 ** 20 // ((N * K + M * K + M * N) * 2)))

@@ -14,6 +14,7 @@ SHAPES = [(256, 12288, 4096), (256, 4096, 4096), (256, 22016, 4096), (256, 4096,
           (24, 12288, 4096), (24, 4096, 4096), (24, 22016, 4096), (24, 4096, 11008), (24, 32002, 4096)]
 sels = sys.argv[1:] or ["0", "blas"]
 lib = _lib.lib()
+_lib.lab()          # experiment kernels (csrc/lab/) register themselves with licv_gemm_select
 g = torch.Generator(device="cuda").manual_seed(1)
 for (M, N, K) in SHAPES:
     nbuf = max(2, -(-640 * 2 ** 20 // (N * K * 2)))

@@ -6,7 +6,7 @@ ROOT = Path(__file__).resolve().parents[1]
 sys.path[:0] = [str(ROOT), str(ROOT / "licv-vqa_amd")]
 import torch
 from licv import _lib
-lib = _lib.lib()
+lib = _lib.lab()          # roofline probes live in liblicv_hip_lab.so
 N, K = 12288, 4096
 ws = [torch.randn(N, K, device="cuda").to(torch.bfloat16) for _ in range(7)]
 sink = torch.zeros(4, dtype=torch.int32, device="cuda")
