@@ -327,6 +327,32 @@ typedef struct {
 int licv_runner_option(int option, int value);
 int licv_idefics_text_forward(const licv_idefics_text_weights* w, const licv_idefics_text_call* c, void* stream);
 
+/* ---- beam search bookkeeping of hooked generate (ref:inference.py:300-321 -> transformers GenerationMixin._beam_search, 5.x form,
+ * generation/utils.py:3077-3460; ref:config/inference.yaml:26-30: 3 beams, 5 new tokens, length_penalty 0) ----
+ * ONE launch per decode step: log_softmax of every beam's logits, top 2*nb of (nb x V) per question, running / finished set update,
+ * early-stop heuristic, and the loop condition.  State buffers are ping-ponged by the caller (in != out for the token rows). */
+typedef struct {
+    const void* logits; int logits_dtype;              /* rows of V logits, bf16 or fp32, row stride ld (elements) */
+    int64_t ld;
+    int64_t q_stride_rows, beam_stride_rows;           /* logits row of (question b, beam k) = b*q_stride_rows + k*beam_stride_rows
+                                                          (nb, 1 in the loop; 1, 0 right after the prefill: all beams share the row) */
+    int64_t B, nb, V, max_len, cur, P;                 /* cur = column being written, P = prompt length, max_len = P + max_new_tokens */
+    int64_t eos;                                       /* -1 = no EOS token */
+    int suppress_eos;                                  /* min_new_tokens not reached: EOS scores -inf */
+    float length_penalty; int early_stopping;          /* early_stopping: 1 = True, 0 = False (the reference's setting) */
+    const int64_t* running_in; const int64_t* finished_in;       /* (B, nb, max_len) token rows */
+    const float* run_scores_in; const float* fin_scores_in;      /* (B, nb) */
+    const uint8_t* is_fin_in; const uint8_t* improve_in;         /* (B, nb), (B) */
+    const int64_t* gen_len_in;                                   /* (B, nb) generated length of each finished hypothesis */
+    int64_t* running_out; int64_t* finished_out; float* run_scores_out; float* fin_scores_out; uint8_t* is_fin_out; uint8_t* improve_out;
+    int64_t* gen_len_out;
+    int64_t* beam_src_flat;                            /* (B*nb): row b*nb + source beam of every new running beam (the KV-cache reorder) */
+    int64_t* next_tokens;                              /* (B*nb): the token each new running beam just appended (next step's input_ids) */
+    int32_t* flags;                                    /* [0] = 1 while the search continues (written by the last workgroup) */
+    int32_t* sync;                                     /* 4 int32, zero before the first call; the kernel leaves them zero */
+} licv_beam_step_args;
+int licv_beam_step(const licv_beam_step_args* a, void* stream);
+
 /* ---- device-side front-end: integer rules between the collator / processor and the first GEMM ---- */
 /* Idefics image_attention_mask (B, S, n_images) int32 one-hot rows from input_ids (B, S) int64 by the incremental rule of
  * hf:idefics/processing_idefics.py:89-110 + :66-79 (ref:icv_src/icv_datamodule.py:80-124 gets it from processor.prepare_input). */

@@ -44,6 +44,18 @@ class AttnArgs(C.Structure):
                 ("key_valid", C.c_void_p), ("img_mask", C.c_void_p), ("n_img", C.c_int64), ("img_len", C.c_int64)]
 
 
+class BeamStepArgs(C.Structure):
+    _fields_ = [("logits", C.c_void_p), ("logits_dtype", C.c_int), ("ld", C.c_int64), ("q_stride_rows", C.c_int64),
+                ("beam_stride_rows", C.c_int64), ("B", C.c_int64), ("nb", C.c_int64), ("V", C.c_int64), ("max_len", C.c_int64),
+                ("cur", C.c_int64), ("P", C.c_int64), ("eos", C.c_int64), ("suppress_eos", C.c_int), ("length_penalty", C.c_float),
+                ("early_stopping", C.c_int),
+                ("running_in", C.c_void_p), ("finished_in", C.c_void_p), ("run_scores_in", C.c_void_p), ("fin_scores_in", C.c_void_p),
+                ("is_fin_in", C.c_void_p), ("improve_in", C.c_void_p), ("gen_len_in", C.c_void_p),
+                ("running_out", C.c_void_p), ("finished_out", C.c_void_p), ("run_scores_out", C.c_void_p), ("fin_scores_out", C.c_void_p),
+                ("is_fin_out", C.c_void_p), ("improve_out", C.c_void_p), ("gen_len_out", C.c_void_p),
+                ("beam_src_flat", C.c_void_p), ("next_tokens", C.c_void_p), ("flags", C.c_void_p), ("sync", C.c_void_p)]
+
+
 def declared_symbols(header: Path = HEADER):
     """Every function name declared in include/licv_hip.h (or the given header)."""
     text = header.read_text()
@@ -105,6 +117,7 @@ def lib() -> C.CDLL:
             "licv_gemm_debug_timestamps": [P],
             "licv_attn_select": [I],
             "licv_attn_fwd": [C.POINTER(AttnArgs), P],
+            "licv_beam_step": [C.POINTER(BeamStepArgs), P],
             "licv_embed_gather": [P, P, P, P, I64, I64, I64, I64, P],
             "licv_im2col_patches": [P, P, I64, I64, I64, I64, I64, P],
             "licv_vit_embed_ln": [P, P, P, P, P, P, I64, I64, I64, F, P],

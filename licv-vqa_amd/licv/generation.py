@@ -32,7 +32,7 @@ class _IdeficsDecoder:
     def _fwd(self, ids, am, iam):
         B, S = ids.shape
         return self.e.forward(input_ids=ids, attention_mask=am, image_states=self.image_states, image_attention_mask=iam,
-                              kv_cache=self.cache, logits_rows=_last_rows(B, S, ids.device), **self.hooks).float()
+                              kv_cache=self.cache, logits_rows=_last_rows(B, S, ids.device), **self.hooks)
 
     def prefill(self, ids, am):
         out = self._fwd(ids, am, self.iam)
@@ -68,7 +68,7 @@ class _Idefics2Decoder:
     def _fwd(self, ids, am, img):
         B, S = ids.shape
         return self.e.forward(input_ids=ids, attention_mask=am, image_hidden_states=img, position_ids=self.pos, kv_cache=self.cache,
-                              logits_rows=_last_rows(B, S, ids.device), **self.hooks).float()
+                              logits_rows=_last_rows(B, S, ids.device), **self.hooks)
 
     def prefill(self, ids, am):
         self.pos = (am.long().cumsum(-1) - 1).masked_fill(am == 0, 0)
@@ -116,8 +116,7 @@ def _decode(model, a, input_ids: torch.Tensor, attention_mask: torch.Tensor, max
     B, P = input_ids.shape
     max_len = P + max_new_tokens
     nb = num_beams
-    logits = model.prefill(input_ids, attention_mask)
-    V = logits.shape[-1]
+    logits = model.prefill(input_ids, attention_mask)          # (B, V) rows in the model's dtype (a view with a padded row stride)
 
     def suppress_eos(lp, n_generated):
         if min_new_tokens > 0 and n_generated < min_new_tokens and eos is not None:
@@ -132,7 +131,7 @@ def _decode(model, a, input_ids: torch.Tensor, attention_mask: torch.Tensor, max
         am = attention_mask
         cur = P
         while True:
-            scores = suppress_eos(logits, cur - P)
+            scores = suppress_eos(logits.float(), cur - P)
             nxt = scores.argmax(-1)
             nxt = torch.where(unfinished, nxt, torch.full_like(nxt, pad))
             seq[:, cur] = nxt
@@ -145,76 +144,77 @@ def _decode(model, a, input_ids: torch.Tensor, attention_mask: torch.Tensor, max
             logits = model.step(nxt[:, None], am)
         return seq[:, :cur]
 
-    # ---- beam search (GenerationMixin._beam_search, transformers 5.x)
-    keep = 2 * nb                                                      # max(2, 1 + n_eos) * num_beams
-    top_mask = torch.cat([torch.ones(nb, dtype=torch.bool), torch.zeros(keep - nb, dtype=torch.bool)]).to(dev)
+    # ---- beam search (GenerationMixin._beam_search, transformers 5.x): ONE kernel per step does the log-softmax, the top 2K
+    # continuations per question and the whole bookkeeping (csrc/beam.hip; the torch restatement it replaced was ~60 launches a step)
     # hf:generation/utils.py:3319 — `output_fill_value = pad_token_id or eos_token_id[0]`: a pad id of 0 (Idefics' <unk>) is falsy
     # there, so finished beams are padded with EOS, not with the pad id (greedy above does use the pad id)
     fill = pad if (pad or eos is None) else eos
-    running = torch.full((B, nb, max_len), fill, dtype=torch.long, device=dev)
-    running[:, :, :P] = input_ids[:, None, :]
-    finished = running.clone()
-    run_scores = torch.zeros((B, nb), dtype=torch.float, device=dev)
-    run_scores[:, 1:] = -1e9
-    fin_scores = torch.full((B, nb), -1e9, dtype=torch.float, device=dev)
-    is_fin = torch.zeros((B, nb), dtype=torch.bool, device=dev)
-    improve = torch.ones((B, 1), dtype=torch.bool, device=dev)
-    gen_len = torch.zeros((B, nb), dtype=torch.long, device=dev)      # generated length of each finished hypothesis
-
-    # replicate the prompt state per beam (HF prefills B*nb identical rows instead)
+    search = BeamSearchState(B, nb, P, max_len, fill, input_ids, eos, length_penalty, early_stopping, min_new_tokens)
+    # replicate the prompt state per beam (HF prefills B*nb identical rows instead); the first step reads the B prefill rows directly
     model.replicate(nb)
     am = attention_mask.repeat_interleave(nb, 0)
-    logits = logits.repeat_interleave(nb, 0)
-    cur = P
-
-    def gather(t, idx):                                                # (B, n, ...) gathered along dim 1
-        ix = idx
-        while ix.dim() < t.dim():
-            ix = ix.unsqueeze(-1)
-        return torch.gather(t, 1, ix.expand(*idx.shape, *t.shape[2:]))
-
+    first = True
     while True:
-        lp = torch.log_softmax(logits, dim=-1)
-        lp = suppress_eos(lp, cur - P).view(B, nb, V) + run_scores[:, :, None]
-        top_lp, top_ix = torch.topk(lp.view(B, nb * V), k=keep)
-        src_beam = top_ix // V
-        top_seq = gather(running, src_beam)
-        top_seq[:, :, cur] = top_ix % V
-        hits = (cur + 1 >= max_len) | ((top_seq[:, :, cur] == eos) if eos is not None else torch.zeros_like(top_ix, dtype=torch.bool))
-        # next running beams: best `nb` continuations that did not just stop
-        run_lp = top_lp + hits.float() * -1.0e9
-        nxt_ix = torch.topk(run_lp, k=nb)[1]
-        running = gather(top_seq, nxt_ix)
-        run_scores = gather(run_lp, nxt_ix)
-        beam_src = gather(src_beam, nxt_ix)
-        # finished set: only the top `nb` candidates may finalise
-        just = hits & top_mask[None, :]
-        fin_lp = top_lp / ((cur + 1 - P) ** length_penalty)
-        fin_lp = fin_lp + (torch.all(is_fin, dim=-1, keepdim=True) & (early_stopping is True)).float() * -1.0e9
-        fin_lp = fin_lp + (~improve).float() * -1.0e9
-        fin_lp = fin_lp + (~just).float() * -1.0e9
-        m_seq = torch.cat([finished, top_seq], 1)
-        m_sc = torch.cat([fin_scores, fin_lp], 1)
-        m_fin = torch.cat([is_fin, just], 1)
-        m_len = torch.cat([gen_len, torch.full_like(top_ix, cur + 1 - P)], 1)
-        best = torch.topk(m_sc, k=nb)[1]
-        finished, fin_scores, is_fin, gen_len = gather(m_seq, best), gather(m_sc, best), gather(m_fin, best), gather(m_len, best)
-        cur += 1
-        # early-stop heuristic (early_stopping=False form): can a running beam still beat the worst finished one?
-        best_run = run_scores[:, :1] / (float(cur - P) ** length_penalty)
-        worst_fin = torch.where(is_fin, fin_scores.min(dim=1, keepdim=True)[0], torch.full_like(fin_scores, -1.0e9))
-        improve = improve & torch.any(best_run > worst_fin, dim=-1, keepdim=True)
-        # one device -> host read per step (the loop's only synchronisation point)
-        unfinished_t = improve.any() & ~hits.all()
-        if early_stopping is True:
-            unfinished_t = unfinished_t & ~is_fin.all()
-        if not bool(unfinished_t):
+        unfinished = search.step(logits, shared_rows=first)            # one device -> host read per step (the loop's only sync point)
+        first = False
+        if not unfinished:
             break
         # reorder the per-beam model state (after the exit test: the last step's reorder would feed no further forward)
-        flat_src = (beam_src + torch.arange(B, device=dev)[:, None] * nb).reshape(-1)
-        model.reorder(flat_src)
+        model.reorder(search.beam_src_flat)
         am = torch.cat([am, torch.ones((B * nb, 1), dtype=am.dtype, device=dev)], 1)
-        logits = model.step(running[:, :, cur - 1].reshape(B * nb, 1), am)
-    out = finished[:, 0, :]
-    out_len = P + int(gen_len[:, 0].max())
-    return out[:, :out_len]
+        logits = model.step(search.next_tokens.view(B * nb, 1), am)
+    return search.result()
+
+
+class BeamSearchState:
+    """Device-side state of one beam search (running / finished token rows, scores, flags), advanced by `licv_beam_step`.
+    Two copies of every buffer: the kernel gathers rows of the old state into the new one."""
+
+    def __init__(self, B, nb, P, max_len, fill, input_ids, eos, length_penalty, early_stopping, min_new_tokens):
+        dev = input_ids.device
+        self.B, self.nb, self.P, self.max_len, self.cur = B, nb, P, max_len, P
+        self.eos = -1 if eos is None else int(eos)
+        self.length_penalty, self.early_stopping, self.min_new_tokens = float(length_penalty), early_stopping is True, int(min_new_tokens)
+        running = torch.full((B, nb, max_len), fill, dtype=torch.long, device=dev)
+        running[:, :, :P] = input_ids[:, None, :]
+        run_scores = torch.zeros((B, nb), dtype=torch.float32, device=dev)
+        run_scores[:, 1:] = -1e9
+        st = dict(running=running, finished=running.clone(), run_scores=run_scores,
+                  fin_scores=torch.full((B, nb), -1e9, dtype=torch.float32, device=dev),
+                  is_fin=torch.zeros((B, nb), dtype=torch.uint8, device=dev), improve=torch.ones((B,), dtype=torch.uint8, device=dev),
+                  gen_len=torch.zeros((B, nb), dtype=torch.long, device=dev))
+        self.state = [st, {k: torch.empty_like(v) for k, v in st.items()}]
+        self.beam_src_flat = torch.empty((B * nb,), dtype=torch.long, device=dev)
+        self.next_tokens = torch.empty((B * nb,), dtype=torch.long, device=dev)
+        self.flags = torch.zeros((1,), dtype=torch.int32, device=dev)
+        self.sync = torch.zeros((4,), dtype=torch.int32, device=dev)
+
+    def step(self, logits: torch.Tensor, shared_rows: bool = False) -> bool:
+        """logits: (B*nb, V) rows (bf16 or fp32, row stride = stride(0)); shared_rows: (B, V) rows of the prefill that all beams of a
+        question share.  Returns whether the search continues (reads one int32 back)."""
+        import ctypes as C
+        from . import _lib
+        from .ops import _dt, _p, _stream, check
+        assert logits.dim() == 2 and logits.stride(1) == 1 and logits.shape[0] == (self.B if shared_rows else self.B * self.nb)
+        a = _lib.BeamStepArgs()
+        a.logits, a.logits_dtype, a.ld = logits.data_ptr(), _dt(logits), logits.stride(0)
+        a.q_stride_rows, a.beam_stride_rows = (1, 0) if shared_rows else (self.nb, 1)
+        a.B, a.nb, a.V, a.max_len, a.cur, a.P = self.B, self.nb, logits.shape[1], self.max_len, self.cur, self.P
+        a.eos = self.eos
+        a.suppress_eos = 1 if (self.min_new_tokens > 0 and self.cur - self.P < self.min_new_tokens and self.eos >= 0) else 0
+        a.length_penalty, a.early_stopping = self.length_penalty, 1 if self.early_stopping else 0
+        src, dst = self.state
+        for k in ("running", "finished", "run_scores", "fin_scores", "is_fin", "improve", "gen_len"):
+            setattr(a, k + "_in", src[k].data_ptr())
+            setattr(a, k + "_out", dst[k].data_ptr())
+        a.beam_src_flat, a.next_tokens = self.beam_src_flat.data_ptr(), self.next_tokens.data_ptr()
+        a.flags, a.sync = self.flags.data_ptr(), self.sync.data_ptr()
+        check(_lib.lib().licv_beam_step(C.byref(a), _stream(logits)))
+        self.state = [dst, src]
+        self.cur += 1
+        return bool(int(self.flags[0]))
+
+    def result(self) -> torch.Tensor:
+        st = self.state[0]
+        out_len = self.P + int(st["gen_len"][:, 0].max())
+        return st["finished"][:, 0, :out_len]

@@ -118,19 +118,40 @@ def _decode(model, arch, input_ids, attention_mask, max_new_tokens=5, num_beams=
             logits = model.step(nxt[:, None], am)
         return seq[:, :cur]
 
-    keep = 2 * nb
-    top_mask = torch.cat([torch.ones(nb, dtype=torch.bool), torch.zeros(keep - nb, dtype=torch.bool)])
+    st = beam_init(input_ids, nb, max_len, eos, pad)
+    while True:
+        cont, flat = beam_step(st, logits, eos, length_penalty, early_stopping)
+        model.reorder(flat)
+        if not cont:
+            break
+        am = torch.cat([am, torch.ones((B * nb, 1), dtype=am.dtype)], 1)
+        logits = model.step(st["running"][:, :, st["cur"] - 1].reshape(B * nb, 1), am)
+    return st["finished"][:, 0, : P + int(st["gen_len"][:, 0].max())]
+
+
+def beam_init(input_ids, nb, max_len, eos, pad):
+    """State of transformers 5.x `_beam_search` before the first step (generation/utils.py:3290-3340)."""
+    B, P = input_ids.shape
     # hf:generation/utils.py:3319 — `output_fill_value = pad_token_id or eos_token_id[0]`: pad id 0 is falsy, EOS fills instead
     fill = pad if (pad or eos is None) else eos
     running = torch.full((B, nb, max_len), fill, dtype=torch.long)
     running[:, :, :P] = input_ids[:, None, :]
-    finished = running.clone()
     run_scores = torch.zeros((B, nb)); run_scores[:, 1:] = -1e9
-    fin_scores = torch.full((B, nb), -1e9)
-    is_fin = torch.zeros((B, nb), dtype=torch.bool)
-    improve = torch.ones((B, 1), dtype=torch.bool)
-    gen_len = torch.zeros((B, nb), dtype=torch.long)
-    cur = P
+    return dict(running=running, finished=running.clone(), run_scores=run_scores, fin_scores=torch.full((B, nb), -1e9),
+                is_fin=torch.zeros((B, nb), dtype=torch.bool), improve=torch.ones((B, 1), dtype=torch.bool),
+                gen_len=torch.zeros((B, nb), dtype=torch.long), cur=P, P=P, max_len=max_len, nb=nb)
+
+
+def beam_step(st, logits, eos, length_penalty=1.0, early_stopping=False, suppress_eos=False):
+    """One iteration of `_beam_search` (generation/utils.py:3360-3460) on the state `st` (updated in place) given the (B*nb, V) fp32
+    logits of the running beams.  Returns (search continues?, flat source-beam index of every new running beam)."""
+    B, nb = st["run_scores"].shape
+    V = logits.shape[-1]
+    cur, P, max_len = st["cur"], st["P"], st["max_len"]
+    keep = 2 * nb
+    top_mask = torch.cat([torch.ones(nb, dtype=torch.bool), torch.zeros(keep - nb, dtype=torch.bool)])
+    running, finished, run_scores, fin_scores = st["running"], st["finished"], st["run_scores"], st["fin_scores"]
+    is_fin, improve, gen_len = st["is_fin"], st["improve"], st["gen_len"]
 
     def gather(t, idx):
         ix = idx
@@ -138,34 +159,35 @@ def _decode(model, arch, input_ids, attention_mask, max_new_tokens=5, num_beams=
             ix = ix.unsqueeze(-1)
         return torch.gather(t, 1, ix.expand(*idx.shape, *t.shape[2:]))
 
-    while True:
-        lp = torch.log_softmax(logits, dim=-1).view(B, nb, V) + run_scores[:, :, None]
-        top_lp, top_ix = torch.topk(lp.view(B, nb * V), k=keep)
-        src = top_ix // V
-        top_seq = gather(running, src)
-        top_seq[:, :, cur] = top_ix % V
-        hits = (top_seq[:, :, cur] == eos) | (cur + 1 >= max_len)
-        run_lp = top_lp + hits.float() * -1.0e9
-        nxt_ix = torch.topk(run_lp, k=nb)[1]
-        running, run_scores, beam_src = gather(top_seq, nxt_ix), gather(run_lp, nxt_ix), gather(src, nxt_ix)
-        just = hits & top_mask[None, :]
-        fin_lp = top_lp / ((cur + 1 - P) ** length_penalty)
-        fin_lp = fin_lp + (torch.all(is_fin, dim=-1, keepdim=True) & (early_stopping is True)).float() * -1.0e9
-        fin_lp = fin_lp + (~improve).float() * -1.0e9 + (~just).float() * -1.0e9
-        m_sc = torch.cat([fin_scores, fin_lp], 1)
-        best = torch.topk(m_sc, k=nb)[1]
-        finished = gather(torch.cat([finished, top_seq], 1), best)
-        is_fin = gather(torch.cat([is_fin, just], 1), best)
-        gen_len = gather(torch.cat([gen_len, torch.full_like(top_ix, cur + 1 - P)], 1), best)
-        fin_scores = gather(m_sc, best)
-        flat = (beam_src + torch.arange(B)[:, None] * nb).reshape(-1)
-        model.reorder(flat)
-        cur += 1
-        best_run = run_scores[:, :1] / (float(cur - P) ** length_penalty)
-        worst = torch.where(is_fin, fin_scores.min(dim=1, keepdim=True)[0], torch.full_like(fin_scores, -1.0e9))
-        improve = improve & torch.any(best_run > worst, dim=-1, keepdim=True)
-        if not (bool(improve.any()) and not (bool(is_fin.all()) and early_stopping is True) and not bool(hits.all())):
-            break
-        am = torch.cat([am, torch.ones((B * nb, 1), dtype=am.dtype)], 1)
-        logits = model.step(running[:, :, cur - 1].reshape(B * nb, 1), am)
-    return finished[:, 0, : P + int(gen_len[:, 0].max())]
+    lp = torch.log_softmax(logits, dim=-1)
+    if suppress_eos:
+        lp = lp.clone()
+        lp[..., eos] = -float("inf")
+    lp = lp.view(B, nb, V) + run_scores[:, :, None]
+    top_lp, top_ix = torch.topk(lp.view(B, nb * V), k=keep)
+    src = top_ix // V
+    top_seq = gather(running, src)
+    top_seq[:, :, cur] = top_ix % V
+    hits = (top_seq[:, :, cur] == eos) | (cur + 1 >= max_len) if eos is not None else torch.full_like(top_ix, cur + 1 >= max_len, dtype=torch.bool)
+    run_lp = top_lp + hits.float() * -1.0e9
+    nxt_ix = torch.topk(run_lp, k=nb)[1]
+    running, run_scores, beam_src = gather(top_seq, nxt_ix), gather(run_lp, nxt_ix), gather(src, nxt_ix)
+    just = hits & top_mask[None, :]
+    fin_lp = top_lp / ((cur + 1 - P) ** length_penalty)
+    fin_lp = fin_lp + (torch.all(is_fin, dim=-1, keepdim=True) & (early_stopping is True)).float() * -1.0e9
+    fin_lp = fin_lp + (~improve).float() * -1.0e9 + (~just).float() * -1.0e9
+    m_sc = torch.cat([fin_scores, fin_lp], 1)
+    best = torch.topk(m_sc, k=nb)[1]
+    finished = gather(torch.cat([finished, top_seq], 1), best)
+    is_fin = gather(torch.cat([is_fin, just], 1), best)
+    gen_len = gather(torch.cat([gen_len, torch.full_like(top_ix, cur + 1 - P)], 1), best)
+    fin_scores = gather(m_sc, best)
+    flat = (beam_src + torch.arange(B)[:, None] * nb).reshape(-1)
+    cur += 1
+    best_run = run_scores[:, :1] / (float(cur - P) ** length_penalty)
+    worst = torch.where(is_fin, fin_scores.min(dim=1, keepdim=True)[0], torch.full_like(fin_scores, -1.0e9))
+    improve = improve & torch.any(best_run > worst, dim=-1, keepdim=True)
+    st.update(running=running, finished=finished, run_scores=run_scores, fin_scores=fin_scores, is_fin=is_fin, improve=improve,
+              gen_len=gen_len, cur=cur)
+    cont = bool(improve.any()) and not (bool(is_fin.all()) and early_stopping is True) and not bool(hits.all())
+    return cont, flat
