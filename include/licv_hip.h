@@ -313,6 +313,7 @@ typedef struct {
     const int32_t* hook_slot;                          /* HOST array [n_layers]: row of icv for that layer's output, -1 = not hooked */
     void* const* kv_cache;                             /* HOST array [n_layers] of (B, cache_max_len, 2*hidden) bf16, or NULL */
     int64_t cache_max_len, past;
+    const int32_t* kv_rows; int64_t ld_kv_rows;        /* decode steps (S == 1): physical cache row of every history position (licv_decode_attn), or NULL */
     const void* const* xkv_cached;                     /* HOST array [n_x] of projected+normed cross-attention K|V (B, Nk, 2*hidden), or NULL */
     void* const* xkv_out;                              /* HOST array [n_x]: project INTO these (they become next step's xkv_cached), or NULL */
     const int64_t* logits_rows; int64_t n_rows;        /* logits only for these flat rows (n_rows = 0: all B*S rows) */
@@ -326,6 +327,25 @@ typedef struct {
  * them sum the slices (the *_ws entry points) instead of a finalize launch (default 1; bit-identical). */
 int licv_runner_option(int option, int value);
 int licv_idefics_text_forward(const licv_idefics_text_weights* w, const licv_idefics_text_call* c, void* stream);
+
+/* ---- one decode step's self-attention block (ref:inference.py:300-321: B x num_beams rows, one new token each; hf eager attention
+ * hf:idefics/modeling_idefics.py:450-470, rotary :396-428, hf:mistral/modeling_mistral.py:122-179 for GQA) in ONE launch: fused QKV rows
+ * (bf16, or the fp32 split-K slices of licv_gemm_bf16_splitk_produce) -> rotary on Q / K -> K | V appended to cache[r, past] -> attention
+ * of the new query over positions 0..past -> out (M, n_heads * head_dim) bf16.  cache: (rows, max_len, 2 * n_kv_heads * head_dim) bf16,
+ * K then V.  kv_rows (M, ld_kv_rows) int32, optional: the physical cache row holding position p of row r's history (beam search keeps
+ * the cache in place and reorders this table, see licv_beam_step); NULL = every row reads its own cache row. */
+typedef struct {
+    const float* qkv_ws; int splits; int64_t slice_elems, row_stride;   /* split-K slices of the QKV projection, or NULL */
+    const void* qkv_bf16; int64_t ldq;                                   /* (M, ldq) bf16 rows [Q | K | V] when qkv_ws == NULL */
+    const void* cos; const void* sin; const int64_t* position_ids; int64_t n_pos;   /* (n_pos, head_dim) bf16 tables, (M) positions */
+    void* cache; int64_t max_len, past;
+    const int32_t* kv_rows; int64_t ld_kv_rows;
+    const int32_t* key_valid;                                            /* (M, past + 1) attention mask, or NULL */
+    void* out;
+    int64_t M, n_heads, n_kv_heads, head_dim;
+    float scale;
+} licv_decode_attn_args;
+int licv_decode_attn(const licv_decode_attn_args* a, void* stream);
 
 /* ---- beam search bookkeeping of hooked generate (ref:inference.py:300-321 -> transformers GenerationMixin._beam_search, 5.x form,
  * generation/utils.py:3077-3460; ref:config/inference.yaml:26-30: 3 beams, 5 new tokens, length_penalty 0) ----
@@ -350,6 +370,9 @@ typedef struct {
     int64_t* next_tokens;                              /* (B*nb): the token each new running beam just appended (next step's input_ids) */
     int32_t* flags;                                    /* [0] = 1 while the search continues (written by the last workgroup) */
     int32_t* sync;                                     /* 4 int32, zero before the first call; the kernel leaves them zero */
+    /* optional: the KV-cache row table of licv_decode_attn, (B*nb, kv_ld) int32.  Row r of the new table = row (source beam of r) of
+     * the old one, then entry [cur] = r: the token a beam appends next lands in its OWN physical cache row.  NULL = not maintained. */
+    const int32_t* kv_rows_in; int32_t* kv_rows_out; int64_t kv_ld;
 } licv_beam_step_args;
 int licv_beam_step(const licv_beam_step_args* a, void* stream);
 

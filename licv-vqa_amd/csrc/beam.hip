@@ -185,6 +185,14 @@ void beam_step_k(licv_beam_step_args a) {
         const int64_t* fs = (ft < 0 ? fin_in : run_in) + (int64_t)plan_fin_src[r] * L;
         for (int64_t c = tid; c < L; c += BEAM_THREADS) fin_out[(int64_t)r * L + c] = (ft >= 0 && c == cur) ? ft : fs[c];
     }
+    // ---- the KV-cache row table of licv_decode_attn: a beam inherits its source beam's history rows and owns its next token's row
+    if (a.kv_rows_in && a.kv_rows_out) {
+        for (int r = 0; r < NB; ++r) {
+            const int32_t* s = a.kv_rows_in + ((int64_t)b * NB + plan_run_src[r]) * a.kv_ld;
+            int32_t* d = a.kv_rows_out + ((int64_t)b * NB + r) * a.kv_ld;
+            for (int64_t c = tid; c < a.kv_ld; c += BEAM_THREADS) d[c] = (c == cur) ? (int32_t)(b * NB + r) : s[c];
+        }
+    }
     // ---- loop condition: the last workgroup to arrive combines the counters and clears them for the next step
     if (tid == 0) {
         __threadfence();
@@ -208,6 +216,8 @@ extern "C" int licv_beam_step(const licv_beam_step_args* x, void* stream) {
     LICV_CHECK_ARG(x->B >= 1 && x->V >= 2 * x->nb && x->ld >= x->V && x->nb * x->V < (1ll << 31), "beam_step: bad batch / vocabulary size");
     LICV_CHECK_ARG(x->cur >= x->P && x->cur < x->max_len && x->P >= 1, "beam_step: position %lld outside [P, max_len)", (long long)x->cur);
     LICV_CHECK_ARG(x->running_in != x->running_out && x->finished_in != x->finished_out, "beam_step: the token rows need separate in / out buffers");
+    LICV_CHECK_ARG((x->kv_rows_in == nullptr) == (x->kv_rows_out == nullptr) && (!x->kv_rows_in || (x->kv_rows_in != x->kv_rows_out && x->kv_ld > x->cur)),
+                   "beam_step: the KV row table needs separate in / out buffers with rows longer than the current position");
     const dim3 grid((unsigned)x->B), block(BEAM_THREADS);
     hipStream_t st = (hipStream_t)stream;
     switch (x->nb) {

@@ -1,0 +1,172 @@
+// One decode step's self-attention block of hooked generate (ref:inference.py:300-321: B x num_beams rows, ONE new token each) as a
+// single launch: the fused QKV projection's output (bf16 rows, or the fp32 split-K slices its producer left in the workspace) ->
+// rotary on Q and K (hf:idefics/modeling_idefics.py:396-428, each bf16 op rounded) -> K | V appended to the row's KV cache ->
+// attention of the new query over the cached keys (hf eager_attention_forward, :450-470) -> O.  It replaces three launches of a
+// decode step per layer (rotary + append, the 64-query tiled attention kernel with one live query per workgroup, and - with
+// kv_rows - the beam search's gather of the whole cache): the cache is never moved.  kv_rows[r][p] names the PHYSICAL cache row that
+// holds position p of beam row r's history (licv_beam_step maintains it: a beam inherits its source beam's row indices and writes
+// its own new token into its own row), so a reorder is an index update of B * beams * max_len ints.
+//
+// One 64-lane wave per (row, kv head); it serves the n_heads / n_kv_heads query heads of that group one after the other.  Scores:
+// one key per lane (a 128-dim dot from 16-byte loads, q in registers); softmax in the log2 domain with P rounded to bf16 before the
+// PV product, the sum taken over the unrounded P - the arithmetic of csrc/attention.hip's tile function; PV: two head-dim columns
+// per lane, keys in order.  The new token's own K / V never make a round trip through memory.
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_d;
+
+struct DecodeP {
+    const float* ws; int splits; int64_t slice, stride;       // split-K slices of the QKV projection (ws == nullptr: qkv16)
+    const bf16_t* qkv16; int64_t ldq;
+    const bf16_t* cosT; const bf16_t* sinT; const int64_t* pos; int64_t n_pos;
+    bf16_t* cache; int64_t max_len;
+    const int32_t* kv_rows; int64_t ld_rows;
+    const int32_t* key_valid;
+    bf16_t* out;
+    int M, Sk, past, nh, nkv, hd;
+    float scale;
+};
+
+__device__ __forceinline__ float dec_in(const DecodeP& a, int64_t row, int64_t col) {
+    if (!a.ws) return bf2f(a.qkv16[row * a.ldq + col]);
+    const float* p = a.ws + row * a.stride + col;
+    float v = p[0];
+    for (int sp = 1; sp < a.splits; ++sp) v += p[(int64_t)sp * a.slice];     // slice order, as skinny_finalize_k adds them
+    return rbf(v);
+}
+
+__global__ __launch_bounds__(64)
+void decode_attn_k(DecodeP a) {
+    extern __shared__ float dsm[];                     // [Sk] scores, then probabilities
+    __shared__ __attribute__((aligned(16))) bf16_t qs[128];
+    const int lane = threadIdx.x;
+    const int r = blockIdx.x / a.nkv, g = blockIdx.x % a.nkv;
+    const int hd = a.hd, half = hd >> 1, rep = a.nh / a.nkv;
+    const int64_t qd = (int64_t)a.nh * hd, kd = (int64_t)a.nkv * hd;
+    const bool act = lane < half;
+    int64_t p = a.pos[r];
+    p = p < 0 ? 0 : (p >= a.n_pos ? a.n_pos - 1 : p);
+    const float c = act ? bf2f(a.cosT[p * hd + lane]) : 0.f, s = act ? bf2f(a.sinT[p * hd + lane]) : 0.f;
+    // ---- the new token's K (rotated) and V of this kv head: into the cache row of THIS beam row at position `past`, and kept in registers
+    float k0 = 0.f, k1 = 0.f, v0 = 0.f, v1 = 0.f;
+    bf16_t* crow = a.cache + ((int64_t)r * a.max_len + a.past) * 2 * kd + (int64_t)g * hd;
+    if (act) {
+        const float lo = dec_in(a, r, qd + (int64_t)g * hd + lane), hi = dec_in(a, r, qd + (int64_t)g * hd + lane + half);
+        k0 = rbf(rbf(lo * c) + rbf(-hi * s));
+        k1 = rbf(rbf(hi * c) + rbf(lo * s));
+        v0 = dec_in(a, r, qd + kd + (int64_t)g * hd + lane);
+        v1 = dec_in(a, r, qd + kd + (int64_t)g * hd + lane + half);
+        crow[lane] = f2bf(k0); crow[lane + half] = f2bf(k1);
+        crow[kd + lane] = f2bf(v0); crow[kd + lane + half] = f2bf(v1);
+    }
+    const float sc = a.scale * 1.4426950408889634f;
+    const int32_t* rows_r = a.kv_rows ? a.kv_rows + (int64_t)r * a.ld_rows : nullptr;
+    const int32_t* valid_r = a.key_valid ? a.key_valid + (int64_t)r * a.Sk : nullptr;
+    const int nch = hd >> 3;                            // 16-byte chunks per K row
+    for (int qh = 0; qh < rep; ++qh) {
+        const int head = g * rep + qh;
+        // ---- Q of this head, rotated; its score against the new key from registers
+        float q0 = 0.f, q1 = 0.f;
+        if (act) {
+            const float lo = dec_in(a, r, (int64_t)head * hd + lane), hi = dec_in(a, r, (int64_t)head * hd + lane + half);
+            q0 = rbf(rbf(lo * c) + rbf(-hi * s));
+            q1 = rbf(rbf(hi * c) + rbf(lo * s));
+            qs[lane] = f2bf(q0); qs[lane + half] = f2bf(q1);
+        }
+        const float s_new = wave_sum(q0 * k0 + q1 * k1);
+        __syncthreads();
+        u32x4_d qreg[16];
+#pragma unroll
+        for (int ch = 0; ch < 16; ++ch) qreg[ch] = ch < nch ? reinterpret_cast<const u32x4_d*>(qs)[ch] : u32x4_d{0u, 0u, 0u, 0u};
+        // ---- scores: one key per lane
+        float mx = -INFINITY;
+        for (int j0 = 0; j0 < a.Sk; j0 += 64) {
+            const int j = j0 + lane;
+            float sj = -INFINITY;
+            if (j < a.Sk) {
+                const bool ok = !valid_r || valid_r[j] != 0;
+                if (j == a.past) sj = s_new;
+                else {
+                    const int64_t prow = rows_r ? rows_r[j] : r;
+                    const u32x4_d* kp = reinterpret_cast<const u32x4_d*>(a.cache + (prow * a.max_len + j) * 2 * kd + (int64_t)g * hd);
+                    float acc = 0.f;
+#pragma unroll
+                    for (int ch = 0; ch < 16; ++ch) {
+                        if (ch < nch) {
+                            const u32x4_d kv = kp[ch];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                acc = __builtin_fmaf(__uint_as_float(kv[e] << 16), __uint_as_float(qreg[ch][e] << 16), acc);
+                                acc = __builtin_fmaf(__uint_as_float(kv[e] & 0xffff0000u), __uint_as_float(qreg[ch][e] & 0xffff0000u), acc);
+                            }
+                        }
+                    }
+                    sj = acc;
+                }
+                if (!ok) sj = -INFINITY;
+                dsm[j] = sj;
+            }
+            mx = fmaxf(mx, sj);
+        }
+        mx = wave_max(mx);
+        const float m_new = mx * sc;
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        float lsum = 0.f;
+        __syncthreads();
+        for (int j0 = 0; j0 < a.Sk; j0 += 64) {
+            const int j = j0 + lane;
+            if (j < a.Sk) {
+                const float pj = __builtin_amdgcn_exp2f(__builtin_fmaf(dsm[j], sc, -m_use));
+                lsum += pj;
+                dsm[j] = rbf(pj);
+            }
+        }
+        lsum = wave_sum(lsum);
+        __syncthreads();
+        // ---- O = P V: two head-dim columns per lane, keys in order
+        float o0 = 0.f, o1 = 0.f;
+        if (act) {
+            for (int j = 0; j < a.Sk; ++j) {
+                const float pj = dsm[j];
+                if (pj == 0.f) continue;
+                float a0, a1;
+                if (j == a.past) { a0 = v0; a1 = v1; }
+                else {
+                    const int64_t prow = rows_r ? rows_r[j] : r;
+                    const bf16_t* vp = a.cache + (prow * a.max_len + j) * 2 * kd + kd + (int64_t)g * hd;
+                    a0 = bf2f(vp[lane]); a1 = bf2f(vp[lane + half]);
+                }
+                o0 = __builtin_fmaf(pj, a0, o0);
+                o1 = __builtin_fmaf(pj, a1, o1);
+            }
+            const float inv = lsum > 0.f ? 1.0f / lsum : 0.f;
+            bf16_t* op = a.out + (int64_t)r * qd + (int64_t)head * hd;
+            op[lane] = f2bf(o0 * inv); op[lane + half] = f2bf(o1 * inv);
+        }
+        __syncthreads();                               // qs / dsm are rewritten by the next query head
+    }
+}
+
+extern "C" int licv_decode_attn(const licv_decode_attn_args* x, void* stream) {
+    LICV_CHECK_ARG(x && (x->qkv_ws || x->qkv_bf16) && x->cos && x->sin && x->position_ids && x->cache && x->out, "decode_attn: null pointer");
+    LICV_CHECK_ARG(x->M > 0 && x->past >= 0 && x->past < x->max_len, "decode_attn: bad rows / past (%lld of %lld)", (long long)x->past, (long long)x->max_len);
+    LICV_CHECK_ARG(x->n_heads > 0 && x->n_kv_heads > 0 && x->n_heads % x->n_kv_heads == 0, "decode_attn: n_heads must be a multiple of n_kv_heads");
+    LICV_CHECK_ARG(x->head_dim >= 16 && x->head_dim <= 128 && x->head_dim % 16 == 0, "decode_attn: head_dim %lld unsupported (multiple of 16, <= 128)", (long long)x->head_dim);
+    LICV_CHECK_ARG(!x->qkv_ws || (x->splits >= 1 && x->slice_elems > 0 && x->row_stride > 0), "decode_attn: bad split-K workspace description");
+    LICV_CHECK_ARG(x->qkv_ws || x->ldq >= (x->n_heads + 2 * x->n_kv_heads) * x->head_dim, "decode_attn: ldq smaller than the fused row");
+    LICV_CHECK_ARG(((uintptr_t)x->cache & 15) == 0, "decode_attn: the cache must be 16-byte aligned");
+    LICV_CHECK_ARG(!x->kv_rows || x->ld_kv_rows > x->past, "decode_attn: kv_rows rows shorter than the history");
+    DecodeP p;
+    p.ws = x->qkv_ws; p.splits = x->splits; p.slice = x->slice_elems; p.stride = x->row_stride;
+    p.qkv16 = (const bf16_t*)x->qkv_bf16; p.ldq = x->ldq;
+    p.cosT = (const bf16_t*)x->cos; p.sinT = (const bf16_t*)x->sin; p.pos = x->position_ids; p.n_pos = x->n_pos;
+    p.cache = (bf16_t*)x->cache; p.max_len = x->max_len; p.kv_rows = x->kv_rows; p.ld_rows = x->ld_kv_rows; p.key_valid = x->key_valid;
+    p.out = (bf16_t*)x->out;
+    p.M = (int)x->M; p.Sk = (int)x->past + 1; p.past = (int)x->past; p.nh = (int)x->n_heads; p.nkv = (int)x->n_kv_heads; p.hd = (int)x->head_dim;
+    p.scale = x->scale;
+    const size_t lds = (size_t)p.Sk * sizeof(float);
+    LICV_CHECK_ARG(lds <= 60 * 1024, "decode_attn: history of %d keys exceeds the kernel's LDS budget", p.Sk);
+    decode_attn_k<<<dim3((unsigned)(x->M * x->n_kv_heads)), dim3(64), lds, (hipStream_t)stream>>>(p);
+    LICV_LAUNCH_CHECK();
+    return LICV_OK;
+}

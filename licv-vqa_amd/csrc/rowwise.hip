@@ -30,6 +30,25 @@ __device__ __forceinline__ void store4_bf16(void* p, int64_t i, floatx4 v) {
     *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p) + i) = u;
 }
 
+// Per-lane sums over a row's NCH chunks are formed in FOUR GROUPS of NCH / 4 consecutive chunks (sequentially inside a group, then
+// ((g0 + g1) + g2) + g3) whenever NCH % 4 == 0, and only then reduced across the 64 lanes.  The "wide" form of a row kernel (one
+// row per 256-thread workgroup, wave w owning group w: *_wide_k below) then produces the same fp32 sums bit for bit, so a 24-row
+// decode call can spread a row over four waves without leaving the results of the one-wave form.
+template <int NCH> struct GroupSum {
+    static constexpr int G = (NCH % 4 == 0) ? 4 : 1;
+    static constexpr int PER = NCH / G;
+    float p[G];
+    __device__ __forceinline__ GroupSum() {
+#pragma unroll
+        for (int g = 0; g < G; ++g) p[g] = 0.f;
+    }
+    __device__ __forceinline__ void add(int c, float v) { p[c / PER] += v; }        // c is a compile-time constant after unrolling
+    __device__ __forceinline__ float total() const { float t = p[0];
+#pragma unroll
+        for (int g = 1; g < G; ++g) t += p[g];
+        return t; }
+};
+
 // ------------------------------------------------------------------------------------------------
 // ICV hook forward.  ref:icv_src/icv_model/icv_intervention.py:62-84
 // ------------------------------------------------------------------------------------------------
@@ -119,7 +138,7 @@ void inject_renorm_fwd_k(const void* __restrict__ h, const float* __restrict__ i
     // The optional operands (`pre`, `res`) are wave-uniform: their loads are issued unconditionally from a stand-in address inside
     // `h` when absent and dropped by a select — no branch per chunk either.
     floatx4 x[NCH], hvv[NCH], bvv[NCH], vvv[NCH];
-    float ss = 0.f, hh = 0.f;
+    GroupSum<NCH> gss, ghh;
     const bool has_pre = WS || pre != nullptr;
     const void* pre_p = has_pre ? (const void*)pre : h;
 #pragma unroll
@@ -152,18 +171,18 @@ void inject_renorm_fwd_k(const void* __restrict__ h, const float* __restrict__ i
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float s = hv[j] + a * vvv[c][j];
-            hh += ok ? hv[j] * hv[j] : 0.f;
-            ss += ok ? s * s : 0.f;
+            ghh.add(c, ok ? hv[j] * hv[j] : 0.f);
+            gss.add(c, ok ? s * s : 0.f);
             x[c][j] = s;
         }
     }
-    ss = wave_sum(ss);
-    hh = wave_sum(hh);
+    const float ss = wave_sum(gss.total());
+    const float hh = wave_sum(ghh.total());
     // shifted / ||shifted|| * ||h||  in that order, as the reference writes it.  torch's .norm() returns
     // the input dtype: for a bf16 stream ||h|| is ROUNDED to bf16 (||h+v|| is fp32: the sum was promoted).
     const float ns = sqrtf(ss);
     const float nh = (DT == LICV_BF16) ? rbf(sqrtf(hh)) : sqrtf(hh);
-    float q2 = 0.f;
+    GroupSum<NCH> gq2;
     floatx4 rvv[NCH], wvv[NCH];
     const bool has_res = res != nullptr;                 // hooked BRANCH output (Idefics2 `.mlp`): stream = residual + edited branch
     const bool res32 = has_res && res_dt == LICV_F32;
@@ -198,11 +217,11 @@ void inject_renorm_fwd_k(const void* __restrict__ h, const float* __restrict__ i
             x[c][j] = has_res ? rvv[c][j] + e : e;
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) q2 += ok ? x[c][j] * x[c][j] : 0.f;
+        for (int j = 0; j < 4; ++j) gq2.add(c, ok ? x[c][j] * x[c][j] : 0.f);
         if (ok) *reinterpret_cast<floatx4*>(out + base + i) = x[c];
     }
     if (FUSE_NORM) {
-        q2 = wave_sum(q2);
+        const float q2 = wave_sum(gq2.total());
         const float rs = rsqrtf(q2 / (float)hidden + eps);
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
@@ -294,7 +313,7 @@ void rmsnorm_fwd_k(const void* __restrict__ x, const bf16_t* __restrict__ w, bf1
     const int64_t ro = row / inner, ri = row % inner;
     const int64_t xb = ro * ld_x + ri * dim, ob = ro * ld_out + ri * dim;
     floatx4 v[NCH], wv[NCH];                                      // all loads first, no per-chunk branch (see inject_renorm_fwd_k)
-    float ss = 0.f;
+    GroupSum<NCH> gss;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int i = (c * 64 + lane) * 4, ii = i < dim ? i : 0;
@@ -305,9 +324,9 @@ void rmsnorm_fwd_k(const void* __restrict__ x, const bf16_t* __restrict__ w, bf1
     for (int c = 0; c < NCH; ++c) {
         const bool ok = (c * 64 + lane) * 4 < dim;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) ss += ok ? v[c][j] * v[c][j] : 0.f;
+        for (int j = 0; j < 4; ++j) gss.add(c, ok ? v[c][j] * v[c][j] : 0.f);
     }
-    ss = wave_sum(ss);
+    const float ss = wave_sum(gss.total());
     const float rs = rsqrtf(ss / (float)dim + eps);
     const bool single_round = (flavour == 1 && DT == LICV_F32);   // Mistral norm on an fp32 stream
 #pragma unroll
@@ -342,7 +361,7 @@ void add_rmsnorm_fwd_k(void* __restrict__ h, const bf16_t* __restrict__ branch, 
     __shared__ __attribute__((aligned(16))) bf16_t ws_img[WS ? NCH * 256 : 8];
     const bool closed = row_gate && row_gate[row] == 0.0f;           // gated cross-attention: a token that attends no image adds nothing
     floatx4 v[NCH], bvv[NCH], wv[NCH];                             // all loads first, no per-chunk branch (see inject_renorm_fwd_k)
-    float ss = 0.f;
+    GroupSum<NCH> gss;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int i = (c * 64 + lane) * 4, ii = i < dim ? i : 0;
@@ -372,14 +391,14 @@ void add_rmsnorm_fwd_k(void* __restrict__ h, const bf16_t* __restrict__ branch, 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             v[c][j] = (DT == LICV_BF16) ? rbf(v[c][j] + bv[j]) : v[c][j] + bv[j];
-            ss += ok ? v[c][j] * v[c][j] : 0.f;
+            gss.add(c, ok ? v[c][j] * v[c][j] : 0.f);
         }
         if (ok) {
             if (DT == LICV_BF16) store4_bf16(h, base + i, v[c]);
             else *reinterpret_cast<floatx4*>(reinterpret_cast<float*>(h) + base + i) = v[c];
         }
     }
-    ss = wave_sum(ss);
+    const float ss = wave_sum(gss.total());
     const float rs = rsqrtf(ss / (float)dim + eps);
     const bool single_round = (flavour == 1 && DT == LICV_F32);
 #pragma unroll
@@ -398,6 +417,161 @@ void add_rmsnorm_fwd_k(void* __restrict__ h, const bf16_t* __restrict__ branch, 
         }
     }
     if (q8.q) emit_row_fp8<NCH>(v, dim, lane, q8.q + base, q8.scale + row);
+}
+
+// ------------------------------------------------------------------------------------------------
+// WIDE forms for the split-K slice consumers of a decode step (24 rows): one row per 256-thread workgroup, wave w owns chunk group w
+// (see GroupSum), every lane sums the split-K slices of its OWN elements in slice order (what skinny_finalize_k adds, rounded to bf16
+// like the branch it would have written) and the three row statistics are combined across the waves through LDS in group order before
+// the 64-lane butterfly: bit-identical to the one-wave kernels above, with a quarter of the serial work per wave (the one-wave form
+// spent ~10 us of a 13 us call in wave 0's 16 dependent chunks).
+// ------------------------------------------------------------------------------------------------
+template <int PER>
+__device__ __forceinline__ void wide_branch_from_slices(const WsSrc& s, int64_t row, int dim, int wave, int lane, floatx4 (&bv)[PER]) {
+    const float* p = s.ws + row * s.stride;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = ((wave * PER + k) * 64 + lane) * 4, ii = i < dim ? i : 0;
+        bv[k] = *reinterpret_cast<const floatx4*>(p + ii);
+    }
+    for (int sp = 1; sp < s.splits; ++sp) {
+        floatx4 t[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = ((wave * PER + k) * 64 + lane) * 4, ii = i < dim ? i : 0;
+            t[k] = *reinterpret_cast<const floatx4*>(p + (int64_t)sp * s.slice + ii);
+        }
+#pragma unroll
+        for (int k = 0; k < PER; ++k) bv[k] += t[k];
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bv[k][j] = rbf(bv[k][j]);
+}
+// the four group partials of a lane, combined in group order, then the butterfly over the lanes (== wave_sum(GroupSum::total()))
+__device__ __forceinline__ float wide_combine(float partial, float (*red)[64], int wave, int lane) {
+    red[wave][lane] = partial;
+    __syncthreads();
+    const float t = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+    return wave_sum(t);
+}
+
+template <int DT, int NCH>
+__global__ __launch_bounds__(256)
+void inject_renorm_wide_k(const void* __restrict__ h, const float* __restrict__ icv, const float* __restrict__ alpha, float* __restrict__ out,
+                          int hidden, const bf16_t* __restrict__ norm_w, bf16_t* __restrict__ xn, float eps, WsSrc src) {
+    constexpr int PER = NCH / 4;
+    __shared__ float red[3][4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row = blockIdx.x, base = row * hidden;
+    const float a = alpha ? *alpha : 1.0f;
+    floatx4 hv[PER], vv[PER], wv[PER], bv[PER], x[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = ((wave * PER + k) * 64 + lane) * 4, ii = i < hidden ? i : 0;
+        hv[k] = RowIO<DT>::load4(h, base + ii);
+        vv[k] = *reinterpret_cast<const floatx4*>(icv + ii);
+        wv[k] = RowIO<LICV_BF16>::load4(norm_w, ii);
+    }
+    wide_branch_from_slices<PER>(src, row, hidden, wave, lane, bv);
+    float pss = 0.f, phh = 0.f;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const bool ok = ((wave * PER + k) * 64 + lane) * 4 < hidden;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float hj = (DT == LICV_BF16) ? rbf(hv[k][j] + bv[k][j]) : hv[k][j] + bv[k][j];
+            const float sj = hj + a * vv[k][j];
+            phh += ok ? hj * hj : 0.f;
+            pss += ok ? sj * sj : 0.f;
+            x[k][j] = sj;
+        }
+    }
+    red[1][wave][lane] = phh;
+    const float ss = wide_combine(pss, red[0], wave, lane);          // (its barrier also publishes red[1])
+    const float hh = wave_sum(((red[1][0][lane] + red[1][1][lane]) + red[1][2][lane]) + red[1][3][lane]);
+    const float ns = sqrtf(ss);
+    const float nh = (DT == LICV_BF16) ? rbf(sqrtf(hh)) : sqrtf(hh);
+    float pq2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = ((wave * PER + k) * 64 + lane) * 4;
+        const bool ok = i < hidden;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[k][j] = x[k][j] / ns * nh;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pq2 += ok ? x[k][j] * x[k][j] : 0.f;
+        if (ok) *reinterpret_cast<floatx4*>(out + base + i) = x[k];
+    }
+    const float q2 = wide_combine(pq2, red[2], wave, lane);
+    const float rs = rsqrtf(q2 / (float)hidden + eps);
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = ((wave * PER + k) * 64 + lane) * 4;
+        if (i < hidden) {
+            floatx4 y;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[j] = wv[k][j] * rbf(x[k][j] * rs);
+            store4_bf16(xn, base + i, y);
+        }
+    }
+}
+
+template <int DT, int NCH>
+__global__ __launch_bounds__(256)
+void add_rmsnorm_wide_k(void* __restrict__ h, const bf16_t* __restrict__ w, bf16_t* __restrict__ out, int dim, float eps, int flavour,
+                        const float* __restrict__ row_gate, int use_scale, float scale, WsSrc src) {
+    constexpr int PER = NCH / 4;
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row = blockIdx.x, base = row * dim;
+    const bool closed = row_gate && row_gate[row] == 0.0f;
+    floatx4 v[PER], wv[PER], bv[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = ((wave * PER + k) * 64 + lane) * 4, ii = i < dim ? i : 0;
+        v[k] = RowIO<DT>::load4(h, base + ii);
+        wv[k] = RowIO<LICV_BF16>::load4(w, ii);
+    }
+    wide_branch_from_slices<PER>(src, row, dim, wave, lane, bv);
+    float pss = 0.f;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = ((wave * PER + k) * 64 + lane) * 4;
+        const bool ok = i < dim;
+        floatx4 b = bv[k];
+        if (closed) b = floatx4{0.f, 0.f, 0.f, 0.f};
+        if (use_scale) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = rbf(scale * b[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[k][j] = (DT == LICV_BF16) ? rbf(v[k][j] + b[j]) : v[k][j] + b[j];
+            pss += ok ? v[k][j] * v[k][j] : 0.f;
+        }
+        if (ok) {
+            if (DT == LICV_BF16) store4_bf16(h, base + i, v[k]);
+            else *reinterpret_cast<floatx4*>(reinterpret_cast<float*>(h) + base + i) = v[k];
+        }
+    }
+    const float ss = wide_combine(pss, red, wave, lane);
+    const float rs = rsqrtf(ss / (float)dim + eps);
+    const bool single_round = (flavour == 1 && DT == LICV_F32);
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = ((wave * PER + k) * 64 + lane) * 4;
+        if (i < dim) {
+            floatx4 y;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float n = v[k][j] * rs;
+                y[j] = wv[k][j] * (single_round ? n : rbf(n));
+            }
+            store4_bf16(out, base + i, y);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1000,6 +1174,15 @@ extern "C" int licv_inject_renorm_pre_fwd_ws(const void* h, int h_dtype, const f
     LICV_CHECK_ARG(nch > 0, "inject_renorm_pre_fwd_ws: hidden %lld unsupported", (long long)hidden);
     hipStream_t st = (hipStream_t)stream;
     const WsSrc src{ws, splits, slice_elems, row_stride};
+    if (nch % 4 == 0) {                                    // the wide form: the row over the four waves of its workgroup
+#define LAUNCH_INJWIDE(DTV, NC) inject_renorm_wide_k<DTV, NC><<<dim3((unsigned)rows), dim3(256), 0, st>>>( \
+            h, icv_row, alpha, out, (int)hidden, (const bf16_t*)norm_w, (bf16_t*)xn_out, norm_eps, src)
+        if (h_dtype == LICV_F32) { switch (nch) { case 4: LAUNCH_INJWIDE(LICV_F32, 4); break; case 8: LAUNCH_INJWIDE(LICV_F32, 8); break; case 16: LAUNCH_INJWIDE(LICV_F32, 16); break; default: LAUNCH_INJWIDE(LICV_F32, 32); break; } }
+        else                     { switch (nch) { case 4: LAUNCH_INJWIDE(LICV_BF16, 4); break; case 8: LAUNCH_INJWIDE(LICV_BF16, 8); break; case 16: LAUNCH_INJWIDE(LICV_BF16, 16); break; default: LAUNCH_INJWIDE(LICV_BF16, 32); break; } }
+#undef LAUNCH_INJWIDE
+        LICV_LAUNCH_CHECK();
+        return LICV_OK;
+    }
 #define LAUNCH_INJW(DTV) inject_renorm_fwd_k<DTV, N, true, true><<<dim3((unsigned)rows), dim3(256), 0, st>>>( \
         h, icv_row, alpha, out, rows, (int)hidden, (const bf16_t*)norm_w, (bf16_t*)xn_out, norm_eps, nullptr, 0, 0, nullptr, Q8Out{nullptr, nullptr}, src)
     if (h_dtype == LICV_F32) { DISPATCH_NCH(nch, LAUNCH_INJW(LICV_F32)); } else { DISPATCH_NCH(nch, LAUNCH_INJW(LICV_BF16)); }
@@ -1089,6 +1272,15 @@ extern "C" int licv_add_rmsnorm_fwd_ws(void* h, int h_dtype, const float* ws, in
     LICV_CHECK_ARG(nch > 0, "add_rmsnorm_fwd_ws: dim %lld unsupported", (long long)dim);
     hipStream_t st = (hipStream_t)stream;
     const WsSrc src{ws, splits, slice_elems, row_stride};
+    if (nch % 4 == 0) {                                    // the wide form: the row over the four waves of its workgroup
+#define LAUNCH_ARMSWIDE(DTV, NC) add_rmsnorm_wide_k<DTV, NC><<<dim3((unsigned)rows), dim3(256), 0, st>>>(h, (const bf16_t*)w, (bf16_t*)out, (int)dim, eps, flavour, \
+            row_gate, use_scale, scale, src)
+        if (h_dtype == LICV_F32) { switch (nch) { case 4: LAUNCH_ARMSWIDE(LICV_F32, 4); break; case 8: LAUNCH_ARMSWIDE(LICV_F32, 8); break; case 16: LAUNCH_ARMSWIDE(LICV_F32, 16); break; default: LAUNCH_ARMSWIDE(LICV_F32, 32); break; } }
+        else                     { switch (nch) { case 4: LAUNCH_ARMSWIDE(LICV_BF16, 4); break; case 8: LAUNCH_ARMSWIDE(LICV_BF16, 8); break; case 16: LAUNCH_ARMSWIDE(LICV_BF16, 16); break; default: LAUNCH_ARMSWIDE(LICV_BF16, 32); break; } }
+#undef LAUNCH_ARMSWIDE
+        LICV_LAUNCH_CHECK();
+        return LICV_OK;
+    }
 #define LAUNCH_ARMSW(DTV) add_rmsnorm_fwd_k<DTV, N, true><<<dim3((unsigned)rows), dim3(256), 0, st>>>(h, nullptr, (const bf16_t*)w, (bf16_t*)out, rows, (int)dim, eps, flavour, \
         row_gate, use_scale, scale, Q8Out{nullptr, nullptr}, src)
     if (h_dtype == LICV_F32) { DISPATCH_NCH(nch, LAUNCH_ARMSW(LICV_F32)); } else { DISPATCH_NCH(nch, LAUNCH_ARMSW(LICV_BF16)); }

@@ -143,6 +143,18 @@ extern "C" int licv_idefics_text_forward(const licv_idefics_text_weights* w, con
         a.q = c->qkv; a.q_bs = S * 3 * H; a.q_rs = 3 * H;
         a.o = c->o; a.B = B; a.Sq = S; a.n_heads = nh; a.n_kv_heads = nh; a.head_dim = hd; a.scale = att_scale; a.mask_mode = 1;
         a.key_valid = c->key_valid; a.img_mask = nullptr; a.n_img = 0; a.img_len = 0;
+        if (c->kv_cache && S == 1) {
+            // a decode step (one new token per row): rotary, the append to the row's cache and the attention over its history in ONE launch
+            // (csrc/decode.hip); with c->kv_rows the history is read through the beam search's row table - the cache itself never moves
+            licv_decode_attn_args d;
+            d.qkv_ws = qs.ws; d.splits = qs.splits; d.slice_elems = qs.slice; d.row_stride = qs.stride;
+            d.qkv_bf16 = qs.ws ? nullptr : c->qkv; d.ldq = 3 * H;
+            d.cos = w->cos; d.sin = w->sin; d.position_ids = c->position_ids; d.n_pos = w->rope_len;
+            d.cache = c->kv_cache[l]; d.max_len = c->cache_max_len; d.past = c->past;
+            d.kv_rows = c->kv_rows; d.ld_kv_rows = c->ld_kv_rows; d.key_valid = c->key_valid;
+            d.out = c->o; d.M = M; d.n_heads = nh; d.n_kv_heads = nh; d.head_dim = hd; d.scale = att_scale;
+            RUN(licv_decode_attn(&d, stream));
+        } else {
         if (!c->kv_cache) {
             a.k = (const char*)c->qkv + H * 2; a.v = (const char*)c->qkv + 2 * H * 2; a.kv_bs = S * 3 * H; a.kv_rs = 3 * H; a.Sk = S;
         } else {
@@ -154,6 +166,7 @@ extern "C" int licv_idefics_text_forward(const licv_idefics_text_weights* w, con
             a.k = cache; a.v = (const char*)cache + H * 2; a.kv_bs = c->cache_max_len * 2 * H; a.kv_rs = 2 * H; a.Sk = c->Sk;
         }
         RUN(licv_attn_fwd(&a, stream));
+        }
         const int slot = (c->hook_slot && c->icv) ? c->hook_slot[l] : -1;
         // Large batches (the 256-tile GEMMs): the two residual adds of the layer leave the GEMM epilogues — a read-modify-write of the
         // fp32 stream costs the o / down projections 16-28 % — and are folded into the row kernels that follow them (same sums, same

@@ -53,7 +53,17 @@ class BeamStepArgs(C.Structure):
                 ("is_fin_in", C.c_void_p), ("improve_in", C.c_void_p), ("gen_len_in", C.c_void_p),
                 ("running_out", C.c_void_p), ("finished_out", C.c_void_p), ("run_scores_out", C.c_void_p), ("fin_scores_out", C.c_void_p),
                 ("is_fin_out", C.c_void_p), ("improve_out", C.c_void_p), ("gen_len_out", C.c_void_p),
-                ("beam_src_flat", C.c_void_p), ("next_tokens", C.c_void_p), ("flags", C.c_void_p), ("sync", C.c_void_p)]
+                ("beam_src_flat", C.c_void_p), ("next_tokens", C.c_void_p), ("flags", C.c_void_p), ("sync", C.c_void_p),
+                ("kv_rows_in", C.c_void_p), ("kv_rows_out", C.c_void_p), ("kv_ld", C.c_int64)]
+
+
+class DecodeAttnArgs(C.Structure):
+    _fields_ = [("qkv_ws", C.c_void_p), ("splits", C.c_int), ("slice_elems", C.c_int64), ("row_stride", C.c_int64),
+                ("qkv_bf16", C.c_void_p), ("ldq", C.c_int64),
+                ("cos", C.c_void_p), ("sin", C.c_void_p), ("position_ids", C.c_void_p), ("n_pos", C.c_int64),
+                ("cache", C.c_void_p), ("max_len", C.c_int64), ("past", C.c_int64),
+                ("kv_rows", C.c_void_p), ("ld_kv_rows", C.c_int64), ("key_valid", C.c_void_p), ("out", C.c_void_p),
+                ("M", C.c_int64), ("n_heads", C.c_int64), ("n_kv_heads", C.c_int64), ("head_dim", C.c_int64), ("scale", C.c_float)]
 
 
 def declared_symbols(header: Path = HEADER):
@@ -118,6 +128,7 @@ def lib() -> C.CDLL:
             "licv_attn_select": [I],
             "licv_attn_fwd": [C.POINTER(AttnArgs), P],
             "licv_beam_step": [C.POINTER(BeamStepArgs), P],
+            "licv_decode_attn": [C.POINTER(DecodeAttnArgs), P],
             "licv_embed_gather": [P, P, P, P, I64, I64, I64, I64, P],
             "licv_im2col_patches": [P, P, I64, I64, I64, I64, I64, P],
             "licv_vit_embed_ln": [P, P, P, P, P, P, I64, I64, I64, F, P],

@@ -23,11 +23,11 @@ def _last_rows(B: int, S: int, dev) -> torch.Tensor:
 class _IdeficsDecoder:
     """Model side of the search for Idefics: image states + per-token image mask + KV cache."""
 
-    def __init__(self, engine: IdeficsEngine, pixel_values, image_attention_mask, batch, max_len, hooks):
+    def __init__(self, engine: IdeficsEngine, pixel_values, image_attention_mask, batch, max_len, hooks, beams: int = 1):
         self.e, self.hooks = engine, hooks
         self.image_states = engine.encode_images(pixel_values)
         self.iam = image_attention_mask
-        self.cache = KVCache(engine.arch, batch, max_len, engine.w.device)
+        self.cache = KVCache(engine.arch, batch, max_len, engine.w.device, beams=beams)
 
     def _fwd(self, ids, am, iam):
         B, S = ids.shape
@@ -52,17 +52,23 @@ class _IdeficsDecoder:
     def reorder(self, flat):
         self.cache.reorder(flat)
 
+    def kv_rows(self):                             # the cache's row table (after replicate): licv_beam_step keeps it up to date itself
+        return self.cache.rows
+
+    def reorder_with_rows(self, flat, rows):
+        self.cache.set_rows(rows)
+
 
 class _Idefics2Decoder:
     """Idefics2: image hidden states only feed the prefill (they are scattered into the prompt embeddings); decode steps
     need the KV cache and HF's generate-time position ids (cumsum(mask)-1 with pads at 0, then previous+1 per step:
     transformers generation/utils.py:751-773, :975-985)."""
 
-    def __init__(self, engine, pixel_values, pixel_attention_mask, batch, max_len, hooks):
+    def __init__(self, engine, pixel_values, pixel_attention_mask, batch, max_len, hooks, beams: int = 1):
         from .idefics2_engine import KVCache2
         self.e, self.hooks = engine, hooks
         self.img = engine.encode_images(pixel_values, pixel_attention_mask) if pixel_values is not None else None
-        self.cache = KVCache2(engine.arch, batch, max_len, engine.w.device)
+        self.cache = KVCache2(engine.arch, batch, max_len, engine.w.device, beams=beams)
         self.pos = None
 
     def _fwd(self, ids, am, img):
@@ -88,13 +94,20 @@ class _Idefics2Decoder:
         self.cache.reorder(flat)
         self.pos = self.pos.index_select(0, flat)
 
+    def kv_rows(self):
+        return self.cache.rows
+
+    def reorder_with_rows(self, flat, rows):
+        self.cache.set_rows(rows)
+        self.pos = self.pos.index_select(0, flat)
+
 
 @torch.no_grad()
 def generate(engine: IdeficsEngine, input_ids: torch.Tensor, attention_mask: torch.Tensor, pixel_values: torch.Tensor,
              image_attention_mask: torch.Tensor, icv: Optional[torch.Tensor] = None,
              hook_layers: Optional[Sequence[int]] = None, max_new_tokens: int = 5, num_beams: int = 1, **kw) -> torch.Tensor:
     hooks = dict(icv=icv, hook_layers=hook_layers) if icv is not None else {}
-    model = _IdeficsDecoder(engine, pixel_values, image_attention_mask, input_ids.shape[0], input_ids.shape[1] + max_new_tokens, hooks)
+    model = _IdeficsDecoder(engine, pixel_values, image_attention_mask, input_ids.shape[0], input_ids.shape[1] + max_new_tokens, hooks, beams=num_beams)
     return _decode(model, engine.arch, input_ids, attention_mask, max_new_tokens=max_new_tokens, num_beams=num_beams, **kw)
 
 
@@ -103,7 +116,7 @@ def generate_idefics2(engine, input_ids: torch.Tensor, attention_mask: torch.Ten
                       pixel_attention_mask: Optional[torch.Tensor] = None, icv: Optional[torch.Tensor] = None,
                       hook_layers: Optional[Sequence[int]] = None, max_new_tokens: int = 5, num_beams: int = 1, **kw) -> torch.Tensor:
     hooks = dict(icv=icv, hook_layers=hook_layers) if icv is not None else {}
-    model = _Idefics2Decoder(engine, pixel_values, pixel_attention_mask, input_ids.shape[0], input_ids.shape[1] + max_new_tokens, hooks)
+    model = _Idefics2Decoder(engine, pixel_values, pixel_attention_mask, input_ids.shape[0], input_ids.shape[1] + max_new_tokens, hooks, beams=num_beams)
     return _decode(model, engine.arch, input_ids, attention_mask, max_new_tokens=max_new_tokens, num_beams=num_beams, **kw)
 
 
@@ -149,9 +162,11 @@ def _decode(model, a, input_ids: torch.Tensor, attention_mask: torch.Tensor, max
     # hf:generation/utils.py:3319 — `output_fill_value = pad_token_id or eos_token_id[0]`: a pad id of 0 (Idefics' <unk>) is falsy
     # there, so finished beams are padded with EOS, not with the pad id (greedy above does use the pad id)
     fill = pad if (pad or eos is None) else eos
-    search = BeamSearchState(B, nb, P, max_len, fill, input_ids, eos, length_penalty, early_stopping, min_new_tokens)
-    # replicate the prompt state per beam (HF prefills B*nb identical rows instead); the first step reads the B prefill rows directly
+    # the prompt state is shared by a question's beams (HF prefills B*nb identical rows instead): no copy of the KV cache, only its row
+    # table, which the search kernel then keeps up to date itself; the first step reads the B prefill rows directly
     model.replicate(nb)
+    table = model.kv_rows() if hasattr(model, "kv_rows") and hasattr(model, "reorder_with_rows") else None
+    search = BeamSearchState(B, nb, P, max_len, fill, input_ids, eos, length_penalty, early_stopping, min_new_tokens, kv_rows=table)
     am = attention_mask.repeat_interleave(nb, 0)
     first = True
     while True:
@@ -160,7 +175,10 @@ def _decode(model, a, input_ids: torch.Tensor, attention_mask: torch.Tensor, max
         if not unfinished:
             break
         # reorder the per-beam model state (after the exit test: the last step's reorder would feed no further forward)
-        model.reorder(search.beam_src_flat)
+        if search.kv_rows is not None:
+            model.reorder_with_rows(search.beam_src_flat, search.kv_rows)
+        else:
+            model.reorder(search.beam_src_flat)
         am = torch.cat([am, torch.ones((B * nb, 1), dtype=am.dtype, device=dev)], 1)
         logits = model.step(search.next_tokens.view(B * nb, 1), am)
     return search.result()
@@ -170,7 +188,7 @@ class BeamSearchState:
     """Device-side state of one beam search (running / finished token rows, scores, flags), advanced by `licv_beam_step`.
     Two copies of every buffer: the kernel gathers rows of the old state into the new one."""
 
-    def __init__(self, B, nb, P, max_len, fill, input_ids, eos, length_penalty, early_stopping, min_new_tokens):
+    def __init__(self, B, nb, P, max_len, fill, input_ids, eos, length_penalty, early_stopping, min_new_tokens, kv_rows=None):
         dev = input_ids.device
         self.B, self.nb, self.P, self.max_len, self.cur = B, nb, P, max_len, P
         self.eos = -1 if eos is None else int(eos)
@@ -188,6 +206,9 @@ class BeamSearchState:
         self.next_tokens = torch.empty((B * nb,), dtype=torch.long, device=dev)
         self.flags = torch.zeros((1,), dtype=torch.int32, device=dev)
         self.sync = torch.zeros((4,), dtype=torch.int32, device=dev)
+        # optional: the KV cache's row table (B*nb, cache max_len) int32, ping-ponged like the rest of the state
+        self.kv_rows = kv_rows
+        self._kv_rows_next = torch.empty_like(kv_rows) if kv_rows is not None else None
 
     def step(self, logits: torch.Tensor, shared_rows: bool = False) -> bool:
         """logits: (B*nb, V) rows (bf16 or fp32, row stride = stride(0)); shared_rows: (B, V) rows of the prefill that all beams of a
@@ -209,7 +230,12 @@ class BeamSearchState:
             setattr(a, k + "_out", dst[k].data_ptr())
         a.beam_src_flat, a.next_tokens = self.beam_src_flat.data_ptr(), self.next_tokens.data_ptr()
         a.flags, a.sync = self.flags.data_ptr(), self.sync.data_ptr()
+        if self.kv_rows is not None:
+            assert self.kv_rows.dtype == torch.int32 and self.kv_rows.is_contiguous() and self.kv_rows.shape[0] == self.B * self.nb
+            a.kv_rows_in, a.kv_rows_out, a.kv_ld = self.kv_rows.data_ptr(), self._kv_rows_next.data_ptr(), self.kv_rows.shape[1]
         check(_lib.lib().licv_beam_step(C.byref(a), _stream(logits)))
+        if self.kv_rows is not None:
+            self.kv_rows, self._kv_rows_next = self._kv_rows_next, self.kv_rows
         self.state = [dst, src]
         self.cur += 1
         return bool(int(self.flags[0]))

@@ -21,7 +21,7 @@ import torch
 
 from . import frontend, ops
 from .config import Idefics2Arch
-from .idefics_engine import _bf, _pad_cols
+from .idefics_engine import KVCache, _bf, _pad_cols
 
 
 @dataclass
@@ -123,26 +123,11 @@ class Idefics2Weights:
         self.max_positions = max_positions
 
 
-class KVCache2:
-    """Per-layer (B, max_len, [K | V] = 2 * n_kv_heads * head_dim) bf16 cache for hooked generate."""
+class KVCache2(KVCache):
+    """Per-layer (rows, max_len, [K | V] = 2 * n_kv_heads * head_dim) bf16 cache for hooked generate; see KVCache (row table, no moves)."""
 
-    def __init__(self, arch: Idefics2Arch, batch: int, max_len: int, device):
-        self.max_len, self.len = max_len, 0
-        # one allocation for all layers: the beam reorder of a decode step is then ONE gather launch instead of one per layer
-        self._all = torch.empty((arch.num_layers, batch, max_len, 2 * arch.num_kv_heads * arch.head_dim), dtype=torch.bfloat16, device=device)
-        self.kv = list(self._all.unbind(0))
-
-    def reorder(self, idx: torch.Tensor):
-        # rows (layer, beam) of the flattened cache: index_select along dim 0 takes torch's vectorised gather (along dim 1 of the 4-d
-        # tensor it falls to a generic element-wise kernel, 8x slower than the per-layer gathers it was meant to replace)
-        L, B = self._all.shape[:2]
-        rows = (torch.arange(L, device=idx.device).unsqueeze(1) * B + idx.unsqueeze(0)).reshape(-1)
-        self._all = self._all.reshape(L * B, -1).index_select(0, rows).view(L, idx.numel(), *self._all.shape[2:])
-        self.kv = list(self._all.unbind(0))
-
-    def replicate(self, nb: int):                  # every row nb times, in place (beams of one question start from one prefill)
-        self._all = self._all.repeat_interleave(nb, 1)
-        self.kv = list(self._all.unbind(0))
+    def __init__(self, arch: Idefics2Arch, batch: int, max_len: int, device, beams: int = 1):
+        super().__init__(arch, batch, max_len, device, beams=beams, width=2 * arch.num_kv_heads * arch.head_dim)
 
 
 class _HostFlags:
@@ -408,9 +393,17 @@ class Idefics2Engine:
             else:
                 x = ops.rmsnorm(h, L.in_ln, a.rms_eps, 1)
             xn = None
-            qkv = self._tlin(x, L, "qkv_w")
-            ops.rotary_(qkv, w.cos, w.sin, pos, M, nh + nkv, hd, ldq, 0, 1)       # Q heads | K heads are contiguous in the fused row: one launch
-            if kv_cache is None:
+            if kv_cache is not None and S == 1:                       # a decode step: rotary + append + GQA attention in one launch
+                qs = ops.linear_produce(x, L.qkv_w) if not isinstance(x, tuple) else None
+                o = ops.decode_attn(qs if qs is not None else self._tlin(x, L, "qkv_w"), w.cos, w.sin, pos, kv_cache.kv[l], past, nh, nkv, hd,
+                                    hd ** -0.5, key_valid=key_valid, kv_rows=kv_cache.rows)
+                qkv = None
+            else:
+                qkv = self._tlin(x, L, "qkv_w")
+                ops.rotary_(qkv, w.cos, w.sin, pos, M, nh + nkv, hd, ldq, 0, 1)   # Q heads | K heads are contiguous in the fused row: one launch
+            if qkv is None:
+                pass
+            elif kv_cache is None:
                 o = ops.attention(qkv, qkv.view(-1)[qd:], qkv.view(-1)[qd + kd:], B, S, S, nh, nkv, hd, S * ldq, ldq, S * ldq, ldq,
                                   hd ** -0.5, 1, key_valid=key_valid)
             else:

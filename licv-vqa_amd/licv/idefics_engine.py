@@ -139,27 +139,42 @@ class IdeficsWeights:
 
 
 class KVCache:
-    """Per-layer (B, max_len, 2, H) bf16 self-attention cache for hooked generate."""
+    """Per-layer (rows, max_len, [K | V]) bf16 self-attention cache for hooked generate, ONE allocation for all layers.
 
-    def __init__(self, arch: IdeficsArch, batch: int, max_len: int, device):
-        H = arch.hidden_size
-        self.max_len, self.len = max_len, 0
-        # one allocation for all layers: the beam reorder of a decode step is then ONE gather launch instead of one per layer
-        self._all = torch.empty((arch.num_layers, batch, max_len, 2 * H), dtype=torch.bfloat16, device=device)
-        self.kv = list(self._all.unbind(0))
+    Beam search never moves it.  The cache is allocated with batch x beams rows; the prefill fills the first `batch` rows (question b's
+    prompt in row b); `replicate` only builds the row table `rows` (rows x max_len int32: the physical row that holds position p of
+    beam row r's history); a decode step appends row r's new token to physical row r (positions >= prompt length, so prompts and
+    appended tokens never collide) and reads its history through the table (licv_decode_attn); a beam reorder permutes table rows
+    (licv_beam_step writes the new table itself; `reorder` is the torch form of the same update for callers that only have the
+    source-beam indices).  The gather of the whole cache per step - and its transient second copy - is gone."""
+
+    def __init__(self, arch, batch: int, max_len: int, device, beams: int = 1, width: Optional[int] = None):
+        width = 2 * arch.hidden_size if width is None else width
+        self.max_len, self.len, self.batch, self.beams = max_len, 0, batch, beams
+        self._all = torch.empty((arch.num_layers, batch * beams, max_len, width), dtype=torch.bfloat16, device=device)
+        self.kv = [t[:batch] for t in self._all.unbind(0)]          # the prefill's view: the first `batch` rows of every layer
+        self.rows = None       # (batch * beams, max_len) int32 after replicate(); None: every row reads its own cache row
         self.xkv = None        # cross-attention K|V per gated layer, projected once at the prefill by the native runner (step-invariant)
 
-    def reorder(self, idx: torch.Tensor):
-        # rows (layer, beam) of the flattened cache: index_select along dim 0 takes torch's vectorised gather (along dim 1 of the 4-d
-        # tensor it falls to a generic element-wise kernel, 8x slower than the per-layer gathers it was meant to replace)
-        L, B = self._all.shape[:2]
-        rows = (torch.arange(L, device=idx.device).unsqueeze(1) * B + idx.unsqueeze(0)).reshape(-1)
-        self._all = self._all.reshape(L * B, -1).index_select(0, rows).view(L, idx.numel(), *self._all.shape[2:])
+    def replicate(self, nb: int):
+        """The prompt state of every question is shared by its `nb` beams: no copy, only the row table."""
+        assert nb == self.beams, f"the cache was allocated for {self.beams} beams per question, not {nb}"
+        n = self.batch * nb
+        dev = self._all.device
+        own = torch.arange(n, device=dev, dtype=torch.int32)
+        self.rows = own.unsqueeze(1).repeat(1, self.max_len)
+        self.rows[:, : self.len] = (own // nb).unsqueeze(1)
         self.kv = list(self._all.unbind(0))
 
-    def replicate(self, nb: int):                  # every row nb times, in place (beams of one question start from one prefill)
-        self._all = self._all.repeat_interleave(nb, 1)
-        self.kv = list(self._all.unbind(0))
+    def reorder(self, idx: torch.Tensor):
+        """Beam r continues the history of beam idx[r]; its next token goes to its own row."""
+        rows = self.rows.index_select(0, idx)
+        rows[:, self.len] = torch.arange(rows.shape[0], device=rows.device, dtype=torch.int32)
+        self.rows = rows
+
+    def set_rows(self, rows: torch.Tensor):
+        """The table as licv_beam_step left it (same content as reorder(), no launch)."""
+        self.rows = rows
 
 
 class IdeficsEngine:
@@ -378,6 +393,10 @@ class IdeficsEngine:
                 ops.rotary_(qkv, w.cos, w.sin, pos, M, nh, hd, 3 * H, H, 2)
                 o = ops.attention(qkv, qkv.view(-1)[H:], qkv.view(-1)[2 * H:], B, S, S, nh, nh, hd, S * 3 * H, 3 * H,
                                   S * 3 * H, 3 * H, hd ** -0.5, 1, key_valid=key_valid)
+            elif S == 1:                                                 # a decode step: rotary + append + attention in one launch
+                qs = ops.linear_produce(x, D.qkv_w)
+                o = ops.decode_attn(qs if qs is not None else ops.linear(x, D.qkv_w), w.cos, w.sin, pos, kv_cache.kv[l], past, nh, nh, hd,
+                                    hd ** -0.5, key_valid=key_valid, kv_rows=kv_cache.rows)
             else:
                 qkv = ops.linear(x, D.qkv_w)
                 ops.rotary_(qkv, w.cos, w.sin, pos, M, nh, hd, 3 * H, H, 2)

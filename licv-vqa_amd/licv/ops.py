@@ -326,6 +326,39 @@ def rotary_kv_append(qkv, cos: torch.Tensor, sin: torch.Tensor, position_ids: to
     return qkv
 
 
+def decode_attn(qkv, cos: torch.Tensor, sin: torch.Tensor, position_ids: torch.Tensor, cache: torch.Tensor, past: int, n_heads: int,
+                n_kv_heads: int, head_dim: int, scale: float, key_valid: Optional[torch.Tensor] = None,
+                kv_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """One decode step's attention block in one launch (licv_decode_attn): qkv = the (M, [Q | K | V]) bf16 rows of the fused projection or
+    its split-K Slices; rotary, K | V appended to cache[r, past], attention over positions 0..past (read through kv_rows when given).
+    cache: (rows >= M, max_len, 2 * n_kv_heads * head_dim) bf16.  Returns O (M, n_heads * head_dim) bf16."""
+    from ._lib import DecodeAttnArgs
+    kd = n_kv_heads * head_dim
+    assert cache.dtype == torch.bfloat16 and cache.is_contiguous() and cache.shape[2] == 2 * kd
+    a = DecodeAttnArgs()
+    if isinstance(qkv, Slices):
+        M = qkv.rows
+        assert qkv.cols == (n_heads + 2 * n_kv_heads) * head_dim
+        a.qkv_ws, a.splits, a.slice_elems, a.row_stride = qkv.ws.data_ptr(), qkv.splits, qkv.slice_elems, qkv.row_stride
+    else:
+        assert qkv.dtype == torch.bfloat16 and qkv.dim() == 2 and qkv.stride(1) == 1
+        M = qkv.shape[0]
+        a.qkv_bf16, a.ldq = qkv.data_ptr(), qkv.stride(0)
+    assert cache.shape[0] >= M and position_ids.numel() == M and position_ids.dtype == torch.int64
+    out = torch.empty((M, n_heads * head_dim), dtype=torch.bfloat16, device=cache.device)
+    a.cos, a.sin, a.position_ids, a.n_pos = cos.data_ptr(), sin.data_ptr(), position_ids.data_ptr(), cos.shape[0]
+    a.cache, a.max_len, a.past = cache.data_ptr(), cache.shape[1], int(past)
+    if kv_rows is not None:
+        assert kv_rows.dtype == torch.int32 and kv_rows.is_contiguous() and kv_rows.shape[0] >= M
+        a.kv_rows, a.ld_kv_rows = kv_rows.data_ptr(), kv_rows.shape[1]
+    if key_valid is not None:
+        assert key_valid.dtype == torch.int32 and key_valid.is_contiguous() and key_valid.shape == (M, past + 1)
+        a.key_valid = key_valid.data_ptr()
+    a.out, a.M, a.n_heads, a.n_kv_heads, a.head_dim, a.scale = out.data_ptr(), M, n_heads, n_kv_heads, head_dim, float(scale)
+    check(_lib.lib().licv_decode_attn(C.byref(a), _stream(cache)))
+    return out
+
+
 def quantize_fp8(x: torch.Tensor):
     """Per-row dynamic quantisation to OCP e4m3: returns (q uint8 (rows, K), scale fp32 (rows,))."""
     assert x.dim() == 2 and x.stride(1) == 1

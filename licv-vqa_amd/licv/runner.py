@@ -31,7 +31,8 @@ class _Weights(C.Structure):
 class _Call(C.Structure):
     _fields_ = [(n, P) for n in ("input_ids", "key_valid", "position_ids", "image_states", "img_mask", "gate")] + \
                [(n, I64) for n in ("B", "S", "Sk", "Nk", "n_img")] + [("icv", P), ("alpha", P), ("hook_slot", C.POINTER(C.c_int32))] + \
-               [("kv_cache", C.POINTER(P)), ("cache_max_len", I64), ("past", I64), ("xkv_cached", C.POINTER(P)), ("xkv_out", C.POINTER(P)),
+               [("kv_cache", C.POINTER(P)), ("cache_max_len", I64), ("past", I64), ("kv_rows", P), ("ld_kv_rows", I64),
+                ("xkv_cached", C.POINTER(P)), ("xkv_out", C.POINTER(P)),
                 ("logits_rows", P), ("n_rows", I64)] + \
                [(n, P) for n in ("h16", "h32", "x", "xn", "q", "qkv", "o", "act", "xkv", "xsel")] + \
                [("workspace", P), ("workspace_bytes", I64), ("logits", P), ("ld_logits", I64)]
@@ -114,6 +115,8 @@ class TextRunner:
         if kv_cache is not None:
             kv_arr = (P * a.num_layers)(*[t.data_ptr() for t in kv_cache.kv])
             c.kv_cache, c.cache_max_len, c.past = kv_arr, kv_cache.max_len, kv_cache.len
+            if S == 1 and getattr(kv_cache, "rows", None) is not None:   # decode step of a beam search: history read through the row table
+                c.kv_rows, c.ld_kv_rows = kv_cache.rows.data_ptr(), kv_cache.rows.shape[1]
             if getattr(kv_cache, "xkv", None) is not None:               # cross-attention K|V projected at the prefill
                 xc_arr = (P * n_x)(*[t.data_ptr() for t in kv_cache.xkv])
                 c.xkv_cached = xc_arr

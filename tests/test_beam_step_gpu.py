@@ -29,11 +29,12 @@ def _run(B, nb, V, P, new, dtype, eos, lp, early, min_new, seed, peaked):
         ld = (V + 7) // 8 * 8 + 8
         buf = torch.randn(rows, ld, generator=g) * (0.5 if peaked else 1.0)
         # the top of every row is decided without ties (bf16 logits tie easily; what torch.topk does with a tie is unspecified, the
-        # kernel takes the lower index): 3 * keep tokens per row get distinct, exactly representable values above the noise
+        # kernel takes the lower index): 3 * keep tokens per row get distinct values above the noise, 0.5 - 1 apart and off any lattice
+        # (values on a lattice made the cumulative scores of different beams collide to within one fp32 ulp)
         n_top = 6 * nb
         for r in range(rows):
             toks = torch.randperm(V, generator=g)[:n_top]
-            buf[r, toks] = 6.0 + 0.75 * torch.arange(n_top, dtype=torch.float32)[torch.randperm(n_top, generator=g)]
+            buf[r, toks] = 6.0 + 0.75 * torch.arange(n_top, dtype=torch.float32)[torch.randperm(n_top, generator=g)] + 0.25 * torch.rand(n_top, generator=g)
             if eos is not None and float(torch.rand((), generator=g)) < (0.5 if peaked else 0.25):
                 buf[r, eos] = 6.0 + 0.75 * (n_top - 1) + (0.375 if float(torch.rand((), generator=g)) < 0.5 else -1.875)   # EOS near / at the top
         buf = buf.to(dtype)

@@ -1,0 +1,102 @@
+"""licv_decode_attn (csrc/decode.hip): one decode step's rotary + KV append + attention in one launch, with the beam search's
+cache-row table, against (a) the oracle's arithmetic — rotary with every bf16 op rounded (oracle/idefics_ref.apply_rotary, bit
+for bit into the cache), attention in fp64 on the rounded operands (hf eager_attention_forward: the kernel, like
+csrc/attention.hip, keeps scores in fp32 and rounds P un-normalised, so the bar is 2 bf16 ulp of the output scale) — and (b) the
+launches it replaces (licv_rotary_kv_append + the tiled licv_attn_fwd over a gathered copy of the cache).  Shapes: the 9B / 8B head
+geometries (32 x 128 MHA, 32q / 8kv x 128 GQA), histories shorter and longer than one 64-key sweep, masked (left-padded) keys."""
+import pytest
+import torch
+
+from oracle import idefics_ref as R
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("from_slices", [False, True], ids=["bf16_rows", "split_k_slices"])
+@pytest.mark.parametrize("M,nh,nkv,hd,past", [(24, 32, 32, 128, 36), (24, 32, 8, 128, 101), (6, 4, 2, 64, 5), (9, 8, 8, 128, 200), (5, 4, 4, 96, 0)])
+def test_decode_attn_matches_oracle_and_the_launches_it_replaces(M, nh, nkv, hd, past, from_slices):
+    from licv import ops
+    g = torch.Generator().manual_seed(M * 1000 + past)
+    qd, kd = nh * hd, nkv * hd
+    ldq = qd + 2 * kd
+    K = 2048
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(ldq, K, generator=g) * K ** -0.5).to(torch.bfloat16).to(DEV)
+    qkv = ops.linear(a, w)                                              # the fused projection's bf16 rows
+    src = qkv
+    if from_slices:
+        src = ops.linear_produce(a, w)
+        if src is None:
+            pytest.skip("the split-K plan keeps this shape in one pass")
+    n_pos, max_len, R_rows = 256, past + 4, M + 3
+    cos, sin = R.rotary_tables(hd, n_pos, 10000.0, torch.bfloat16)
+    pos = torch.randint(0, n_pos, (M,), generator=g)
+    cache0 = torch.randn(R_rows, max_len, 2 * kd, generator=g).to(torch.bfloat16)
+    rows = torch.randint(0, R_rows, (M, max_len), generator=g).to(torch.int32)
+    rows[:, past] = torch.arange(M, dtype=torch.int32)                  # a row's own new token lives in its own cache row
+    valid = (torch.rand(M, past + 1, generator=g) > 0.2).to(torch.int32)
+    valid[:, past] = 1
+    if M > 2:
+        valid[2, : max(past - 1, 0)] = 0                                # a row that sees (almost) only its own token
+    cache = cache0.clone().to(DEV)
+    out = ops.decode_attn(src, cos.to(DEV), sin.to(DEV), pos.to(DEV), cache, past, nh, nkv, hd, hd ** -0.5, key_valid=valid.to(DEV),
+                          kv_rows=rows.to(DEV))
+    # ---- (a) the oracle's arithmetic
+    x = qkv.cpu()
+    q = x[:, :qd].view(M, 1, nh, hd).transpose(1, 2)
+    k = x[:, qd:qd + kd].view(M, 1, nkv, hd).transpose(1, 2)
+    v = x[:, qd + kd:].view(M, nkv, hd)
+    cs, sn = cos[pos].view(M, 1, 1, hd), sin[pos].view(M, 1, 1, hd)
+    qr = (q * cs) + (R.rotate_half(q) * sn)
+    kr = (k * cs) + (R.rotate_half(k) * sn)
+    new_kv = torch.cat([kr.reshape(M, kd), v.reshape(M, kd)], 1)
+    got_cache = cache.cpu()
+    assert torch.equal(got_cache[:M, past], new_kv), "K (rotated) | V of the new token as appended to the cache"
+    keep = torch.ones_like(got_cache, dtype=torch.bool)
+    keep[:M, past] = False
+    assert torch.equal(got_cache[keep], cache0[keep]), "nothing else in the cache may change"
+    hist = cache0.clone()
+    hist[:M, past] = new_kv
+    jj = torch.arange(past + 1)
+    Kh = hist[rows[:, : past + 1].long(), jj[None, :], :kd].view(M, past + 1, nkv, hd)          # (M, Sk, nkv, hd) through the row table
+    Vh = hist[rows[:, : past + 1].long(), jj[None, :], kd:].view(M, past + 1, nkv, hd)
+    rep = nh // nkv
+    Kh, Vh = Kh.repeat_interleave(rep, 2).double(), Vh.repeat_interleave(rep, 2).double()
+    s = torch.einsum("mhd,mjhd->mhj", qr.reshape(M, nh, hd).double(), Kh) * hd ** -0.5
+    s = s.masked_fill(valid[:, None, :] == 0, float("-inf"))
+    ref = torch.einsum("mhj,mjhd->mhd", torch.softmax(s, -1), Vh).reshape(M, qd)
+    err = float((out.cpu().double() - ref).abs().max())
+    assert err <= 2 * 2.0 ** -8 * float(ref.abs().max()), f"decode attention vs fp64: {err:.3e} at scale {float(ref.abs().max()):.3e}"
+    # ---- (b) the launches it replaces: rotary + append on a physically gathered cache, then the tiled attention kernel
+    gathered = hist[rows[:, : past + 1].long(), jj[None, :]].contiguous()                       # (M, Sk, 2kd): what a cache reorder would have built
+    gc = torch.zeros(M, past + 1, 2 * kd, dtype=torch.bfloat16)
+    gc[:, :past] = gathered[:, :past]
+    gc = gc.to(DEV)
+    q2 = qkv.clone()
+    if nkv == nh:
+        ops.rotary_kv_append(q2, cos.to(DEV), sin.to(DEV), pos.to(DEV), M, 1, nh, hd, gc, past)
+    else:
+        ops.rotary_(q2, cos.to(DEV), sin.to(DEV), pos.to(DEV), M, nh + nkv, hd, ldq, 0, 1)
+        gc[:, past] = q2[:, qd:]
+    old = ops.attention(q2, gc, gc.view(-1)[kd:], M, 1, past + 1, nh, nkv, hd, ldq, ldq, (past + 1) * 2 * kd, 2 * kd, hd ** -0.5, 1,
+                        key_valid=valid.to(DEV))
+    d = (out.float() - old.view(M, qd).float()).abs()
+    assert float(d.max()) <= 2 * 2.0 ** -8 * float(ref.abs().max()), f"decode kernel vs rotary + tiled attention: {float(d.max()):.3e}"
+    assert float((d == 0).float().mean()) >= 0.90
+
+
+def test_decode_attn_without_a_row_table_reads_the_rows_own_history():
+    from licv import ops
+    g = torch.Generator().manual_seed(7)
+    M, nh, hd, past = 4, 4, 128, 9
+    H = nh * hd
+    qkv = torch.randn(M, 3 * H, generator=g).to(torch.bfloat16).to(DEV)
+    cos, sin = R.rotary_tables(hd, 64, 10000.0, torch.bfloat16)
+    pos = torch.full((M,), past, dtype=torch.int64)
+    c1 = torch.randn(M, past + 2, 2 * H, generator=g).to(torch.bfloat16).to(DEV)
+    c2 = c1.clone()
+    own = torch.arange(M, dtype=torch.int32).unsqueeze(1).repeat(1, past + 2).to(DEV)
+    o1 = ops.decode_attn(qkv, cos.to(DEV), sin.to(DEV), pos.to(DEV), c1, past, nh, nh, hd, hd ** -0.5)
+    o2 = ops.decode_attn(qkv, cos.to(DEV), sin.to(DEV), pos.to(DEV), c2, past, nh, nh, hd, hd ** -0.5, kv_rows=own)
+    assert torch.equal(o1, o2) and torch.equal(c1, c2)

@@ -281,7 +281,8 @@ def test_w6_idefics9b_widths_hooked_beam_generate_vs_oracle(nl, side):
     hooks = dict(icv=icv, hook_layers=layers)
     # ---- native search, model side wrapped by the recorder (same engine.forward / KV cache / runner as interface.generate)
     dev_batch = {k: v.to(DEV) for k, v in batch.items()}
-    model = NG._IdeficsDecoder(eng, dev_batch["pixel_values"], dev_batch["image_attention_mask"], B, 32 + 5, dict(icv=icv.to(DEV), hook_layers=layers))
+    model = NG._IdeficsDecoder(eng, dev_batch["pixel_values"], dev_batch["image_attention_mask"], B, 32 + 5, dict(icv=icv.to(DEV), hook_layers=layers),
+                               beams=nb)
     nrec = _Recorder(model)
     t0 = time.perf_counter()
     with torch.no_grad():
