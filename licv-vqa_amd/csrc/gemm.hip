@@ -1481,7 +1481,9 @@ void gemm_fp8_flow64_k(const char* __restrict__ A, int64_t lda, const char* __re
 // D = K tiles in flight ahead of the one being multiplied.  2: the ring of five pairs above (80 KiB, two workgroups per CU).  4: nine
 // pairs (144 KiB, one workgroup per CU): the W pieces of K tile t + D are issued D - 0.5 K tiles before their rendezvous instead of
 // 1.5 - an experiment (licv_gemm_experiment knob 10), bit-identical and no faster: see mid_deep().
-template <int SPLITK, int ABL = 0, int D = 2>      // ABL (timing only, wrong results): 1 = the A pieces are never issued, 2 = the W pieces
+// NT = 1: the W pieces (the once-read weight stream) carry the non-temporal cache policy (MI355X_MICROARCH.md, price list row nt-weights:
+// issued -> landed -18 % for once-read bytes; the A pieces, re-read by every workgroup from L2, keep the default policy).  knob 11.
+template <int SPLITK, int ABL = 0, int D = 2, int NT = 0>      // ABL (timing only, wrong results): 1 = the A pieces are never issued, 2 = the W pieces
 __global__ __launch_bounds__(256, 2)      // (also for D = 4, one workgroup per CU by LDS: with 512 registers allowed the allocator moves the accumulators through AGPRs with copies around every loop)
 void gemm_bf16_mid_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw,
                      void* __restrict__ C, int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n, GemmEpi ep, int per) {
@@ -1518,6 +1520,8 @@ void gemm_bf16_mid_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __
     auto pv = [](int pair) { return pair == 0 ? RING - MID_PAIR : pair - MID_PAIR; };
 #define MID_M0(ADDR) asm volatile("s_mov_b32 m0, %0" :: "s"(ADDR) : "memory")
 #define MID_PIECE(VOFF, RSRC, KB) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds\n\ts_add_u32 m0, m0, 0x400" :: "v"(VOFF), "s"(RSRC), "s"(KB) : "memory", "scc")
+#define MID_PIECE_NT(VOFF, RSRC, KB) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen nt lds\n\ts_add_u32 m0, m0, 0x400" :: "v"(VOFF), "s"(RSRC), "s"(KB) : "memory", "scc")
+#define MID_PIECE_W(VOFF, RSRC, KB) do { if constexpr (NT) MID_PIECE_NT(VOFF, RSRC, KB); else MID_PIECE(VOFF, RSRC, KB); } while (0)
 
     floatx4 acc[4][4];
 #pragma unroll
@@ -1536,7 +1540,7 @@ void gemm_bf16_mid_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __
         MID_M0(lds_base + 2 * gk * MID_PAIR);
         asm volatile("s_nop 0" ::: "memory");
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { const int vo = offW[q]; const auto r = rW; MID_PIECE(vo, r, gk * 128); }   // (locals: asm operands alone do not capture)
+        for (int q = 0; q < 4; ++q) { const int vo = offW[q]; const auto r = rW; MID_PIECE_W(vo, r, gk * 128); }   // (locals: asm operands alone do not capture)
         MID_M0(lds_base + (2 * gk + 1) * MID_PAIR);
         asm volatile("s_nop 0" ::: "memory");
 #pragma unroll
@@ -1571,7 +1575,7 @@ void gemm_bf16_mid_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __
                     else fa1[m - 4] = *(lds_fptr)(pa + (m - 4) * 2048);
                 }
                 if constexpr (m >= 8 && m < 16 && (m & 1) == 0) {
-                    if (more2 && !(ABL & 2)) MID_PIECE(offW[(m - 8) >> 1], rW, kb);
+                    if (more2 && !(ABL & 2)) MID_PIECE_W(offW[(m - 8) >> 1], rW, kb);
                 }
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw0[j], fa0[i], acc[i][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
@@ -1618,6 +1622,8 @@ void gemm_bf16_mid_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __
     for (; t < nt; ++t) ktile(t, std::false_type{});
 #undef MID_M0
 #undef MID_PIECE
+#undef MID_PIECE_NT
+#undef MID_PIECE_W
     if (SPLITK) {                                            // fp32 partial tile -> this split's workspace slice ([split][M_pad][N_pad], pads of 128)
         const int64_t np = (int64_t)tiles_n * 128;
         float* slice = reinterpret_cast<float*>(C) + (int64_t)blockIdx.y * ((int64_t)tiles_m * 128) * np;
@@ -1901,7 +1907,7 @@ void skinny_finalize_k(const float* __restrict__ ws, void* __restrict__ C, int64
     skinny_finalize_item<false>(ws, C, ldc, N, np, splits, ep, slice_rows, m, c);
 }
 
-template <int MB>                   // 16-row blocks of A: 1 (M <= 16) or 2 (M <= 32)
+template <int MB, int NT = 0>       // 16-row blocks of A: 1 (M <= 16) or 2 (M <= 32); NT = 1: the weight stream is loaded non-temporal (knob 11)
 __global__ __launch_bounds__(256)
 void gemm_bf16_skinny_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw, float* __restrict__ ws,
                         int M, int N, int K, int steps_per_split, int64_t np, unsigned* __restrict__ tickets, void* __restrict__ C, int64_t ldc, GemmEpi ep) {
@@ -1932,7 +1938,7 @@ void gemm_bf16_skinny_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t*
         for (int u = 0; u < UN; ++u) {
             const int k = kbase + (s + u) * 32 + fq * 8;
             const bool ok = (int)row_ok & (int)(s + u < ns) & (int)(k < K);
-            dst[u] = __builtin_amdgcn_raw_buffer_load_b128(rsw, ok ? wrow + (uint32_t)(s + u) * 64u : OOB, 0, 0);
+            dst[u] = __builtin_amdgcn_raw_buffer_load_b128(rsw, ok ? wrow + (uint32_t)(s + u) * 64u : OOB, 0, NT ? 2 : 0);     // aux 2 = nt
         }
     };
     loadw(0, wf[0]);
@@ -2078,6 +2084,7 @@ static bool mid_deep(int64_t M, int64_t min_ktiles) {
     (void)M;
     return g_mid_depth == 4 && min_ktiles >= 4;
 }
+static int g_nt_weights = 0;   // knob 11: bit 0 = the 128-tile mid kernel's W pieces non-temporal, bit 1 = the skinny kernel's weight stream (A/B timing; bit-identical results)
 static int g_mid_ablate = 0;    // knob 9 (timing only, WRONG RESULTS): the 128-tile mid kernel without its A pieces (1) / W pieces (2)
 static int g_flow_default = 1;  // auto mode takes the flow kernels where they are eligible (knob 2 of licv_gemm_experiment; 0 = staged epilogues only)
 // A/B timing knobs:
@@ -2088,6 +2095,7 @@ static int g_flow_default = 1;  // auto mode takes the flow kernels where they a
 //   knob 7: 1 = the skinny kernel reduces over its splits in its own launch (default 0: a separate finalize launch)
 //   knob 8: 0 = fp8 GEMMs never take the 4-wave kernel on the 128-deep MFMA
 //   knob 9: timing-only ablation of the mid kernel's operand stream (1 = no A pieces, 2 = no W pieces; results are wrong)
+//   knob 11: bit 0 / bit 1 = non-temporal weight loads in the mid / skinny kernel (default set below)
 //   knob 10: 4 = the mid kernel keeps four K tiles in flight (nine-pair ring) wherever it fits; anything else = the five-pair ring
 extern "C" int licv_gemm_experiment(int knob, int value) {
     if (knob == 0) return g_lab_knob ? g_lab_knob(0, value) : licv_set_error(LICV_E_UNSUPPORTED, "gemm_experiment: knob 0 belongs to liblicv_hip_lab.so, which is not loaded");
@@ -2099,6 +2107,7 @@ extern "C" int licv_gemm_experiment(int knob, int value) {
     else if (knob == 8) g_fp8_flow64 = value;
     else if (knob == 9) g_mid_ablate = value;
     else if (knob == 10) g_mid_depth = value;
+    else if (knob == 11) g_nt_weights = value;
     else return licv_set_error(LICV_E_BADARG, "gemm_experiment: unknown knob %d", knob);
     return LICV_OK;
 }
@@ -2329,6 +2338,12 @@ extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
                 gemm_bf16_mid_k<0, 0, 4><<<dim3(t128m * t128n), dim3(256), MID_LDS_DEEP, (hipStream_t)stream>>>(
                     (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, t128m, t128n, ep, 0);
             } else
+            if (g_nt_weights & 1) {
+                static bool amidnt = false;
+                if (!amidnt) { (void)hipFuncSetAttribute((const void*)gemm_bf16_mid_k<0, 0, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, MID_LDS); amidnt = true; }
+                gemm_bf16_mid_k<0, 0, 2, 1><<<dim3(t128m * t128n), dim3(256), MID_LDS, (hipStream_t)stream>>>(
+                (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, t128m, t128n, ep, 0);
+            } else
             gemm_bf16_mid_k<0><<<dim3(t128m * t128n), dim3(256), MID_LDS, (hipStream_t)stream>>>(
                 (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, (int)M, (int)N, (int)K, t128m, t128n, ep, 0);
         } else
@@ -2455,8 +2470,19 @@ static int splitk_run(const void* A, int64_t lda, const void* W, int64_t ldw, vo
         const size_t lds = (size_t)(M + 1) * (per * 32 * 2 + 16);
         unsigned* tickets = (g_skinny_inlaunch && finalize) ? skinny_tickets_for(sst, (int)grid.x) : nullptr;
         if (slice_elems) { *slice_elems = 32 * np; *row_stride = np; }
+        if (g_nt_weights & 2) {
+            static bool sattr_nt = false;
+            if (!sattr_nt) {
+                (void)hipFuncSetAttribute((const void*)gemm_bf16_skinny_k<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 32 * (SKINNY_KR_MAX * 2 + 16));
+                (void)hipFuncSetAttribute((const void*)gemm_bf16_skinny_k<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 32 * (SKINNY_KR_MAX * 2 + 16));
+                sattr_nt = true;
+            }
+            if (mb == 1) gemm_bf16_skinny_k<1, 1><<<grid, 256, lds, sst>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, (float*)workspace, (int)M, (int)N, (int)K, per, np, tickets, C, ldc, eps);
+            else         gemm_bf16_skinny_k<2, 1><<<grid, 256, lds, sst>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, (float*)workspace, (int)M, (int)N, (int)K, per, np, tickets, C, ldc, eps);
+        } else {
         if (mb == 1) gemm_bf16_skinny_k<1><<<grid, 256, lds, sst>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, (float*)workspace, (int)M, (int)N, (int)K, per, np, tickets, C, ldc, eps);
         else         gemm_bf16_skinny_k<2><<<grid, 256, lds, sst>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, (float*)workspace, (int)M, (int)N, (int)K, per, np, tickets, C, ldc, eps);
+        }
         if (!tickets && finalize) {
             const int n_out = e->swiglu ? (int)(N / 2) : (int)N;
             const int64_t items = (int64_t)M * ((n_out + 3) / 4);
@@ -2490,6 +2516,12 @@ static int splitk_run(const void* A, int64_t lda, const void* W, int64_t ldw, vo
             if (!adeep) { (void)hipFuncSetAttribute((const void*)gemm_bf16_mid_k<1, 0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, MID_LDS_DEEP); adeep = true; }
             gemm_bf16_mid_k<1, 0, 4><<<dim3(tiles_m * tiles_n, splits), dim3(256), MID_LDS_DEEP, st>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw,
                 workspace, 0, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, per);
+        } else
+        if (g_nt_weights & 1) {
+            static bool asplnt = false;
+            if (!asplnt) { (void)hipFuncSetAttribute((const void*)gemm_bf16_mid_k<1, 0, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, MID_LDS); asplnt = true; }
+            gemm_bf16_mid_k<1, 0, 2, 1><<<dim3(tiles_m * tiles_n, splits), dim3(256), MID_LDS, st>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw,
+            workspace, 0, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, per);
         } else
         gemm_bf16_mid_k<1><<<dim3(tiles_m * tiles_n, splits), dim3(256), MID_LDS, st>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw,
             workspace, 0, (int)M, (int)N, (int)K, tiles_m, tiles_n, ep, per);

@@ -394,6 +394,7 @@ class IdeficsEngine:
                 o = ops.attention(qkv, qkv.view(-1)[H:], qkv.view(-1)[2 * H:], B, S, S, nh, nh, hd, S * 3 * H, 3 * H,
                                   S * 3 * H, 3 * H, hd ** -0.5, 1, key_valid=key_valid)
             elif S == 1:                                                 # a decode step: rotary + append + attention in one launch
+                qkv = None
                 qs = ops.linear_produce(x, D.qkv_w)
                 o = ops.decode_attn(qs if qs is not None else ops.linear(x, D.qkv_w), w.cos, w.sin, pos, kv_cache.kv[l], past, nh, nh, hd,
                                     hd ** -0.5, key_valid=key_valid, kv_rows=kv_cache.rows)
