@@ -349,8 +349,8 @@ int licv_decode_attn(const licv_decode_attn_args* a, void* stream);
 
 /* ---- beam search bookkeeping of hooked generate (ref:inference.py:300-321 -> transformers GenerationMixin._beam_search, 5.x form,
  * generation/utils.py:3077-3460; ref:config/inference.yaml:26-30: 3 beams, 5 new tokens, length_penalty 0) ----
- * ONE launch per decode step: log_softmax of every beam's logits, top 2*nb of (nb x V) per question, running / finished set update,
- * early-stop heuristic, and the loop condition.  State buffers are ping-ponged by the caller (in != out for the token rows). */
+ * ONE call (two launches: a scan over vocabulary chunks, a finish per question) per decode step: log_softmax of every beam's logits,
+ * top 2*nb of (nb x V) per question, running / finished set update, early-stop heuristic, and the loop condition.  State buffers are ping-ponged by the caller (in != out for the token rows). */
 typedef struct {
     const void* logits; int logits_dtype;              /* rows of V logits, bf16 or fp32, row stride ld (elements) */
     int64_t ld;
@@ -373,7 +373,9 @@ typedef struct {
     /* optional: the KV-cache row table of licv_decode_attn, (B*nb, kv_ld) int32.  Row r of the new table = row (source beam of r) of
      * the old one, then entry [cur] = r: the token a beam appends next lands in its OWN physical cache row.  NULL = not maintained. */
     const int32_t* kv_rows_in; int32_t* kv_rows_out; int64_t kv_ld;
+    void* scratch; int64_t scratch_bytes;              /* >= licv_beam_step_scratch_bytes(B, nb), 16-byte aligned: the scan's per-chunk partials */
 } licv_beam_step_args;
+int64_t licv_beam_step_scratch_bytes(int64_t B, int64_t nb);
 int licv_beam_step(const licv_beam_step_args* a, void* stream);
 
 /* ---- device-side front-end: integer rules between the collator / processor and the first GEMM ---- */

@@ -27,11 +27,20 @@ struct DecodeP {
     float scale;
 };
 
+// One element of the fused QKV row: the bf16 value, or bf16(slice 0 + slice 1 + ... in slice order), as skinny_finalize_k adds them.
+// Every slice is requested before the first is used (clamped indices, selects instead of branches): a loop of load -> add would put
+// one memory round trip per slice on the wave's critical path.
 __device__ __forceinline__ float dec_in(const DecodeP& a, int64_t row, int64_t col) {
     if (!a.ws) return bf2f(a.qkv16[row * a.ldq + col]);
     const float* p = a.ws + row * a.stride + col;
-    float v = p[0];
-    for (int sp = 1; sp < a.splits; ++sp) v += p[(int64_t)sp * a.slice];     // slice order, as skinny_finalize_k adds them
+    float v = 0.f;
+    for (int s0 = 0; s0 < a.splits; s0 += 8) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = p[(int64_t)min(s0 + u, a.splits - 1) * a.slice];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v += (s0 + u < a.splits) ? t[u] : 0.f;
+    }
     return rbf(v);
 }
 
@@ -123,21 +132,29 @@ void decode_attn_k(DecodeP a) {
         }
         lsum = wave_sum(lsum);
         __syncthreads();
-        // ---- O = P V: two head-dim columns per lane, keys in order
+        // ---- O = P V: two head-dim columns per lane, keys in order, eight keys' loads in flight at a time (no branch around a load: the
+        // row-table entries, then the V elements, are requested for the whole group before the first product)
         float o0 = 0.f, o1 = 0.f;
         if (act) {
-            for (int j = 0; j < a.Sk; ++j) {
-                const float pj = dsm[j];
-                if (pj == 0.f) continue;
-                float a0, a1;
-                if (j == a.past) { a0 = v0; a1 = v1; }
-                else {
-                    const int64_t prow = rows_r ? rows_r[j] : r;
-                    const bf16_t* vp = a.cache + (prow * a.max_len + j) * 2 * kd + kd + (int64_t)g * hd;
-                    a0 = bf2f(vp[lane]); a1 = bf2f(vp[lane + half]);
+            for (int j0 = 0; j0 < a.Sk; j0 += 8) {
+                int64_t prow[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int j = min(j0 + u, a.Sk - 1); prow[u] = rows_r ? rows_r[j] : r; }
+                float a0[8], a1[8], pj[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int j = min(j0 + u, a.Sk - 1);
+                    const bf16_t* vp = a.cache + (prow[u] * a.max_len + j) * 2 * kd + kd + (int64_t)g * hd;
+                    a0[u] = bf2f(vp[lane]); a1[u] = bf2f(vp[lane + half]);
+                    pj[u] = (j0 + u < a.Sk) ? dsm[j] : 0.f;
                 }
-                o0 = __builtin_fmaf(pj, a0, o0);
-                o1 = __builtin_fmaf(pj, a1, o1);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const bool own = (j0 + u == a.past);            // the new token's V comes from registers, not from the store just issued
+                    const bool live = pj[u] != 0.f;                   // (a masked key contributes nothing, whatever its cache row holds)
+                    o0 = __builtin_fmaf(pj[u], live ? (own ? v0 : a0[u]) : 0.f, o0);
+                    o1 = __builtin_fmaf(pj[u], live ? (own ? v1 : a1[u]) : 0.f, o1);
+                }
             }
             const float inv = lsum > 0.f ? 1.0f / lsum : 0.f;
             bf16_t* op = a.out + (int64_t)r * qd + (int64_t)head * hd;

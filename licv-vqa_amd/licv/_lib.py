@@ -54,7 +54,8 @@ class BeamStepArgs(C.Structure):
                 ("running_out", C.c_void_p), ("finished_out", C.c_void_p), ("run_scores_out", C.c_void_p), ("fin_scores_out", C.c_void_p),
                 ("is_fin_out", C.c_void_p), ("improve_out", C.c_void_p), ("gen_len_out", C.c_void_p),
                 ("beam_src_flat", C.c_void_p), ("next_tokens", C.c_void_p), ("flags", C.c_void_p), ("sync", C.c_void_p),
-                ("kv_rows_in", C.c_void_p), ("kv_rows_out", C.c_void_p), ("kv_ld", C.c_int64)]
+                ("kv_rows_in", C.c_void_p), ("kv_rows_out", C.c_void_p), ("kv_ld", C.c_int64),
+                ("scratch", C.c_void_p), ("scratch_bytes", C.c_int64)]
 
 
 class DecodeAttnArgs(C.Structure):
@@ -87,6 +88,8 @@ def lib() -> C.CDLL:
         _lib.licv_workspace_size.restype = C.c_int64
         _lib.licv_workspace_size.argtypes = [C.c_int64, C.c_int64, C.c_int64]
         _lib.licv_inject_bwd_partials.argtypes = [C.c_int64]
+        _lib.licv_beam_step_scratch_bytes.restype = C.c_int64
+        _lib.licv_beam_step_scratch_bytes.argtypes = [C.c_int64, C.c_int64]
         P, I64, F, I = C.c_void_p, C.c_int64, C.c_float, C.c_int
         sig = {
             "licv_inject_renorm_fwd": [P, I, P, P, P, I64, I64, P, P, F, P],

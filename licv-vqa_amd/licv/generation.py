@@ -206,6 +206,8 @@ class BeamSearchState:
         self.next_tokens = torch.empty((B * nb,), dtype=torch.long, device=dev)
         self.flags = torch.zeros((1,), dtype=torch.int32, device=dev)
         self.sync = torch.zeros((4,), dtype=torch.int32, device=dev)
+        from . import _lib
+        self.scratch = torch.empty((int(_lib.lib().licv_beam_step_scratch_bytes(B, nb)),), dtype=torch.uint8, device=dev)
         # optional: the KV cache's row table (B*nb, cache max_len) int32, ping-ponged like the rest of the state
         self.kv_rows = kv_rows
         self._kv_rows_next = torch.empty_like(kv_rows) if kv_rows is not None else None
@@ -230,6 +232,7 @@ class BeamSearchState:
             setattr(a, k + "_out", dst[k].data_ptr())
         a.beam_src_flat, a.next_tokens = self.beam_src_flat.data_ptr(), self.next_tokens.data_ptr()
         a.flags, a.sync = self.flags.data_ptr(), self.sync.data_ptr()
+        a.scratch, a.scratch_bytes = self.scratch.data_ptr(), self.scratch.numel()
         if self.kv_rows is not None:
             assert self.kv_rows.dtype == torch.int32 and self.kv_rows.is_contiguous() and self.kv_rows.shape[0] == self.B * self.nb
             a.kv_rows_in, a.kv_rows_out, a.kv_ld = self.kv_rows.data_ptr(), self._kv_rows_next.data_ptr(), self.kv_rows.shape[1]

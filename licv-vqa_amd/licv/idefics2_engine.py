@@ -350,6 +350,9 @@ class Idefics2Engine:
         a, w = self.arch, self.w
         dev = w.device
         B, S = input_ids.shape
+        # `capture` records per-layer tensors and, by default, takes the unfused kernels (every intermediate exists as a tensor);
+        # with self.capture_keeps_path the product's fused path runs and only the layer outputs are recorded (diagnostics)
+        cap = None if getattr(self, "capture_keeps_path", False) else capture
         past = kv_cache.len if kv_cache is not None else 0
         Sk = past + S
         assert Sk <= w.max_positions, "sequence longer than the rotary table"
@@ -388,7 +391,7 @@ class Idefics2Engine:
         for l, L in enumerate(w.text):
             if xn is not None:
                 x = xn
-            elif self._q8_in(L, "qkv_w", M) and capture is None:
+            elif self._q8_in(L, "qkv_w", M) and cap is None:
                 x = ops.rmsnorm_q8(h, L.in_ln, a.rms_eps, 1)
             else:
                 x = ops.rmsnorm(h, L.in_ln, a.rms_eps, 1)
@@ -411,7 +414,7 @@ class Idefics2Engine:
                 cache[:, past:Sk] = qkv.view(B, S, ldq)[:, :, qd:]                         # append K|V (device copy)
                 o = ops.attention(qkv, cache, cache.view(-1)[kd:], B, S, Sk, nh, nkv, hd, S * ldq, ldq, kv_cache.max_len * 2 * kd, 2 * kd,
                                   hd ** -0.5, 1, key_valid=key_valid)
-            if M >= 512 and capture is None and self.fold_residual:   # the residual add folded into the norm that follows (as in IdeficsEngine): bit-identical
+            if M >= 512 and cap is None and self.fold_residual:   # the residual add folded into the norm that follows (as in IdeficsEngine): bit-identical
                 if self._q8_in(L, "gu_w", M):
                     x = ops.add_rmsnorm_q8_(h, self._tlin(o.view(M, qd), L, "o_w"), L.post_ln, a.rms_eps, 1)
                 else:
@@ -424,11 +427,11 @@ class Idefics2Engine:
             if l in idx_of:
                 i = idx_of[l]
                 m = self._tlin(act, L, "down_w")                                           # raw MLP branch (bf16)
-                if capture is not None:
+                if cap is not None:
                     capture.setdefault("mlp_raw", []).append(m.view(B, S, H).clone())
                 al = alpha[0, i:i + 1] if alpha is not None else None
                 nw = w.text[l + 1].in_ln if l + 1 < a.num_layers else w.final_ln
-                if self.fuse_hook_norm and capture is None and l + 1 < a.num_layers and self._q8_in(w.text[l + 1], "qkv_w", M):
+                if self.fuse_hook_norm and cap is None and l + 1 < a.num_layers and self._q8_in(w.text[l + 1], "qkv_w", M):
                     h, xq_, xs_ = ops.inject_renorm_add_q8(m, icv[0, i], h, al, nw, norm_eps=a.rms_eps, norm_flavour=1)
                     xn = (xq_, xs_)
                 elif self.fuse_hook_norm:
@@ -437,7 +440,7 @@ class Idefics2Engine:
                     h = ops.inject_renorm_add(m, icv[0, i], h, alpha=al)
                 del m
             else:
-                if capture is not None:
+                if cap is not None:
                     capture.setdefault("mlp_raw", []).append(ops.linear(act, L.down_w).view(B, S, H).clone())
                 self._tlin(act, L, "down_w", residual=h, out=h)
             del act
