@@ -148,6 +148,7 @@ void beam_finish_k(licv_beam_step_args a, const float* __restrict__ stats, const
             if (s_wp[w] >= 0 && (gp < 0 || cand_better(s_wv[w], s_wi[w], gv, gi))) { gv = s_wv[w]; gi = s_wi[w]; gp = s_wp[w]; }
         __syncthreads();
         if (tid == 0) { top_lp[r] = gp >= 0 ? gv : -INFINITY; top_ix[r] = gp >= 0 ? gi : 0; if (gp >= 0) lpi[gp] = -1; }       // taken
+        __syncthreads();                                   // ... before the next round scans the list
     }
     __syncthreads();
     // ---- (4) bookkeeping of this question (hf:generation/utils.py _beam_search: running beams, finished set, early-stop heuristic)

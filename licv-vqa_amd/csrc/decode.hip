@@ -46,7 +46,7 @@ __device__ __forceinline__ float dec_in(const DecodeP& a, int64_t row, int64_t c
 
 __global__ __launch_bounds__(64)
 void decode_attn_k(DecodeP a) {
-    extern __shared__ float dsm[];                     // [Sk] scores, then probabilities
+    extern __shared__ float dsm[];                     // [Sk] scores, then probabilities; [Sk] ints: physical cache row of every key, -1 = masked
     __shared__ __attribute__((aligned(16))) bf16_t qs[128];
     const int lane = threadIdx.x;
     const int r = blockIdx.x / a.nkv, g = blockIdx.x % a.nkv;
@@ -56,6 +56,17 @@ void decode_attn_k(DecodeP a) {
     int64_t p = a.pos[r];
     p = p < 0 ? 0 : (p >= a.n_pos ? a.n_pos - 1 : p);
     const float c = act ? bf2f(a.cosT[p * hd + lane]) : 0.f, s = act ? bf2f(a.sinT[p * hd + lane]) : 0.f;
+    const float sc = a.scale * 1.4426950408889634f;
+    const int32_t* rows_r = a.kv_rows ? a.kv_rows + (int64_t)r * a.ld_rows : nullptr;
+    const int32_t* valid_r = a.key_valid ? a.key_valid + (int64_t)r * a.Sk : nullptr;
+    // the row table and the mask of this row go to LDS first (requested before the slices above are summed): the K and V loads below
+    // then depend on no other global load
+    int* srow = reinterpret_cast<int*>(dsm + a.Sk);
+    for (int j = lane; j < a.Sk; j += 64) {
+        const int pr = rows_r ? rows_r[j] : r;
+        const bool ok = !valid_r || valid_r[j] != 0;
+        srow[j] = ok ? pr : -1;
+    }
     // ---- the new token's K (rotated) and V of this kv head: into the cache row of THIS beam row at position `past`, and kept in registers
     float k0 = 0.f, k1 = 0.f, v0 = 0.f, v1 = 0.f;
     bf16_t* crow = a.cache + ((int64_t)r * a.max_len + a.past) * 2 * kd + (int64_t)g * hd;
@@ -68,9 +79,6 @@ void decode_attn_k(DecodeP a) {
         crow[lane] = f2bf(k0); crow[lane + half] = f2bf(k1);
         crow[kd + lane] = f2bf(v0); crow[kd + lane + half] = f2bf(v1);
     }
-    const float sc = a.scale * 1.4426950408889634f;
-    const int32_t* rows_r = a.kv_rows ? a.kv_rows + (int64_t)r * a.ld_rows : nullptr;
-    const int32_t* valid_r = a.key_valid ? a.key_valid + (int64_t)r * a.Sk : nullptr;
     const int nch = hd >> 3;                            // 16-byte chunks per K row
     for (int qh = 0; qh < rep; ++qh) {
         const int head = g * rep + qh;
@@ -93,10 +101,11 @@ void decode_attn_k(DecodeP a) {
             const int j = j0 + lane;
             float sj = -INFINITY;
             if (j < a.Sk) {
-                const bool ok = !valid_r || valid_r[j] != 0;
+                const int pr = srow[j];
+                const bool ok = pr >= 0;
                 if (j == a.past) sj = s_new;
                 else {
-                    const int64_t prow = rows_r ? rows_r[j] : r;
+                    const int64_t prow = ok ? pr : r;
                     const u32x4_d* kp = reinterpret_cast<const u32x4_d*>(a.cache + (prow * a.max_len + j) * 2 * kd + (int64_t)g * hd);
                     float acc = 0.f;
 #pragma unroll
@@ -136,20 +145,18 @@ void decode_attn_k(DecodeP a) {
         // row-table entries, then the V elements, are requested for the whole group before the first product)
         float o0 = 0.f, o1 = 0.f;
         if (act) {
-            for (int j0 = 0; j0 < a.Sk; j0 += 8) {
-                int64_t prow[8];
+            for (int j0 = 0; j0 < a.Sk; j0 += 16) {
+                float a0[16], a1[16], pj[16];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { const int j = min(j0 + u, a.Sk - 1); prow[u] = rows_r ? rows_r[j] : r; }
-                float a0[8], a1[8], pj[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < 16; ++u) {
                     const int j = min(j0 + u, a.Sk - 1);
-                    const bf16_t* vp = a.cache + (prow[u] * a.max_len + j) * 2 * kd + kd + (int64_t)g * hd;
+                    const int pr = srow[j];
+                    const bf16_t* vp = a.cache + ((int64_t)(pr >= 0 ? pr : r) * a.max_len + j) * 2 * kd + kd + (int64_t)g * hd;
                     a0[u] = bf2f(vp[lane]); a1[u] = bf2f(vp[lane + half]);
                     pj[u] = (j0 + u < a.Sk) ? dsm[j] : 0.f;
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < 16; ++u) {
                     const bool own = (j0 + u == a.past);            // the new token's V comes from registers, not from the store just issued
                     const bool live = pj[u] != 0.f;                   // (a masked key contributes nothing, whatever its cache row holds)
                     o0 = __builtin_fmaf(pj[u], live ? (own ? v0 : a0[u]) : 0.f, o0);
@@ -181,7 +188,7 @@ extern "C" int licv_decode_attn(const licv_decode_attn_args* x, void* stream) {
     p.out = (bf16_t*)x->out;
     p.M = (int)x->M; p.Sk = (int)x->past + 1; p.past = (int)x->past; p.nh = (int)x->n_heads; p.nkv = (int)x->n_kv_heads; p.hd = (int)x->head_dim;
     p.scale = x->scale;
-    const size_t lds = (size_t)p.Sk * sizeof(float);
+    const size_t lds = (size_t)p.Sk * (sizeof(float) + sizeof(int));
     LICV_CHECK_ARG(lds <= 60 * 1024, "decode_attn: history of %d keys exceeds the kernel's LDS budget", p.Sk);
     decode_attn_k<<<dim3((unsigned)(x->M * x->n_kv_heads)), dim3(64), lds, (hipStream_t)stream>>>(p);
     LICV_LAUNCH_CHECK();
