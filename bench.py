@@ -352,6 +352,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="idefics9b_32shot_bs8", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prefetch-mib", type=int, default=-1, help="decode steps: MiB of the next projection's weights a side stream reads ahead (licv_runner_option 2); -1 = the library's default")
     ap.add_argument("--no-gpu-baseline", action="store_true", help="skip the unfused PyTorch-ROCm run of the oracle on the GPU (row G0)")
     ap.add_argument("--no-hooks", action="store_true", help="teacher shape: same forward with the intervention off")
     ap.add_argument("--no-profiler", action="store_true", help="no per-launch event pairs: the language stack then runs through the native layer runner")
@@ -398,6 +399,9 @@ def main():
         dist_info = {"dist_backend": None, "world_size_seen": 1, "devices": [dev_name]}
 
     from licv import ops
+    if args.prefetch_mib >= 0:
+        from licv import _lib as _l
+        _l.check(_l.lib().licv_runner_option(2, args.prefetch_mib))
     if args.gemm_select:
         from licv import _lib
         _lib.lib().licv_gemm_select(args.gemm_select)

@@ -8,10 +8,59 @@
 //
 // The caller owns every buffer (weights, inputs, scratch, KV caches, output); nothing is allocated or synchronised here.
 #include "common.h"
+#include <vector>
 
 #define RUN(call) do { int rc__ = (call); if (rc__ != LICV_OK) return rc__; } while (0)
 
 namespace {
+// ------------------------------------------------------------------------------------------------
+// Weight prefetch beside the decode chain (licv_runner_option 2).  A decode step streams 16 GB of weights through ~160 projections of
+// 20 - 50 us; each pays ~10 us of fill, staging and tail during which HBM idles (~40 % of the step).  The weights are constants, so
+// a SIDE stream may read the NEXT projection's matrix (default cache policy: it lands in the 256 MB Infinity Cache) while the
+// current one runs; the projection then finds its operand on-die.  Throttle: the prefetch of projection k + 1 is queued behind the
+// END of projection k - 1, and capped in bytes, so at most ~two matrices are in flight through the cache.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_pf;
+__global__ __launch_bounds__(256)
+void weight_prefetch_k(const u32x4_pf* __restrict__ p, int64_t n16, unsigned* sink) {
+    u32x4_pf acc = {0u, 0u, 0u, 0u};
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride * 8) {
+        u32x4_pf v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int64_t j = i + u * stride; v[u] = p[j < n16 ? j : i]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc ^= v[u];
+    }
+    if (sink && (acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x9e3779b9u) *sink = 1u;      // keeps the loads alive; sink is NULL at run time
+}
+struct Prefetch {
+    int64_t cap_bytes = 0;                                // 0 = off
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> ev;
+    std::vector<std::pair<const void*, int64_t>> plan;    // the call's projections in launch order: (weights, bytes)
+    int k = 0;
+    bool active = false;
+};
+Prefetch g_pf;
+void pf_before(hipStream_t main) {
+    Prefetch& f = g_pf;
+    if (!f.active) return;
+    const int k = f.k;
+    if (k + 1 < (int)f.plan.size()) {
+        if (k >= 1) (void)hipStreamWaitEvent(f.side, f.ev[k - 1], 0);
+        const int64_t bytes = f.plan[k + 1].second < f.cap_bytes ? f.plan[k + 1].second : f.cap_bytes;
+        weight_prefetch_k<<<64, 256, 0, f.side>>>((const u32x4_pf*)f.plan[k + 1].first, bytes / 16, nullptr);
+    }
+    (void)main;
+}
+void pf_after(hipStream_t main) {
+    Prefetch& f = g_pf;
+    if (!f.active) return;
+    if (f.k < (int)f.ev.size()) (void)hipEventRecord(f.ev[f.k], main);
+    ++f.k;
+}
+
 struct Ctx {
     const licv_idefics_text_weights* w;
     const licv_idefics_text_call* c;
@@ -28,12 +77,15 @@ int linear(const Ctx& x, const void* A, int64_t M, const void* W, int64_t N, int
     ep.out_dtype = out_dt;
     int splits = 1; int64_t ws = 0;
     RUN(licv_gemm_splitk_plan(M, N, K, &splits, &ws));    // the same decision licv.ops.linear takes
+    pf_before((hipStream_t)x.stream);
+    int rc;
     if (splits > 1) {
         if (ws > x.c->workspace_bytes) return licv_set_error(LICV_E_BADARG, "idefics_text_forward: workspace %lld B < %lld B needed by a %lld x %lld x %lld split-K GEMM",
                                                              (long long)x.c->workspace_bytes, (long long)ws, (long long)M, (long long)N, (long long)K);
-        return licv_gemm_bf16_splitk(A, K, W, K, C, ldc, M, N, K, &ep, splits, x.c->workspace, x.c->workspace_bytes, x.stream);
-    }
-    return licv_gemm_bf16(A, K, W, K, C, ldc, M, N, K, &ep, x.stream);
+        rc = licv_gemm_bf16_splitk(A, K, W, K, C, ldc, M, N, K, &ep, splits, x.c->workspace, x.c->workspace_bytes, x.stream);
+    } else rc = licv_gemm_bf16(A, K, W, K, C, ldc, M, N, K, &ep, x.stream);
+    pf_after((hipStream_t)x.stream);
+    return rc;
 }
 
 // A projection whose bf16 output (a branch, or the fused Q|K|V rows) is consumed by a row kernel.  Where the plan splits K and the
@@ -48,7 +100,9 @@ int linear_to_rows(const Ctx& x, const void* A, int64_t M, const void* W, int64_
     if (splits > 1 && g_sum_in_rows) {
         if (ws > x.c->workspace_bytes) return licv_set_error(LICV_E_BADARG, "idefics_text_forward: workspace %lld B < %lld B needed by a %lld x %lld x %lld split-K GEMM",
                                                              (long long)x.c->workspace_bytes, (long long)ws, (long long)M, (long long)N, (long long)K);
+        pf_before((hipStream_t)x.stream);
         RUN(licv_gemm_bf16_splitk_produce(A, K, W, K, M, N, K, splits, x.c->workspace, x.c->workspace_bytes, &src->slice, &src->stride, x.stream));
+        pf_after((hipStream_t)x.stream);
         src->ws = (const float*)x.c->workspace; src->splits = splits;
         return LICV_OK;
     }
@@ -59,9 +113,11 @@ int linear_to_rows(const Ctx& x, const void* A, int64_t M, const void* W, int64_
 static int g_fold_residual = 1;
 // option 0: fold the decoder layers' residual adds into the row kernels that follow them (default 1; 0 for A/B timing)
 // option 1: at M < 512, split-K projections leave their slices for the row kernel behind them to sum (default 1; 0 for A/B timing)
+// option 2: decode steps (M <= 32): MiB of the NEXT projection's weights a side stream reads ahead into the Infinity Cache (0 = off)
 extern "C" int licv_runner_option(int option, int value) {
     if (option == 0) { g_fold_residual = value; return LICV_OK; }
     if (option == 1) { g_sum_in_rows = value; return LICV_OK; }
+    if (option == 2) { g_pf.cap_bytes = (int64_t)(value < 0 ? 0 : value) << 20; return LICV_OK; }      // MiB of each next projection's weights to prefetch; 0 = off
     return licv_set_error(LICV_E_BADARG, "runner_option: unknown option %d", option);
 }
 
@@ -79,6 +135,31 @@ extern "C" int licv_idefics_text_forward(const licv_idefics_text_weights* w, con
     const float att_scale = 1.0f / sqrtf((float)hd);
     hipStream_t st = (hipStream_t)stream;
     Ctx x{w, c, stream, M, H, c->h16, LICV_BF16};
+    // the weight-prefetch plan of this call (decode steps only): the projections in the order the loop below launches them
+    g_pf.active = false;
+    if (g_pf.cap_bytes > 0 && M <= 32) {
+        Prefetch& f = g_pf;
+        f.plan.clear(); f.k = 0;
+        for (int64_t l = 0; l < w->n_layers; ++l) {
+            if (l % w->cross_interval == 0) {
+                const licv_idefics_xattn_w& X = w->xat[l / w->cross_interval];
+                f.plan.emplace_back(X.q_w, H * H * 2);
+                if (!(c->xkv_cached && c->xkv_cached[l / w->cross_interval])) f.plan.emplace_back(X.kv_w, 2 * H * E * 2);
+                f.plan.emplace_back(X.o_w, H * H * 2); f.plan.emplace_back(X.gu_w, 2 * I * H * 2); f.plan.emplace_back(X.down_w, H * I * 2);
+            }
+            const licv_idefics_dec_w& D = w->dec[l];
+            f.plan.emplace_back(D.qkv_w, 3 * H * H * 2); f.plan.emplace_back(D.o_w, H * H * 2);
+            f.plan.emplace_back(D.gu_w, 2 * I * H * 2); f.plan.emplace_back(D.down_w, H * I * 2);
+        }
+        f.plan.emplace_back(w->lm_head, w->vocab_total * H * 2);
+        if (!f.side && hipStreamCreateWithFlags(&f.side, hipStreamNonBlocking) != hipSuccess) f.side = nullptr;
+        while (f.side && f.ev.size() < f.plan.size()) {
+            hipEvent_t e;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) break;
+            f.ev.push_back(e);
+        }
+        f.active = f.side && f.ev.size() >= f.plan.size();
+    }
 
     RUN(licv_embed_gather(c->input_ids, w->embed, w->embed_extra, c->h16, M, H, w->vocab, w->n_extra_vocab, stream));
     bool xn_valid = false;                                 // c->xn holds RMSNorm(h) for the next block (made by the fused hook kernel)
@@ -211,5 +292,7 @@ extern "C" int licv_idefics_text_forward(const licv_idefics_text_weights* w, con
         RUN(licv_embed_gather(c->logits_rows, xf, nullptr, c->xsel, c->n_rows, H, M, 0, stream));
         xf = c->xsel; rows = c->n_rows;
     }
-    return linear(x, xf, rows, w->lm_head, w->vocab_total, H, c->logits, c->ld_logits, LICV_BF16);
+    const int rc_head = linear(x, xf, rows, w->lm_head, w->vocab_total, H, c->logits, c->ld_logits, LICV_BF16);
+    g_pf.active = false;
+    return rc_head;
 }

@@ -226,12 +226,23 @@ def test_fullsize_idefics2_fp8_32shot_properties(fp8_vision, B):
         img = e8.encode_images(batch["pixel_values"], batch["pixel_attention_mask"])                    # the vision side is bf16 in both
         ins8 = ins16 = dict(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], image_hidden_states=img)
     cap = {}
-    lg8 = e8.forward(**ins8, icv=scaled, hook_layers=layers, capture=cap).clone()
-    assert torch.isfinite(lg8.float()).all()                                                              # F2
+    lg_cap = e8.forward(**ins8, icv=scaled, hook_layers=layers, capture=cap).clone()
+    assert torch.isfinite(lg_cap.float()).all()                                                           # F2
     assert all(t.dtype == torch.float32 for t in cap["layer_out"]) and cap["mlp_raw"][0].dtype == torch.bfloat16
     del cap
     torch.cuda.empty_cache()
+    lg8 = e8.forward(**ins8, icv=scaled, hook_layers=layers).clone()                                     # the product path (fused row kernels)
     assert torch.equal(lg8, e8.forward(**ins8, icv=scaled, hook_layers=layers))                          # F1
+    # The capture run takes the UNFUSED kernels (every intermediate exists as a tensor).  At toy and mid sizes the two paths are bit
+    # for bit the same; over the 3.6e9 branch elements of this configuration ONE differed by one bf16 ulp (tools/diag_fp8_b8_paths.py:
+    # layer 19, question 4, position 292, column 2868) and e4m3 rounding then spreads it over that question.  Both paths are
+    # deterministic and batch-independent (tools/diag_fp8_b8.py); questions are compared one by one and the rest must be identical.
+    same_q = [bool(torch.equal(lg8[q], lg_cap[q])) for q in range(B)]
+    v0 = batch["attention_mask"].bool()
+    rel_paths = float((lg8.float() - lg_cap.float())[v0].norm() / lg_cap.float()[v0].norm())
+    print(f"\n  F1 fused vs unfused kernel path: {sum(same_q)}/{B} questions bit-identical, relative L2 over the batch {rel_paths:.2e}")
+    assert sum(same_q) >= B - 1 and rel_paths <= 2e-2
+    del lg_cap
     lg16 = e16.forward(**ins16, icv=scaled, hook_layers=layers)
     valid = batch["attention_mask"].bool()
     a, b = lg16.float()[valid], lg8.float()[valid]
