@@ -7,13 +7,17 @@
 // holds position p of beam row r's history (licv_beam_step maintains it: a beam inherits its source beam's row indices and writes
 // its own new token into its own row), so a reorder is an index update of B * beams * max_len ints.
 //
-// One 64-lane wave per (row, kv head); it serves the n_heads / n_kv_heads query heads of that group one after the other.  Scores:
-// one key per lane (a 128-dim dot from 16-byte loads, q in registers); softmax in the log2 domain with P rounded to bf16 before the
-// PV product, the sum taken over the unrounded P - the arithmetic of csrc/attention.hip's tile function; PV: two head-dim columns
-// per lane, keys in order.  The new token's own K / V never make a round trip through memory.
+// One 64-lane wave per (row, kv head); it serves the n_heads / n_kv_heads query heads of that group one after the other.  Sweeps of
+// 64 keys, one key per lane: the lane requests its key's K row and V row together (16-byte loads; nothing waits for the softmax),
+// takes the 128-dim dot with q from registers, and the sweep's softmax runs in the log2 domain with P rounded to bf16 before the PV
+// product and the sum taken over the unrounded P - the arithmetic of csrc/attention.hip's tile function, online across sweeps; the V
+// rows and probabilities then pass through LDS and every lane accumulates two head-dim columns over the keys in order.  Dependent
+// memory round trips per call: (row table, positions, QKV slices) -> (cos / sin) -> (K and V rows).  The new token's own K / V
+// never make a round trip through memory.
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_d;
+#define DEC_VSTR 272                  // LDS stride of a V row (256 B + 16: conflict-free 16-byte row writes, 2-byte column reads)
 
 struct DecodeP {
     const float* ws; int splits; int64_t slice, stride;       // split-K slices of the QKV projection (ws == nullptr: qkv16)
@@ -46,7 +50,7 @@ __device__ __forceinline__ float dec_in(const DecodeP& a, int64_t row, int64_t c
 
 __global__ __launch_bounds__(64)
 void decode_attn_k(DecodeP a) {
-    extern __shared__ float dsm[];                     // [Sk] scores, then probabilities; [Sk] ints: physical cache row of every key, -1 = masked
+    extern __shared__ int srow_s[];                     // [Sk] ints: physical cache row of every key, -1 = masked
     __shared__ __attribute__((aligned(16))) bf16_t qs[128];
     const int lane = threadIdx.x;
     const int r = blockIdx.x / a.nkv, g = blockIdx.x % a.nkv;
@@ -61,7 +65,7 @@ void decode_attn_k(DecodeP a) {
     const int32_t* valid_r = a.key_valid ? a.key_valid + (int64_t)r * a.Sk : nullptr;
     // the row table and the mask of this row go to LDS first (requested before the slices above are summed): the K and V loads below
     // then depend on no other global load
-    int* srow = reinterpret_cast<int*>(dsm + a.Sk);
+    int* srow = srow_s;
     for (int j = lane; j < a.Sk; j += 64) {
         const int pr = rows_r ? rows_r[j] : r;
         const bool ok = !valid_r || valid_r[j] != 0;
@@ -79,7 +83,9 @@ void decode_attn_k(DecodeP a) {
         crow[lane] = f2bf(k0); crow[lane + half] = f2bf(k1);
         crow[kd + lane] = f2bf(v0); crow[kd + lane + half] = f2bf(v1);
     }
-    const int nch = hd >> 3;                            // 16-byte chunks per K row
+    const int nch = hd >> 3;                            // 16-byte chunks per K / V row
+    __shared__ __attribute__((aligned(16))) char vt[64 * DEC_VSTR];     // the chunk's V rows (bf16), one per key
+    __shared__ float pch[64];                                            // ... and their probabilities
     for (int qh = 0; qh < rep; ++qh) {
         const int head = g * rep + qh;
         // ---- Q of this head, rotated; its score against the new key from registers
@@ -95,79 +101,64 @@ void decode_attn_k(DecodeP a) {
         u32x4_d qreg[16];
 #pragma unroll
         for (int ch = 0; ch < 16; ++ch) qreg[ch] = ch < nch ? reinterpret_cast<const u32x4_d*>(qs)[ch] : u32x4_d{0u, 0u, 0u, 0u};
-        // ---- scores: one key per lane
-        float mx = -INFINITY;
+        // ---- 64 keys per sweep, ONE key per lane: its K row and its V row are requested together (the V loads do not wait for the
+        // softmax), scores -> online softmax across sweeps (the arithmetic of csrc/attention.hip's tiles) -> the V rows and the bf16
+        // probabilities go through LDS and every lane then accumulates two head-dim columns over the sweep's keys in order
+        float m_run = -INFINITY, l_run = 0.f, o0 = 0.f, o1 = 0.f;
         for (int j0 = 0; j0 < a.Sk; j0 += 64) {
             const int j = j0 + lane;
-            float sj = -INFINITY;
-            if (j < a.Sk) {
-                const int pr = srow[j];
-                const bool ok = pr >= 0;
-                if (j == a.past) sj = s_new;
-                else {
-                    const int64_t prow = ok ? pr : r;
-                    const u32x4_d* kp = reinterpret_cast<const u32x4_d*>(a.cache + (prow * a.max_len + j) * 2 * kd + (int64_t)g * hd);
-                    float acc = 0.f;
+            const bool in = j < a.Sk;
+            const int pr = in ? srow[j] : -1;
+            const bool ok = pr >= 0, own = in && j == a.past;
+            const bf16_t* rowp = a.cache + ((int64_t)(ok ? pr : r) * a.max_len + (in ? j : 0)) * 2 * kd + (int64_t)g * hd;
+            const u32x4_d* kp = reinterpret_cast<const u32x4_d*>(rowp);
+            const u32x4_d* vp = reinterpret_cast<const u32x4_d*>(rowp + kd);
+            u32x4_d kv[16], vv[16];
 #pragma unroll
-                    for (int ch = 0; ch < 16; ++ch) {
-                        if (ch < nch) {
-                            const u32x4_d kv = kp[ch];
+            for (int ch = 0; ch < 16; ++ch) kv[ch] = ch < nch ? kp[ch] : u32x4_d{0u, 0u, 0u, 0u};
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                acc = __builtin_fmaf(__uint_as_float(kv[e] << 16), __uint_as_float(qreg[ch][e] << 16), acc);
-                                acc = __builtin_fmaf(__uint_as_float(kv[e] & 0xffff0000u), __uint_as_float(qreg[ch][e] & 0xffff0000u), acc);
-                            }
-                        }
-                    }
-                    sj = acc;
+            for (int ch = 0; ch < 16; ++ch) vv[ch] = ch < nch ? vp[ch] : u32x4_d{0u, 0u, 0u, 0u};
+            float acc = 0.f;
+#pragma unroll
+            for (int ch = 0; ch < 16; ++ch)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc = __builtin_fmaf(__uint_as_float(kv[ch][e] << 16), __uint_as_float(qreg[ch][e] << 16), acc);
+                    acc = __builtin_fmaf(__uint_as_float(kv[ch][e] & 0xffff0000u), __uint_as_float(qreg[ch][e] & 0xffff0000u), acc);
                 }
-                if (!ok) sj = -INFINITY;
-                dsm[j] = sj;
+            float sj = own ? s_new : acc;
+            if (!ok) sj = -INFINITY;
+            const float cmax = wave_max(sj);
+            const float m_new = fmaxf(m_run, cmax * sc);
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);            // m_run = -inf -> 0
+            const float pj = __builtin_amdgcn_exp2f(__builtin_fmaf(sj, sc, -m_use));
+            l_run = l_run * alpha + wave_sum(pj);
+            m_run = m_new;
+            __syncthreads();                                                      // the previous sweep's readers are done with vt / pch
+            pch[lane] = rbf(pj);
+#pragma unroll
+            for (int ch = 0; ch < 16; ++ch) if (ch < nch) *reinterpret_cast<u32x4_d*>(vt + lane * DEC_VSTR + ch * 16) = vv[ch];
+            __syncthreads();
+            o0 *= alpha; o1 *= alpha;
+            if (act) {
+                const int nk = min(64, a.Sk - j0);
+                for (int jj = 0; jj < nk; ++jj) {
+                    const float pv = pch[jj];
+                    const bf16_t* vr = reinterpret_cast<const bf16_t*>(vt + jj * DEC_VSTR);
+                    const bool ownj = (j0 + jj == a.past);                        // the new token's V comes from registers, not from the store just issued
+                    const bool live = pv != 0.f;                                  // (a masked key contributes nothing, whatever its cache row holds)
+                    o0 = __builtin_fmaf(pv, live ? (ownj ? v0 : bf2f(vr[lane])) : 0.f, o0);
+                    o1 = __builtin_fmaf(pv, live ? (ownj ? v1 : bf2f(vr[lane + half])) : 0.f, o1);
+                }
             }
-            mx = fmaxf(mx, sj);
         }
-        mx = wave_max(mx);
-        const float m_new = mx * sc;
-        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-        float lsum = 0.f;
-        __syncthreads();
-        for (int j0 = 0; j0 < a.Sk; j0 += 64) {
-            const int j = j0 + lane;
-            if (j < a.Sk) {
-                const float pj = __builtin_amdgcn_exp2f(__builtin_fmaf(dsm[j], sc, -m_use));
-                lsum += pj;
-                dsm[j] = rbf(pj);
-            }
-        }
-        lsum = wave_sum(lsum);
-        __syncthreads();
-        // ---- O = P V: two head-dim columns per lane, keys in order, eight keys' loads in flight at a time (no branch around a load: the
-        // row-table entries, then the V elements, are requested for the whole group before the first product)
-        float o0 = 0.f, o1 = 0.f;
         if (act) {
-            for (int j0 = 0; j0 < a.Sk; j0 += 16) {
-                float a0[16], a1[16], pj[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const int j = min(j0 + u, a.Sk - 1);
-                    const int pr = srow[j];
-                    const bf16_t* vp = a.cache + ((int64_t)(pr >= 0 ? pr : r) * a.max_len + j) * 2 * kd + kd + (int64_t)g * hd;
-                    a0[u] = bf2f(vp[lane]); a1[u] = bf2f(vp[lane + half]);
-                    pj[u] = (j0 + u < a.Sk) ? dsm[j] : 0.f;
-                }
-#pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const bool own = (j0 + u == a.past);            // the new token's V comes from registers, not from the store just issued
-                    const bool live = pj[u] != 0.f;                   // (a masked key contributes nothing, whatever its cache row holds)
-                    o0 = __builtin_fmaf(pj[u], live ? (own ? v0 : a0[u]) : 0.f, o0);
-                    o1 = __builtin_fmaf(pj[u], live ? (own ? v1 : a1[u]) : 0.f, o1);
-                }
-            }
-            const float inv = lsum > 0.f ? 1.0f / lsum : 0.f;
+            const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
             bf16_t* op = a.out + (int64_t)r * qd + (int64_t)head * hd;
             op[lane] = f2bf(o0 * inv); op[lane + half] = f2bf(o1 * inv);
         }
-        __syncthreads();                               // qs / dsm are rewritten by the next query head
+        __syncthreads();                               // qs / vt / pch are rewritten by the next query head
     }
 }
 
@@ -188,8 +179,8 @@ extern "C" int licv_decode_attn(const licv_decode_attn_args* x, void* stream) {
     p.out = (bf16_t*)x->out;
     p.M = (int)x->M; p.Sk = (int)x->past + 1; p.past = (int)x->past; p.nh = (int)x->n_heads; p.nkv = (int)x->n_kv_heads; p.hd = (int)x->head_dim;
     p.scale = x->scale;
-    const size_t lds = (size_t)p.Sk * (sizeof(float) + sizeof(int));
-    LICV_CHECK_ARG(lds <= 60 * 1024, "decode_attn: history of %d keys exceeds the kernel's LDS budget", p.Sk);
+    const size_t lds = (size_t)p.Sk * sizeof(int);
+    LICV_CHECK_ARG(lds <= 40 * 1024, "decode_attn: history of %d keys exceeds the kernel's LDS budget", p.Sk);
     decode_attn_k<<<dim3((unsigned)(x->M * x->n_kv_heads)), dim3(64), lds, (hipStream_t)stream>>>(p);
     LICV_LAUNCH_CHECK();
     return LICV_OK;
