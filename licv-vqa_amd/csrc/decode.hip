@@ -57,33 +57,54 @@ void decode_attn_k(DecodeP a) {
     const int hd = a.hd, half = hd >> 1, rep = a.nh / a.nkv;
     const int64_t qd = (int64_t)a.nh * hd, kd = (int64_t)a.nkv * hd;
     const bool act = lane < half;
-    int64_t p = a.pos[r];
-    p = p < 0 ? 0 : (p >= a.n_pos ? a.n_pos - 1 : p);
-    const float c = act ? bf2f(a.cosT[p * hd + lane]) : 0.f, s = act ? bf2f(a.sinT[p * hd + lane]) : 0.f;
     const float sc = a.scale * 1.4426950408889634f;
+    const int nch = hd >> 3;                            // 16-byte chunks per K / V row
     const int32_t* rows_r = a.kv_rows ? a.kv_rows + (int64_t)r * a.ld_rows : nullptr;
     const int32_t* valid_r = a.key_valid ? a.key_valid + (int64_t)r * a.Sk : nullptr;
-    // the row table and the mask of this row go to LDS first (requested before the slices above are summed): the K and V loads below
-    // then depend on no other global load
     int* srow = srow_s;
-    for (int j = lane; j < a.Sk; j += 64) {
+    // ---- memory round trip 1: the position, this lane's row-table entry and mask for the FIRST sweep, and the raw elements of K, V and
+    // the first query head (bf16 values or sums of split-K slices) - nothing here depends on anything else
+    int64_t p = a.pos[r];
+    const bool in1 = lane < a.Sk;
+    const int pr1_raw = (in1 && rows_r) ? rows_r[lane] : r;
+    const int vd1 = (in1 && valid_r) ? valid_r[lane] : 1;
+    float klo = 0.f, khi = 0.f, v0 = 0.f, v1 = 0.f, qlo = 0.f, qhi = 0.f;
+    if (act) {
+        klo = dec_in(a, r, qd + (int64_t)g * hd + lane); khi = dec_in(a, r, qd + (int64_t)g * hd + lane + half);
+        v0 = dec_in(a, r, qd + kd + (int64_t)g * hd + lane); v1 = dec_in(a, r, qd + kd + (int64_t)g * hd + lane + half);
+        qlo = dec_in(a, r, (int64_t)(g * rep) * hd + lane); qhi = dec_in(a, r, (int64_t)(g * rep) * hd + lane + half);
+    }
+    for (int j = lane + 64; j < a.Sk; j += 64) {       // (longer histories: the rest of the table goes to LDS)
         const int pr = rows_r ? rows_r[j] : r;
         const bool ok = !valid_r || valid_r[j] != 0;
         srow[j] = ok ? pr : -1;
     }
+    const int pr1 = (in1 && vd1 != 0) ? pr1_raw : -1;
+    if (in1) srow[lane] = pr1;
+    // ---- round trip 2: cos / sin of the position, and the K and V rows of the first sweep's keys (one key per lane) - they need the
+    // position and the table entry only, not the rotary
+    p = p < 0 ? 0 : (p >= a.n_pos ? a.n_pos - 1 : p);
+    const float c = act ? bf2f(a.cosT[p * hd + lane]) : 0.f, s = act ? bf2f(a.sinT[p * hd + lane]) : 0.f;
+    u32x4_d kv1[16], vv1[16];
+    {
+        const bf16_t* rowp = a.cache + ((int64_t)(pr1 >= 0 ? pr1 : r) * a.max_len + (in1 ? lane : 0)) * 2 * kd + (int64_t)g * hd;
+        const u32x4_d* kp = reinterpret_cast<const u32x4_d*>(rowp);
+        const u32x4_d* vp = reinterpret_cast<const u32x4_d*>(rowp + kd);
+#pragma unroll
+        for (int ch = 0; ch < 16; ++ch) kv1[ch] = ch < nch ? kp[ch] : u32x4_d{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int ch = 0; ch < 16; ++ch) vv1[ch] = ch < nch ? vp[ch] : u32x4_d{0u, 0u, 0u, 0u};
+    }
     // ---- the new token's K (rotated) and V of this kv head: into the cache row of THIS beam row at position `past`, and kept in registers
-    float k0 = 0.f, k1 = 0.f, v0 = 0.f, v1 = 0.f;
+    // (the loads above read position `past` of no row: a row's own key is taken from registers below)
+    float k0 = 0.f, k1 = 0.f;
     bf16_t* crow = a.cache + ((int64_t)r * a.max_len + a.past) * 2 * kd + (int64_t)g * hd;
     if (act) {
-        const float lo = dec_in(a, r, qd + (int64_t)g * hd + lane), hi = dec_in(a, r, qd + (int64_t)g * hd + lane + half);
-        k0 = rbf(rbf(lo * c) + rbf(-hi * s));
-        k1 = rbf(rbf(hi * c) + rbf(lo * s));
-        v0 = dec_in(a, r, qd + kd + (int64_t)g * hd + lane);
-        v1 = dec_in(a, r, qd + kd + (int64_t)g * hd + lane + half);
+        k0 = rbf(rbf(klo * c) + rbf(-khi * s));
+        k1 = rbf(rbf(khi * c) + rbf(klo * s));
         crow[lane] = f2bf(k0); crow[lane + half] = f2bf(k1);
         crow[kd + lane] = f2bf(v0); crow[kd + lane + half] = f2bf(v1);
     }
-    const int nch = hd >> 3;                            // 16-byte chunks per K / V row
     __shared__ __attribute__((aligned(16))) char vt[64 * DEC_VSTR];     // the chunk's V rows (bf16), one per key
     __shared__ float pch[64];                                            // ... and their probabilities
     for (int qh = 0; qh < rep; ++qh) {
@@ -91,7 +112,7 @@ void decode_attn_k(DecodeP a) {
         // ---- Q of this head, rotated; its score against the new key from registers
         float q0 = 0.f, q1 = 0.f;
         if (act) {
-            const float lo = dec_in(a, r, (int64_t)head * hd + lane), hi = dec_in(a, r, (int64_t)head * hd + lane + half);
+            const float lo = qh == 0 ? qlo : dec_in(a, r, (int64_t)head * hd + lane), hi = qh == 0 ? qhi : dec_in(a, r, (int64_t)head * hd + lane + half);
             q0 = rbf(rbf(lo * c) + rbf(-hi * s));
             q1 = rbf(rbf(hi * c) + rbf(lo * s));
             qs[lane] = f2bf(q0); qs[lane + half] = f2bf(q1);
@@ -114,10 +135,15 @@ void decode_attn_k(DecodeP a) {
             const u32x4_d* kp = reinterpret_cast<const u32x4_d*>(rowp);
             const u32x4_d* vp = reinterpret_cast<const u32x4_d*>(rowp + kd);
             u32x4_d kv[16], vv[16];
+            if (j0 == 0) {                                                        // requested in round trip 2, the same for every query head
 #pragma unroll
-            for (int ch = 0; ch < 16; ++ch) kv[ch] = ch < nch ? kp[ch] : u32x4_d{0u, 0u, 0u, 0u};
+                for (int ch = 0; ch < 16; ++ch) { kv[ch] = kv1[ch]; vv[ch] = vv1[ch]; }
+            } else {
 #pragma unroll
-            for (int ch = 0; ch < 16; ++ch) vv[ch] = ch < nch ? vp[ch] : u32x4_d{0u, 0u, 0u, 0u};
+                for (int ch = 0; ch < 16; ++ch) kv[ch] = ch < nch ? kp[ch] : u32x4_d{0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int ch = 0; ch < 16; ++ch) vv[ch] = ch < nch ? vp[ch] : u32x4_d{0u, 0u, 0u, 0u};
+            }
             float acc = 0.f;
 #pragma unroll
             for (int ch = 0; ch < 16; ++ch)
