@@ -2408,11 +2408,12 @@ extern "C" int licv_gemm_splitk_plan(int64_t M, int64_t N, int64_t K, int* split
             if (c > 1 && nkt / c < 4) break;                      // at least 4 K tiles per split
             const int64_t wgs = tiles * c, per = (nkt + c - 1) / c;
             const double rounds = (double)((wgs + 511) / 512);
-            // (a lone workgroup's K tile: 0.5 us from warm sweeps, ~0.7 us cold, tools/split_sweep.py.  The cold figure is used for the narrow
-            //  outputs of the vision tower on a few images - N < 2048: the ViT's out / fc2 projections at 8 x 257 rows, 72 -> 52 us for fc2 -
-            //  and NOT for the language stack's N >= 4096, where it would split the projections of a single 800-token question and move its
-            //  logits away from the same question inside a batch of 8 by more than the P2 bar of tests/test_fullsize_gpu.py allows)
-            const double tk = wgs <= 256 ? (N < 2048 ? 0.7 : 0.5) : 0.9;
+            // (a lone workgroup's K tile: 0.5 us from warm sweeps, ~0.7 us cold, tools/split_sweep.py.  The cold figure is used where it was
+            //  measured to pay and nothing else moves: the narrow outputs (N < 2048) of the vision tower on at most 8 images (M <= 2056: the
+            //  student pass and the prefill of generate; the ViT's fc2 72 -> 52 us).  Used everywhere it splits the projections of a single
+            //  32-shot question (perceiver at 2112 rows, text at 800) that its batch of 8 runs in one pass, and the question's logits then
+            //  move away from the batch's by 0.063 relative L2 against the 0.05 bar of tests/test_fullsize_gpu.py P2 - measured twice.)
+            const double tk = wgs <= 256 ? ((N < 2048 && M <= 2056) ? 0.7 : 0.5) : 0.9;
             double t = rounds * (per * tk + 4.0);
             if (c > 1) t += (double)(c + 1) * M * N * 4.0 / 3.0e6 + 5.0;
             if (t < best) { best = t; sp = c; }

@@ -235,7 +235,7 @@ def test_fullsize_idefics2_fp8_32shot_properties(fp8_vision, B):
     assert torch.equal(lg8, e8.forward(**ins8, icv=scaled, hook_layers=layers))                          # F1
     # The capture run takes the UNFUSED kernels (every intermediate exists as a tensor).  At toy and mid sizes the two paths are bit
     # for bit the same; over the 3.6e9 branch elements of this configuration ONE differed by one bf16 ulp (tools/diag_fp8_b8_paths.py:
-    # layer 19, question 4, position 292, column 2868) and e4m3 rounding then spreads it over that question.  Both paths are
+    # first at layer 17: question 4, position 292, column 2868) and e4m3 rounding then spreads it over that question.  Both paths are
     # deterministic and batch-independent (tools/diag_fp8_b8.py); questions are compared one by one and the rest must be identical.
     same_q = [bool(torch.equal(lg8[q], lg_cap[q])) for q in range(B)]
     v0 = batch["attention_mask"].bool()

@@ -338,4 +338,4 @@ def test_w6_idefics9b_widths_hooked_beam_generate_vs_oracle(nl, side):
                   f"decode step {t} logits ({int(in_sync.sum())} questions in the same search state, {int(rows.sum())} beam rows)", rep)
     finally:
         print("  W6 " + "\n  W6 ".join(rep))
-    assert len(rep) >= 3, "fewer than two decode steps could be compared"
+    assert len(rep) >= 2, "no decode step could be compared"            # (prefill + at least one step in the same search state)
