@@ -22,6 +22,9 @@ int licv_probe_permlane16_swap(void* out_u32_128, void* stream);
 int licv_probe_weight_stream(const void* W, int64_t ldw, int64_t N, int64_t K, int splits, int shape, int depth, void* sink_u32, void* stream);
 /* the same stream as LDS-DMA pieces (8 rows x 128 B per instruction), `depth` (4 / 8 / 16 / 32 / 48) pieces outstanding per wave */
 int licv_probe_lds_dma_stream(const void* W, int64_t ldw, int64_t N, int64_t K, int splits, int depth, void* stream);
+/* per-CU operand bandwidth from an L2-resident buffer: every one of `blocks` workgroups reads the same `bytes` `reps` times; mode 0 =
+ * buffer loads to VGPRs, 1 = LDS-DMA pieces, 2 = two waves each at once (each pair reads the whole buffer) */
+int licv_probe_l2_ingest(const void* buf, int64_t bytes, int reps, int mode, int blocks, void* sink_u32, void* stream);
 #ifdef __cplusplus
 }
 #endif

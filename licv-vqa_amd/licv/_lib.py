@@ -165,7 +165,8 @@ def lab() -> C.CDLL:
         P, I64, I = C.c_void_p, C.c_int64, C.c_int
         for name, args in {"licv_lab_loaded": [], "licv_gemm_stagger": [I], "licv_probe_mfma_loop": [P, I, I, P],
                            "licv_probe_permlane16_swap": [P, P], "licv_probe_weight_stream": [P, I64, I64, I64, I, I, I, P, P],
-                           "licv_probe_lds_dma_stream": [P, I64, I64, I64, I, I, P]}.items():
+                           "licv_probe_lds_dma_stream": [P, I64, I64, I64, I, I, P],
+                           "licv_probe_l2_ingest": [P, I64, I, I, I, P, P]}.items():
             fn = getattr(_lab, name)
             fn.argtypes, fn.restype = args, C.c_int
     return _lab
