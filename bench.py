@@ -594,7 +594,7 @@ def main():
         have, want = pmc.get("gemm_src_sha16"), gemm_src_sha16()
         if have != want:                                                  # measured on other kernels than the ones that just ran
             pmc_why = (f"null: the newest committed PMC summary (profiles/{pmc_file.name}, commit {pmc.get('commit', '?')}) was measured on GEMM "
-                       f"sources {have or 'without a recorded hash'}; this tree's are {want} - re-run the PMC passes (tools/r03_profile.sh)")
+                       f"sources {have or 'without a recorded hash'}; this tree's are {want} - re-run the PMC passes (tools/r04_profile.sh <commit> partA) and commit profiles/rNN_pmc_headline_gemm.json")
             pmc = None
     ti, by, ni = agg("inject")
     fq = {"total": fl / max(roof_steps, 1) / B} if is2 else flops_per_question(arch, S, n_img)   # Idefics2: GEMM flops as launched
