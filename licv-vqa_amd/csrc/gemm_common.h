@@ -431,6 +431,30 @@ __device__ __forceinline__ void epilogue_rows(const GemmEpi& ep, void* __restric
     else             epilogue_rows_generic<TM, TN, NWAVES, 4>(ep, C, ldc, M, N, m0, n0, wave, lane, smem);
 }
 
+// The same dispatch with every family inlined at the call (the statement attribute overrides the callee's noinline): for a kernel whose
+// register budget is half a SIMD's file (the tall kernel: eight waves, 128 accumulators) - as separate functions the families keep
+// their own ~150 arch VGPRs, which are added to the kernel's accumulator file in its resource record.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wignored-attributes"
+template <int TM, int TN, int NWAVES>
+__device__ __forceinline__ void epilogue_rows_inlined(const GemmEpi& ep, void* __restrict__ C, int64_t ldc, int M, int N, int m0, int n0,
+                                                      int wave, int lane, const char* smem) {
+    const bool bf_out = ep.out_dtype == LICV_BF16;
+    const bool simple = !ep.residual && !ep.row_gate && !ep.use_scale && bf_out;
+    if (simple && ep.swiglu)                 { [[clang::always_inline]] epilogue_rows_swiglu<TM, TN, NWAVES>(C, ldc, M, N, m0, n0, wave, lane, smem); }
+    else if (simple && ep.act == 0)          { [[clang::always_inline]] epilogue_rows_plain<TM, TN, NWAVES>(C, ldc, M, N, m0, n0, wave, lane, smem); }
+    else if (simple && ep.act == 1)          { [[clang::always_inline]] epilogue_rows_act<TM, TN, NWAVES, 1>(C, ldc, M, N, m0, n0, wave, lane, smem); }
+    else if (simple && ep.act == 2)          { [[clang::always_inline]] epilogue_rows_act<TM, TN, NWAVES, 2>(C, ldc, M, N, m0, n0, wave, lane, smem); }
+    else if (simple && ep.act == 3)          { [[clang::always_inline]] epilogue_rows_act<TM, TN, NWAVES, 3>(C, ldc, M, N, m0, n0, wave, lane, smem); }
+    else if (ep.residual && !ep.swiglu && !ep.act && ep.residual_dtype == LICV_BF16 && bf_out)
+        { [[clang::always_inline]] epilogue_rows_res<TM, TN, NWAVES, false>(ep, C, ldc, M, N, m0, n0, wave, lane, smem); }
+    else if (ep.residual && !ep.swiglu && !ep.act && ep.residual_dtype == LICV_F32 && !bf_out)
+        { [[clang::always_inline]] epilogue_rows_res<TM, TN, NWAVES, true>(ep, C, ldc, M, N, m0, n0, wave, lane, smem); }
+    else if (bf_out) { [[clang::always_inline]] epilogue_rows_generic<TM, TN, NWAVES, 8>(ep, C, ldc, M, N, m0, n0, wave, lane, smem); }
+    else             { [[clang::always_inline]] epilogue_rows_generic<TM, TN, NWAVES, 4>(ep, C, ldc, M, N, m0, n0, wave, lane, smem); }
+}
+#pragma clang diagnostic pop
+
 // ------------------------------------------------------------------------------------------------
 // LDS-staged epilogue (all kernels).  Two measured problems of storing straight from the accumulator layout:
 // 32-byte row fragments per store, and — far worse — code size: the element-wise epilogue (erf / tanh / exp
@@ -452,12 +476,12 @@ static int set_dbg_ts(void* dev_buffer) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_ts), &p, sizeof(p)) == hipSuccess ? LICV_OK : LICV_E_HIP;
 }
 
-template <int TM, int TN, int NWAVES, int MT, int NT, bool SCALED = false>
-__device__ __forceinline__ void epilogue_staged(floatx4 (&acc)[MT][NT], const GemmEpi& ep, void* __restrict__ C, int64_t ldc,
-                                                int M, int N, int m0, int n0, int wrow0, int wcol0, int wave, int lane, char* smem,
-                                                long long* ts = nullptr, const float (*bias_pre)[4] = nullptr) {
+// phase A alone: registers -> LDS image of y0 = bf16(acc + bias) (the tall kernel runs it on its four multiplying waves only and
+// phase B on all eight)
+template <int TN, int MT, int NT, bool SCALED = false>
+__device__ __forceinline__ void epilogue_image(floatx4 (&acc)[MT][NT], const GemmEpi& ep, int M, int N, int m0, int n0, int wrow0, int wcol0,
+                                               int lane, char* smem, const float (*bias_pre)[4] = nullptr) {
     constexpr int YS = TN * 2 + 16;                       // LDS row stride in bytes
-    // ---- phase A: registers -> LDS image of y0 = bf16(acc + bias)
     {
         const int rl = wrow0 + (lane & 15);
         const int cq = (lane >> 4) * 4;
@@ -495,6 +519,14 @@ __device__ __forceinline__ void epilogue_staged(floatx4 (&acc)[MT][NT], const Ge
             });
         });
     }
+}
+
+template <int TM, int TN, int NWAVES, int MT, int NT, bool SCALED = false>
+__device__ __forceinline__ void epilogue_staged(floatx4 (&acc)[MT][NT], const GemmEpi& ep, void* __restrict__ C, int64_t ldc,
+                                                int M, int N, int m0, int n0, int wrow0, int wcol0, int wave, int lane, char* smem,
+                                                long long* ts = nullptr, const float (*bias_pre)[4] = nullptr) {
+    // ---- phase A: registers -> LDS image of y0 = bf16(acc + bias)
+    epilogue_image<TN, MT, NT, SCALED>(acc, ep, M, N, m0, n0, wrow0, wcol0, lane, smem, bias_pre);
     __syncthreads();
     if (ts) ts[3] = wall_clock64();
     // ---- phase B: compact loop over rows; lane -> 8 (bf16 out) or 4 (fp32 out) consecutive OUTPUT columns

@@ -841,6 +841,54 @@ def test_rotary_and_cache_append_from_split_k_slices(B, S, nh, hd, K):
     assert c1[:, past:past + S].abs().sum() > 0 and not c1[:, :past].any() and not c1[:, past + S:].any()
 
 
+@pytest.mark.parametrize("epi", ["plain", "bias_gelu", "swiglu", "res32", "res_bf16_gate_scale", "f32_out"])
+@pytest.mark.parametrize("M,N,K", [(256, 4096, 4096), (256, 640, 128), (129, 200, 192), (200, 1312, 2048), (255, 4096, 11008), (256, 32002, 256)])
+def test_tall_kernel_matches_mid_kernel(M, N, K, epi):
+    """The 256 x 128 tall kernel (129-256 rows; licv_gemm_select 71 / knob 12) multiplies the K tiles in the mid kernel's order with the
+    same rounding points: bit-identical to it (select 70) in one pass for every epilogue family — ragged M, a partial last tile column
+    (N % 128 != 0), the minimum K (two K tiles: prologue and tail only), three K tiles (one steady tile) — and, as the split-K
+    producer under the same forced split count, slice for slice (the finalized outputs agree bit for bit).  Run twice: no state left
+    in LDS matters."""
+    from licv import _lib, ops
+    if epi == "swiglu" and N % 32:
+        pytest.skip("swiglu needs N % 32 == 0")
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(torch.bfloat16).to(DEV)
+    n_out = N // 2 if epi == "swiglu" else N
+    kw = {}
+    if epi == "bias_gelu":
+        kw = dict(bias=torch.randn(N, generator=g).to(torch.bfloat16).to(DEV), act="gelu")
+    elif epi == "swiglu":
+        kw = dict(swiglu=True)
+    elif epi == "res32":
+        kw = dict(residual=torch.randn(M, (n_out + 7) // 8 * 8, generator=g).to(DEV), ld_res=(n_out + 7) // 8 * 8)
+    elif epi == "res_bf16_gate_scale":
+        kw = dict(residual=torch.randn(M, (n_out + 7) // 8 * 8, generator=g).to(torch.bfloat16).to(DEV), ld_res=(n_out + 7) // 8 * 8, scale=0.37,
+                  row_gate=(torch.rand(M, generator=g) > 0.3).float().to(DEV))
+    elif epi == "f32_out":
+        kw = dict(out_dtype=torch.float32)
+    lib = _lib.lib()
+    outs = {}
+    try:
+        for sp in (1, 2, 3, 8):
+            if sp > 1 and K // 64 // sp < 2:
+                continue
+            lib.licv_gemm_experiment(5, sp)
+            for sel in (70, 71, 71):
+                lib.licv_gemm_select(sel)
+                outs.setdefault((sp, sel), []).append(ops.linear(a, w, **kw).clone())
+            assert torch.equal(outs[(sp, 71)][0], outs[(sp, 71)][1]), f"two launches of the tall kernel differ (splits {sp})"
+            bad = outs[(sp, 70)][0] != outs[(sp, 71)][0]
+            assert not bool(bad.any()), f"splits {sp}: tall differs from mid in {int(bad.sum())} elements, first at {bad.nonzero()[0].tolist()}"
+    finally:
+        lib.licv_gemm_experiment(5, 0)
+        lib.licv_gemm_select(0)
+    if epi == "plain":
+        ref = a.float() @ w.float().t()
+        assert (outs[(1, 71)][0].float() - ref).abs().max() <= 2 ** -7 * ref.abs().max()
+
+
 @pytest.mark.parametrize("M,N,K,epi", [(256, 4096, 4096, "plain"), (256, 1536, 1280, "bias_gelu"), (200, 640, 2048, "res32"), (130, 4096, 11008, "plain"),
                                        (1376, 4096, 4096, "plain")])
 def test_mid_kernel_with_four_k_tiles_in_flight_is_bit_identical(M, N, K, epi):
