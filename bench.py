@@ -357,6 +357,8 @@ def main():
     ap.add_argument("--no-hooks", action="store_true", help="teacher shape: same forward with the intervention off")
     ap.add_argument("--no-profiler", action="store_true", help="no per-launch event pairs: the language stack then runs through the native layer runner")
     ap.add_argument("--batch-streams", type=int, default=-1, help="diagnostic A/B only: slices of the batch run on HIP streams of their own (engine default: 2); 1 = off")
+    ap.add_argument("--gemm-knob", type=int, nargs=2, action="append", default=[], metavar=("KNOB", "VALUE"),
+                    help="diagnostic A/B only: licv_gemm_experiment(KNOB, VALUE), e.g. 12 0 = rows 129-256 stay on the 128-tile kernel")
     ap.add_argument("--gemm-select", type=int, default=0, help="diagnostic A/B only: force a GEMM kernel variant (licv_gemm_select); 0 = the library's own choice")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; default).  'gloo' only to rehearse the multi-rank code path "
                     "on a box with fewer GPUs than ranks (ranks then share devices: timings are meaningless)")
@@ -402,6 +404,9 @@ def main():
     if args.prefetch_mib >= 0:
         from licv import _lib as _l
         _l.check(_l.lib().licv_runner_option(2, args.prefetch_mib))
+    for knob, value in args.gemm_knob:
+        from licv import _lib as _lk
+        _lk.check(_lk.lib().licv_gemm_experiment(knob, value))
     if args.gemm_select:
         from licv import _lib
         _lib.lib().licv_gemm_select(args.gemm_select)

@@ -2254,9 +2254,19 @@ static bool mid_deep(int64_t M, int64_t min_ktiles) {
     return g_mid_depth == 4 && min_ktiles >= 4;
 }
 static int g_nt_weights = 0;   // knob 11: bit 0 = the 128-tile mid kernel's W pieces non-temporal, bit 1 = the skinny kernel's weight stream (A/B timing; bit-identical results)
-static int g_tall = 1;         // knob 12: 1 = 128 < M <= 256 takes the 256 x 128 tall kernel (one pass and split-K producer); 0 = the mid kernel as before (A/B, tests)
+static int g_tall = 1;         // knob 12: 1 = wide outputs at 128 < M <= 256 take the 256 x 128 tall kernel (one pass and split-K producer); 0 = the mid kernel (A/B)
+static int g_force_kernel = 0;  // licv_gemm_select
 static bool tall_ok(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw) {
     return M > 128 && M <= 256 && N >= 128 && K % 64 == 0 && K >= 128 && lda * 510 < (1ll << 31) && ldw * 510 < (1ll << 31);
+}
+// Where the tall kernel is the route (select 71: wherever it can run).  Measured cold at M = 256 (tools/tall_bench.py,
+// profiles/r04_tall_bench_v2_loader_waves.txt, us tall | mid at each one's best split count): 22016 x 4096 SwiGLU 60.0 | 73.7, 32002 x 4096
+// 78.0 | 86.1, 28672 x 4096 74.4 | 80.1, 12288 x 4096 45.4 | 49.1; but 8192 x 4096 34.4 | 33.2, 4096 x 4096 26.2 | 22.7, 4096 x 11008
+// 44.0 | 42.5, 2048 x 4096 20.5 | 18.1: with few tile columns the 128-tile grid fills the chip with half the split-K slices.
+static bool tall_route(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw) {
+    if (!tall_ok(M, N, K, lda, ldw)) return false;
+    if (g_force_kernel == 71) return true;
+    return g_force_kernel == 0 && g_tall && N >= 10240;
 }
 static int g_mid_ablate = 0;    // knob 9 (timing only, WRONG RESULTS): the 128-tile mid kernel without its A pieces (1) / W pieces (2)
 static int g_flow_default = 1;  // auto mode takes the flow kernels where they are eligible (knob 2 of licv_gemm_experiment; 0 = staged epilogues only)
@@ -2288,9 +2298,8 @@ extern "C" int licv_gemm_experiment(int knob, int value) {
 }
 static int g_num_cus = 256;        // persistent grid size (queried once)
 // 0 auto; 1 tile128; 20 the 8-wave flow kernel where eligible (else lean); 22-27 lean variants; 40-42 quad64 variants (staged
-// epilogue); 60 the 4-wave flow64 kernel where eligible; 70 the 128-tile mid kernel at any M; every other value names a kernel of
+// epilogue); 60 the 4-wave flow64 kernel where eligible; 70 the 128-tile mid kernel at any M; 71 the 256 x 128 tall kernel wherever it can run (129-256 rows); every other value names a kernel of
 // gemm_experiments.hip
-static int g_force_kernel = 0;
 extern "C" int licv_gemm_select(int which) { g_force_kernel = which; return LICV_OK; }
 
 // The flow kernel's counted s_waitcnt vmcnt(N) assume that the ONLY vector-memory operations a wave issues are its LDS-DMA
@@ -2499,7 +2508,7 @@ extern "C" int licv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
     } else {
         const int t128m = (int)((M + 127) / 128), t128n = (int)((N + 127) / 128);
         // 129-256 rows: one 256-row tile per 128 columns (select 71: forced; 70 / knob 12 = 0: the mid kernel instead)
-        if ((fk == 71 || (fk == 0 && g_tall)) && tall_ok(M, N, K, lda, ldw)) {
+        if (tall_route(M, N, K, lda, ldw)) {
             static bool atall = false;
             if (!atall) { (void)hipFuncSetAttribute((const void*)gemm_bf16_tall_k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, TALL_LDS); atall = true; }
             gemm_bf16_tall_k<0><<<dim3(t128n), dim3(512), TALL_LDS, (hipStream_t)stream>>>(
@@ -2586,7 +2595,7 @@ extern "C" int licv_gemm_splitk_plan(int64_t M, int64_t N, int64_t K, int* split
         // CU is shared by its two workgroups: ~0.5 us per 32 KiB K tile alone, ~0.9 us each in pairs), plus — for sp > 1 — the fp32
         // partials written once and read once at ~3 TB/s and a second launch.  Constants from tools/mid_bench.py sweeps.
         double best = 1e30;
-        const bool tall = g_tall && (g_force_kernel == 0 || g_force_kernel == 71) && tall_ok(M, N, K, K, K);
+        const bool tall = tall_route(M, N, K, K, K);
         for (int64_t c : {1, 2, 3, 4, 6, 8, 12, 16}) {
             if (c > 1 && nkt / c < 4) break;                      // at least 4 K tiles per split
             if (tall) {
@@ -2705,7 +2714,7 @@ static int splitk_run(const void* A, int64_t lda, const void* W, int64_t ldw, vo
         attr = true;
     }
     hipStream_t st = (hipStream_t)stream;
-    if ((g_force_kernel == 71 || (g_force_kernel == 0 && g_tall)) && tall_ok(M, N, K, lda, ldw) && nkt - (splits - 1) * per >= 2) {
+    if (tall_route(M, N, K, lda, ldw) && nkt - (splits - 1) * per >= 2) {
         // 129-256 rows: the tall kernel as the producer (slices of 256 rows: the same layout)
         static bool atall = false;
         if (!atall) { (void)hipFuncSetAttribute((const void*)gemm_bf16_tall_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, TALL_LDS); atall = true; }

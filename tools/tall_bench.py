@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The 256 x 128 tall kernel (licv_gemm_experiment knob 12; 129-256 rows) against the 128-tile mid kernel on the M = 256 weight-streaming
+"""The 256 x 128 tall kernel (licv_gemm_select 71; 129-256 rows) against the 128-tile mid kernel on the M = 256 weight-streaming
 shapes of the student pass and of generate's prefill, COLD (distinct matrices cycled, as tools/split_sweep.py), under the plan's own
 split-K choice (sp0) and forced counts (knob 5): the data the plan's tall constants are fitted to.  Also checks that at every forced
 count the two producers give the same bits."""
@@ -25,7 +25,7 @@ for (M, N, K, epi) in SHAPES:
     lines = {}
     outs = {}
     for tall in (0, 1):
-        lib.licv_gemm_experiment(12, tall)
+        lib.licv_gemm_select(71 if tall else 70)             # forced: the tall kernel wherever it can run / the mid kernel
         line = f"{M:4d} {N:6d} {K:6d} {epi:6s} {'tall' if tall else 'mid '}"
         for sp in (0, 1, 2, 3, 4, 6, 8, 12, 16):
             if sp > 1 and K // 64 // sp < 2:
@@ -48,7 +48,7 @@ for (M, N, K, epi) in SHAPES:
                 outs[(tall, sp)] = ops.linear(a, ws[0], **kw).clone()
         lib.licv_gemm_experiment(5, 0)
         print(line, flush=True)
-    lib.licv_gemm_experiment(12, 1)
+    lib.licv_gemm_select(0)
     bad = [sp for (t, sp) in outs if t == 0 and (1, sp) in outs and not torch.equal(outs[(0, sp)], outs[(1, sp)])]
     print(f"     bits: {'identical at every forced count' if not bad else 'DIFFER at sp ' + str(bad)}", flush=True)
     del ws
