@@ -2077,7 +2077,7 @@ void skinny_finalize_k(const float* __restrict__ ws, void* __restrict__ C, int64
 }
 
 template <int MB, int NT = 0>       // 16-row blocks of A: 1 (M <= 16) or 2 (M <= 32); NT = 1: the weight stream is loaded non-temporal (knob 11)
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256, 3)       // three workgroups per CU (3 x 52 KB of LDS at M = 24): at most 168 registers
 void gemm_bf16_skinny_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw, float* __restrict__ ws,
                         int M, int N, int K, int steps_per_split, int64_t np, unsigned* __restrict__ tickets, void* __restrict__ C, int64_t ldc, GemmEpi ep) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -2110,31 +2110,50 @@ void gemm_bf16_skinny_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t*
             dst[u] = __builtin_amdgcn_raw_buffer_load_b128(rsw, ok ? wrow + (uint32_t)(s + u) * 64u : OOB, 0, NT ? 2 : 0);     // aux 2 = nt
         }
     };
-    loadw(0, wf[0]);
-    // ---- activations of this K range -> LDS (zero rows past M, zero columns past K)
+    // ---- activations of this K range -> LDS (zero rows past M, zero columns past K), and the first TWO weight sets.
+    // Order of issue: the activation loads (L2 hits), then both weight sets, then the LDS writes.  Vector-memory operations retire in
+    // order: with the weight set requested first (the version before) the activations' wait drained it - a whole HBM latency before the
+    // first LDS write, and the second set was not requested until the barrier behind the writes.  Now the writes wait for the
+    // activations alone (counted vmcnt, 16 weight loads left in flight) and two sets per wave are on their way while the image is built.
     const auto rsa = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0xFFFFFFFF, 0x00020000);
     const int chunks = kr / 8;
-    constexpr int XU = 8;                                           // loads in flight per thread (one at a time: ~16 serial L2 round trips per workgroup)
+    constexpr int XU = 13;                                          // activation loads in flight per thread: one batch covers 25 rows (M = 24 + the zero row) x 1024 K; more would not fit 168 registers beside the two weight sets
     // rows 0 .. M - 1 and ONE zero row (index M) that every fragment row >= M reads: 25 rows instead of 32 at M = 24 is a third
     // workgroup per CU (3 x 52 KB of LDS), and 768 workgroups are one round instead of one and a half
     const int xrows = M + 1;
-    for (int c0 = tid; c0 < xrows * chunks; c0 += 256 * XU) {
-        u32x4 v[XU];
+    const int nitem = xrows * chunks;
+    u32x4 v[XU];
+    // item c = row * chunks + ch of the image, c = tid + 256 j: (row, ch) walks by a fixed step - one division per thread, not one per item
+    // (thirty-two 32-bit divisions were ~1000 VALU instructions at the head of every workgroup).  No branch around a load or a write: an
+    // item past the image is a zero (out-of-range load) written into the zero row.
+    const int q256 = 256 / chunks, r256 = 256 - q256 * chunks;
+    int row_s = tid / chunks, ch_s = tid - row_s * chunks;          // first item of the batch being staged
+    auto xload = [&]() {
+        int row = row_s, ch = ch_s;
 #pragma unroll
         for (int j = 0; j < XU; ++j) {
-            const int c = c0 + j * 256;
-            const int row = c / chunks, ch = c - row * chunks;
             const int k = kbase + ch * 8;
-            const bool ok = (int)(c < xrows * chunks) & (int)(row < M) & (int)(k < K);
+            const bool ok = (int)(row < M) & (int)(k < K);
             v[j] = __builtin_amdgcn_raw_buffer_load_b128(rsa, ok ? (uint32_t)(row * (int)lda + k) * 2u : OOB, 0, 0);
+            ch += r256; row += q256;
+            if (ch >= chunks) { ch -= chunks; ++row; }
         }
+    };
+    auto xstore = [&]() {
+        int row = row_s, ch = ch_s;
 #pragma unroll
         for (int j = 0; j < XU; ++j) {
-            const int c = c0 + j * 256;
-            const int row = c / chunks, ch = c - row * chunks;
-            if (c < xrows * chunks) *reinterpret_cast<u32x4*>(smem + row * xstr + ch * 16) = v[j];
+            *reinterpret_cast<u32x4*>(smem + min(row, M) * xstr + ch * 16) = v[j];
+            ch += r256; row += q256;
+            if (ch >= chunks) { ch -= chunks; ++row; }
         }
-    }
+        row_s = row; ch_s = ch;
+    };
+    xload();
+    loadw(0, wf[0]);
+    loadw(UN, wf[1]);
+    xstore();
+    for (int c0 = 256 * XU; c0 < nitem; c0 += 256 * XU) { xload(); xstore(); }      // (M > 25 at 1024 K only)
     __syncthreads();
     const char* xp[MB];
 #pragma unroll
@@ -2154,10 +2173,10 @@ void gemm_bf16_skinny_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t*
         }
     };
     for (int s = 0; s < ns; s += 2 * UN) {
-        loadw(s + UN, wf[1]);                                       // (sets past the range: all lanes out of range, no traffic)
         mul(s, wf[0]);
-        loadw(s + 2 * UN, wf[0]);
+        loadw(s + 2 * UN, wf[0]);                                   // (sets past the range: all lanes out of range, no traffic)
         mul(s + UN, wf[1]);
+        loadw(s + 3 * UN, wf[1]);
     }
     // lane holds rows m = mb*16 + fr, columns n0 + fq*4 .. +3  (W was the A operand)
     float* slice = ws + (int64_t)blockIdx.y * 32 * np;
