@@ -17,10 +17,13 @@ than the reference's own bf16 path, measured against the fp32 oracle):
   (ii)  max|hip - f32_gold|  <= 1.5 * max|bf16_gold - f32_gold| + 1e-3 * scale
   (iii) relative L2 |hip - f32_gold| / |f32_gold| <= 1.25 * the same figure of the bf16 oracle + 1e-4
 Token ids are integers: a row must be IDENTICAL to the oracle's bf16 decode whenever the oracle itself decides that row by more than
-its own bf16-vs-fp32 noise — operationally: the fp32 oracle returns the same row, and so do N_JITTER re-decodes of the bf16 oracle
-with every logit moved by uniform noise whose variance is that of the measured bf16-vs-fp32 logit deviation of that question (per
-unit of head-row norm: a logit's error is proportional to the norm of its head row) — the full-width form of the stability column
-of fixtures g11 / g15 (measured on the CPU: 4 of 8 rows decided at either depth).
+TWICE its own bf16-vs-fp32 noise — operationally: the fp32 oracle returns the same row, and so do N_JITTER re-decodes of the bf16
+oracle with every logit moved by uniform noise of JITTER_SCALE = 2 x the standard deviation of the measured bf16-vs-fp32 logit
+deviation of that question (per unit of head-row norm: a logit's error is proportional to the norm of its head row) — the full-width
+form of the stability column of fixtures g11 / g15.  (At 1 x the noise and six samples a "decided" row still flips for a ninth sample of
+the same noise about one run in ten — seen once the tall kernel's split-K plan moved the engine's own rounding: row by row on the CPU,
+rows that survive four samples at 2 x are the ones no sample at 1 x moves: 2 of 8 at 4 layers, 3 of 8 at 8 layers.)  The re-decodes
+replay the recorded prefill (logits and KV cache) of the plain bf16 decode: only the noise differs.
 The number of decided rows is printed and must be positive.  A random-init head gives 32002 near-Gaussian logits whose top
 candidates sit closer together than bf16 noise (measured: 0 - 2 of 8 rows decided), so — as fixtures g15 / g16 scale the embedding
 and the head to get decisive prompts — the head rows get log-normal norms (exp(N(0, 1)), seeded): a peaked next-token
@@ -46,7 +49,8 @@ from oracle import idefics_ref as R
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
-N_JITTER = 6
+N_JITTER = 4
+JITTER_SCALE = 2.0
 
 
 def _wbar(hip, gold_bf16, gold_f32, what, report, rel_floor=None):
@@ -233,7 +237,11 @@ class _Recorder:
         return lg
 
     def prefill(self, ids, am):
-        return self._out(self.inner.prefill(ids, am))
+        lg = self.inner.prefill(ids, am)
+        if isinstance(getattr(self.inner, "cache", None), list):
+            self.cache0 = list(self.inner.cache)            # (the oracle's KV cache right after the prefill: entries are replaced, never written in place)
+        self.clean0 = lg.float().cpu()
+        return self._out(lg)
 
     def step(self, new_ids, am):
         self.fed.append(new_ids.reshape(-1).cpu().clone())
@@ -247,8 +255,25 @@ class _Recorder:
         self.inner.replicate(nb)
 
 
-def _oracle_decode(sd, arch, batch, hooks, nb, noise=None, seed=0):
-    m = G._IdeficsModel(sd, arch, batch["pixel_values"], batch["image_attention_mask"], nb, hooks)
+class _Replay:
+    """The oracle model behind a recorded prefill: prefill() hands back the recorded logits and the KV cache that prefill left."""
+
+    def __init__(self, base):
+        self.inner, self.lg, self.c0 = base.inner, base.clean0, base.cache0
+
+    def prefill(self, ids, am):
+        self.inner.cache = list(self.c0)
+        return self.lg.clone()
+
+    def step(self, new_ids, am):
+        return self.inner.step(new_ids, am)
+
+    def reorder(self, flat):
+        self.inner.reorder(flat)
+
+
+def _oracle_decode(sd, arch, batch, hooks, nb, noise=None, seed=0, replay=None):
+    m = _Replay(replay) if replay is not None else G._IdeficsModel(sd, arch, batch["pixel_values"], batch["image_attention_mask"], nb, hooks)
     rec = _Recorder(m, noise, torch.Generator().manual_seed(seed))
     with torch.no_grad():
         ids = G._decode(rec, arch, batch["input_ids"], batch["attention_mask"], max_new_tokens=5, num_beams=nb, length_penalty=0.0,
@@ -307,15 +332,15 @@ def test_w6_idefics9b_widths_hooked_beam_generate_vs_oracle(nl, side):
     envelope = ((pre16 - pre32) / wn[None]).pow(2).mean(dim=1, keepdim=True).sqrt() * wn[None] * 3 ** 0.5           # (B, V)
     decided = torch.tensor([_same_row(ids16, ids32, q) for q in range(B)])
     for j in range(N_JITTER):
-        idsj, _ = _oracle_decode(s16, arch, batch, hooks, nb, noise=envelope, seed=980 + j)
+        idsj, _ = _oracle_decode(s16, arch, batch, hooks, nb, noise=envelope * JITTER_SCALE, seed=980 + j, replay=r16)
         decided &= torch.tensor([_same_row(ids16, idsj, q) for q in range(B)])
     same = torch.tensor([_same_row(got, ids16, q) for q in range(B)])
     same32 = torch.tensor([_same_row(got, ids32, q) for q in range(B)])
     print(f"\n  W6 {nl} layers, {side}-padded prompts, B = {B}, {nb} beams x 5 tokens: native {t_native:.2f}s, CPU oracle bf16 {t_oracle:.1f}s; "
-          f"rows identical to the bf16 oracle {int(same.sum())}/{B}, to the fp32 oracle {int(same32.sum())}/{B}; decided by more than the "
-          f"oracle's own noise (fp32 + {N_JITTER} jittered re-decodes agree) {int(decided.sum())}/{B}; bf16 and fp32 oracles agree on "
+          f"rows identical to the bf16 oracle {int(same.sum())}/{B}, to the fp32 oracle {int(same32.sum())}/{B}; decided by more than "
+          f"{JITTER_SCALE:g} x the oracle's own noise (fp32 + {N_JITTER} jittered re-decodes agree) {int(decided.sum())}/{B}; bf16 and fp32 oracles agree on "
           f"{sum(_same_row(ids16, ids32, q) for q in range(B))}/{B}")
-    assert int(decided.sum()) > 0, "no row of this batch is decided by more than the oracle's own bf16 noise: the id check would be vacuous"
+    assert int(decided.sum()) > 0, "no row of this batch is decided by more than twice the oracle's own bf16 noise: the id check would be vacuous"
     assert bool(same[decided].all()), f"rows decided by more than bf16 noise differ: {(~same & decided).nonzero().flatten().tolist()}"
     # ---- logits of every model call while the two searches are in the same state (same fed ids, same beam order so far)
     rep = []
