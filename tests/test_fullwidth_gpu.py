@@ -62,7 +62,7 @@ def _cpu(sd, dtype):
 
 def test_w1_idefics9b_widths_truncated_depth_vs_oracle():
     from licv.idefics_engine import IdeficsEngine, IdeficsWeights
-    torch.set_num_threads(max(torch.get_num_threads(), 8))
+    torch.set_num_threads(max(torch.get_num_threads(), 8))      # (conftest.py caps the default at twice the cgroup quota)
     arch = IDEFICS_9B.with_(v_layers=2, r_depth=2, num_layers=2, cross_layer_interval=2)
     sd = trained_like_(synth_idefics_weights(arch, seed=901, dtype=torch.float32, device=DEV), 2)
     eng = IdeficsEngine(IdeficsWeights(sd, arch, DEV))
@@ -105,7 +105,7 @@ def test_w1_idefics9b_widths_truncated_depth_vs_oracle():
 @pytest.mark.parametrize("fp8", [False, True, "all"], ids=["bf16", "fp8_text", "fp8_text_and_vision"])
 def test_w2_idefics2_8b_widths_truncated_depth_vs_oracle(fp8):
     from licv.idefics2_engine import Idefics2Engine, Idefics2Weights
-    torch.set_num_threads(max(torch.get_num_threads(), 8))
+    torch.set_num_threads(max(torch.get_num_threads(), 8))      # (conftest.py caps the default at twice the cgroup quota)
     arch = IDEFICS2_8B.with_(v_layers=2, r_depth=2, num_layers=2)
     sd = trained_like_(synth_idefics2_weights(arch, seed=911, dtype=torch.float32, device=DEV), 2)
     fp8_vis = fp8 == "all"
@@ -223,7 +223,7 @@ def test_w3_configs0_idefics9b_full_depth_one_shot_through_icv_module():
     """BASELINE.json configs[0]: "Idefics-9B 1-shot VQAv2, bs=1, CPU reference forward via icv_module (plumbing)"."""
     from icv_src.icv_module import VQAICVModule
     from lmm_icl_interface import IdeficsInterface
-    torch.set_num_threads(max(torch.get_num_threads(), 8))
+    torch.set_num_threads(max(torch.get_num_threads(), 8))      # (conftest.py caps the default at twice the cgroup quota)
     arch = IDEFICS_9B
     t0 = time.perf_counter()
     sd = trained_like_(synth_idefics_weights(arch, seed=426, dtype=torch.bfloat16, device=DEV), arch.num_layers)
@@ -287,7 +287,7 @@ def test_w4_configs1_idefics9b_full_depth_32shot_question_vs_oracle():
     headline batch of 8 are bit for bit those of the question alone — so the bench configuration itself sits on the oracle."""
     from licv import ops
     from licv.idefics_engine import IdeficsEngine, IdeficsWeights
-    torch.set_num_threads(max(torch.get_num_threads(), 8))
+    torch.set_num_threads(max(torch.get_num_threads(), 8))      # (conftest.py caps the default at twice the cgroup quota)
     arch = IDEFICS_9B
     t0 = time.perf_counter()
     sd = trained_like_(synth_idefics_weights(arch, seed=426, dtype=torch.bfloat16, device=DEV), arch.num_layers)

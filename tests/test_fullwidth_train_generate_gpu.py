@@ -105,7 +105,7 @@ def test_w5_idefics9b_widths_gradients_vs_oracle_autograd():
     from licv import ops
     from licv.trainer import ICVTrainer
     from lmm_icl_interface import IdeficsInterface
-    torch.set_num_threads(max(torch.get_num_threads(), 8))
+    torch.set_num_threads(max(torch.get_num_threads(), 8))      # (conftest.py caps the default at twice the cgroup quota)
     nl = 4
     arch = IDEFICS_9B.with_(v_layers=2, r_depth=2, num_layers=nl)
     assert arch.num_cross_layers == 1
@@ -167,7 +167,7 @@ def test_w5_idefics2_8b_widths_gradients_vs_oracle_autograd():
     from licv import ops
     from licv.trainer import ICVTrainer
     from lmm_icl_interface import Idefics2Interface
-    torch.set_num_threads(max(torch.get_num_threads(), 8))
+    torch.set_num_threads(max(torch.get_num_threads(), 8))      # (conftest.py caps the default at twice the cgroup quota)
     nl = 4
     arch = IDEFICS2_8B.with_(v_layers=2, r_depth=2, num_layers=nl)
     sd = trained_like_(synth_idefics2_weights(arch, seed=961, dtype=torch.float32, device=DEV), nl)
@@ -292,7 +292,7 @@ def _same_row(a, b, q):
 def test_w6_idefics9b_widths_hooked_beam_generate_vs_oracle(nl, side):
     from licv import generation as NG
     from licv.idefics_engine import IdeficsEngine, IdeficsWeights
-    torch.set_num_threads(max(torch.get_num_threads(), 8))
+    torch.set_num_threads(max(torch.get_num_threads(), 8))      # (conftest.py caps the default at twice the cgroup quota)
     arch = IDEFICS_9B.with_(v_layers=1, r_depth=1, num_layers=nl)
     sd = trained_like_(synth_idefics_weights(arch, seed=971 + nl, dtype=torch.bfloat16, device=DEV), nl)
     # a peaked next-token distribution: log-normal head-row norms (module docstring)
