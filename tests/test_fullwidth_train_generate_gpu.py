@@ -5,8 +5,8 @@ kernels):
   W5  the training signal — d loss / d icv and d loss / d alpha of ref:icv_src/icv_module.py:97-118 (hooked student forward with
       grad, unhooked teacher, masked KL) through ICVTrainer.loss_and_backward (explicit HIP backward, csrc/backward.hip + the
       transposed-weight dgrad GEMMs) against torch autograd through the CPU oracle in bf16 AND fp32.  Idefics-9B widths (H 4096,
-      I 11008, V 32002, 32 x 128 heads; 2 ViT layers, 2 perceiver blocks, 1 gated cross-attention layer, 4 decoder layers), B = 8,
-      student S = 32; and Idefics2-8B widths (Mistral 32q / 8kv x 128, I 14336, V 32003, hook on the `.mlp` branch; 4 text layers).
+      I 11008, V 32002, 32 x 128 heads; 2 ViT layers, 2 perceiver blocks, 1 gated cross-attention layer, 4 decoder layers - and the
+      WHOLE model: 32 ViT layers, 6 perceiver blocks, 8 + 32 layers, gradients on all 32 hooks), B = 8, student S = 32; and Idefics2-8B widths (Mistral 32q / 8kv x 128, I 14336, V 32003, hook on the `.mlp` branch; 4 text layers).
   W6  hooked generate — ref:inference.py:300-321 with ref:config/inference.yaml:26-30 (3 beams, 5 new tokens, length_penalty 0)
       at Idefics-9B widths truncated to 4 and to 8 decoder layers and at FULL depth (the whole model: 32 ViT layers, 6 perceiver
       blocks, 32 decoder + 8 gated cross-attention layers), B = 8, against oracle/generate_ref.py: token ids, and the logits of
@@ -102,15 +102,18 @@ def _share_answers(stu, tea, pad, ans=4):
 
 
 # =========================================================================================================== W5
-def test_w5_idefics9b_widths_gradients_vs_oracle_autograd():
+@pytest.mark.parametrize("nl", [4, IDEFICS_9B.num_layers], ids=["4_layers", "full_depth"])
+def test_w5_idefics9b_widths_gradients_vs_oracle_autograd(nl):
     from icv_src.icv_module import VQAICVModule
     from licv import ops
     from licv.trainer import ICVTrainer
     from lmm_icl_interface import IdeficsInterface
     torch.set_num_threads(max(torch.get_num_threads(), 8))      # (conftest.py caps the default at twice the cgroup quota)
-    nl = 4
-    arch = IDEFICS_9B.with_(v_layers=2, r_depth=2, num_layers=nl)
-    assert arch.num_cross_layers == 1
+    # full depth: the whole Idefics-9B (32 ViT layers, 6 perceiver blocks, 32 decoder + 8 gated cross-attention layers), hooks and
+    # gradients on all 32 layers - the model ref:icv_src/icv_module.py trains against
+    full = nl == IDEFICS_9B.num_layers
+    arch = IDEFICS_9B if full else IDEFICS_9B.with_(v_layers=2, r_depth=2, num_layers=nl)
+    assert full or arch.num_cross_layers == 1
     sd = trained_like_(synth_idefics_weights(arch, seed=951, dtype=torch.float32, device=DEV), nl)
     iface = IdeficsInterface(state_dict=sd, arch=arch, device=DEV)
     lmm_cfg = dict(intervention_layer=-1, layer_format="model.model.layers.<LAYER_NUM>", total_layers=nl, hidden_size=arch.hidden_size)
@@ -157,8 +160,8 @@ def test_w5_idefics9b_widths_gradients_vs_oracle_autograd():
     assert abs(got["kl"] - gold["f32"]["kl"]) <= 1.5 * abs(gold["bf16"]["kl"] - gold["f32"]["kl"]) + 0.05 * abs(gold["f32"]["kl"]) + 1e-3
     rep = []
     try:
-        _wbar(got["icv"], gold["bf16"]["icv"], gold["f32"]["icv"], "d loss / d icv (4 x 4096)", rep)
-        _wbar(got["alpha"], gold["bf16"]["alpha"], gold["f32"]["alpha"], "d loss / d alpha (4)", rep,
+        _wbar(got["icv"], gold["bf16"]["icv"], gold["f32"]["icv"], f"d loss / d icv ({nl} x 4096)", rep)
+        _wbar(got["alpha"], gold["bf16"]["alpha"], gold["f32"]["alpha"], f"d loss / d alpha ({nl})", rep,
               rel_floor=_rel_spread(gold["bf16"]["icv"], gold["f32"]["icv"]))
     finally:
         print("  W5 " + "\n  W5 ".join(rep))
