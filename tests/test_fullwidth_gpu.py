@@ -219,6 +219,55 @@ def test_w2_idefics2_8b_widths_truncated_depth_vs_oracle(fp8):
     print("\n  W2 " + "\n  W2 ".join(rep))
 
 
+def test_w7_configs3_idefics2_8b_full_depth_one_shot_vs_oracle():
+    """BASELINE.json configs[3] pinned to the oracle: Idefics2-8B at FULL depth (27 SigLIP layers on NaViT images, the perceiver
+    connector, 32 Mistral layers with GQA), two 1-shot questions (two ragged 378 x 504 images each, S = 384, right padded), hooks on the
+    `.mlp` branch of all 32 layers — the HIP engine against the CPU oracle in bf16 (under autocast, the reference's regime for this
+    model) and in fp32, same three-part bar as W1 - W4; then argmax agreement wherever the oracle's own top-2 margin exceeds its
+    bf16-vs-fp32 spread."""
+    from licv.idefics2_engine import Idefics2Engine, Idefics2Weights
+    torch.set_num_threads(max(torch.get_num_threads(), 8))      # (conftest.py caps the default at twice the cgroup quota)
+    arch = IDEFICS2_8B
+    t0 = time.perf_counter()
+    sd = trained_like_(synth_idefics2_weights(arch, seed=921, dtype=torch.float32, device=DEV), arch.num_layers)
+    eng = Idefics2Engine(Idefics2Weights(sd, arch, DEV))
+    batch = synth_vqa_batch_idefics2(arch, 2, 384, 2, 378, 504, seed=922, min_len=300, dtype=torch.float32, ragged=True)
+    layers = list(range(arch.num_layers))
+    icv = torch.randn(1, arch.num_layers, arch.hidden_size, generator=torch.Generator().manual_seed(923)) * 0.05
+    t1 = time.perf_counter()
+    lg = eng.forward(**{k: v.to(DEV) for k, v in batch.items()}, icv=icv.to(DEV), hook_layers=layers)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    sdc = _cpu(sd, torch.float32)
+    del sd, eng
+    torch.cuda.empty_cache()
+    gold, tm = {}, {}
+    for name, dt in (("bf16", torch.bfloat16), ("f32", torch.float32)):
+        s = sdc if dt == torch.float32 else {k: v.to(dt) for k, v in sdc.items()}
+        kw = dict(batch)
+        kw["pixel_values"] = batch["pixel_values"].to(dt)
+        ta = time.perf_counter()
+        with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16, enabled=(dt == torch.bfloat16)):
+            gold[name] = R2.forward(s, arch, **kw, icv=icv, hook_layers=layers).float()
+        tm[name] = time.perf_counter() - ta
+        del s
+    print(f"\n  W7 weights {t1 - t0:.1f}s, native forward (cold) {t2 - t1:.2f}s, CPU oracle ({torch.get_num_threads()} threads): "
+          f"bf16 {tm['bf16']:.1f}s, fp32 {tm['f32']:.1f}s")
+    rep = []
+    valid = batch["attention_mask"].bool()
+    try:
+        _check(lg.float().cpu()[valid], gold["bf16"][valid], gold["f32"][valid], "logits, full depth, two 1-shot questions (real positions)", rep)
+    finally:
+        print("  W7 " + "\n  W7 ".join(rep))
+    g16 = gold["bf16"]
+    top2 = g16.topk(2, dim=-1).values
+    spread = float((g16 - gold["f32"])[valid].abs().max())
+    sure = ((top2[..., 0] - top2[..., 1]) > 2 * spread) & valid
+    if int(sure.sum()) > 0:
+        assert torch.equal(lg.float().cpu().argmax(-1)[sure], g16.argmax(-1)[sure])
+    print(f"  W7 positions whose argmax is decided by more than the reference's own bf16 noise: {int(sure.sum())} of {int(valid.sum())}")
+
+
 def test_w3_configs0_idefics9b_full_depth_one_shot_through_icv_module():
     """BASELINE.json configs[0]: "Idefics-9B 1-shot VQAv2, bs=1, CPU reference forward via icv_module (plumbing)"."""
     from icv_src.icv_module import VQAICVModule
