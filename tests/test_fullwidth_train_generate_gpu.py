@@ -167,14 +167,15 @@ def test_w5_idefics9b_widths_gradients_vs_oracle_autograd(nl):
         print("  W5 " + "\n  W5 ".join(rep))
 
 
-def test_w5_idefics2_8b_widths_gradients_vs_oracle_autograd():
+@pytest.mark.parametrize("nl", [4, IDEFICS2_8B.num_layers], ids=["4_layers", "full_depth"])
+def test_w5_idefics2_8b_widths_gradients_vs_oracle_autograd(nl):
     from icv_src.icv_module import VQAICVModule
     from licv import ops
     from licv.trainer import ICVTrainer
     from lmm_icl_interface import Idefics2Interface
     torch.set_num_threads(max(torch.get_num_threads(), 8))      # (conftest.py caps the default at twice the cgroup quota)
-    nl = 4
-    arch = IDEFICS2_8B.with_(v_layers=2, r_depth=2, num_layers=nl)
+    # full depth: the whole Idefics2-8B (27 SigLIP layers, the connector, 32 Mistral layers), gradients on all 32 hooked `.mlp` branches
+    arch = IDEFICS2_8B if nl == IDEFICS2_8B.num_layers else IDEFICS2_8B.with_(v_layers=2, r_depth=2, num_layers=nl)
     sd = trained_like_(synth_idefics2_weights(arch, seed=961, dtype=torch.float32, device=DEV), nl)
     iface = Idefics2Interface(state_dict=sd, arch=arch, device=DEV)
     lmm_cfg = dict(intervention_layer=-1, layer_format="model.model.text_model.layers.<LAYER_NUM>.mlp", total_layers=nl,
@@ -217,8 +218,8 @@ def test_w5_idefics2_8b_widths_gradients_vs_oracle_autograd():
     assert abs(got["kl"] - gold["f32"]["kl"]) <= 1.5 * abs(gold["bf16"]["kl"] - gold["f32"]["kl"]) + 0.05 * abs(gold["f32"]["kl"]) + 1e-3
     rep = []
     try:
-        _wbar(got["icv"], gold["bf16"]["icv"], gold["f32"]["icv"], "idefics2 d loss / d icv (4 x 4096)", rep)
-        _wbar(got["alpha"], gold["bf16"]["alpha"], gold["f32"]["alpha"], "idefics2 d loss / d alpha (4)", rep,
+        _wbar(got["icv"], gold["bf16"]["icv"], gold["f32"]["icv"], f"idefics2 d loss / d icv ({nl} x 4096)", rep)
+        _wbar(got["alpha"], gold["bf16"]["alpha"], gold["f32"]["alpha"], f"idefics2 d loss / d alpha ({nl})", rep,
               rel_floor=_rel_spread(gold["bf16"]["icv"], gold["f32"]["icv"]))
     finally:
         print("  W5 " + "\n  W5 ".join(rep))
