@@ -246,6 +246,8 @@ class _Recorder:
         lg = self.inner.prefill(ids, am)
         if isinstance(getattr(self.inner, "cache", None), list):
             self.cache0 = list(self.inner.cache)            # (the oracle's KV cache right after the prefill: entries are replaced, never written in place)
+        elif hasattr(self.inner, "prompt_len"):             # the cache-less Idefics2 oracle model: its prefix (replaced by torch.cat, never written in place)
+            self.state0 = (self.inner.ids, self.inner.pos, self.inner.prompt_len)
         self.clean0 = lg.float().cpu()
         return self._out(lg)
 
@@ -265,10 +267,13 @@ class _Replay:
     """The oracle model behind a recorded prefill: prefill() hands back the recorded logits and the KV cache that prefill left."""
 
     def __init__(self, base):
-        self.inner, self.lg, self.c0 = base.inner, base.clean0, base.cache0
+        self.inner, self.lg, self.c0, self.s0 = base.inner, base.clean0, getattr(base, "cache0", None), getattr(base, "state0", None)
 
     def prefill(self, ids, am):
-        self.inner.cache = list(self.c0)
+        if self.c0 is not None:
+            self.inner.cache = list(self.c0)
+        else:
+            self.inner.ids, self.inner.pos, self.inner.prompt_len = self.s0
         return self.lg.clone()
 
     def step(self, new_ids, am):
@@ -279,9 +284,17 @@ class _Replay:
 
 
 def _oracle_decode(sd, arch, batch, hooks, nb, noise=None, seed=0, replay=None):
-    m = _Replay(replay) if replay is not None else G._IdeficsModel(sd, arch, batch["pixel_values"], batch["image_attention_mask"], nb, hooks)
+    i2 = "pixel_attention_mask" in batch
+    if replay is not None:
+        m = _Replay(replay)
+    elif i2:
+        m = G._Idefics2Model(sd, arch, batch["pixel_values"], batch["pixel_attention_mask"], nb, hooks)
+    else:
+        m = G._IdeficsModel(sd, arch, batch["pixel_values"], batch["image_attention_mask"], nb, hooks)
     rec = _Recorder(m, noise, torch.Generator().manual_seed(seed))
-    with torch.no_grad():
+    # (Idefics2 in bf16 runs under autocast - the reference's regime for that model, as fixtures g4 / g8 / g12 and W2 / W7 do)
+    bf16_i2 = i2 and next(iter(sd.values())).dtype == torch.bfloat16
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16, enabled=bf16_i2):
         ids = G._decode(rec, arch, batch["input_ids"], batch["attention_mask"], max_new_tokens=5, num_beams=nb, length_penalty=0.0,
                         min_new_tokens=0)
     return ids, rec
@@ -364,6 +377,8 @@ def test_w6_idefics9b_widths_hooked_beam_generate_vs_oracle(nl, side):
     n_calls = min(len(nrec.logits), len(r16.logits), len(r32.logits))
     try:
         _wbar(nrec.logits[0], pre16, pre32, "prefill logits (last prompt position, 32002 wide)", rep)
+        # a late step compares as few as 3 beam rows: the oracle's noise level there is taken as at least the one its 8 prefill rows show
+        floor = _rel_spread(pre16, pre32)
         for t in range(1, n_calls):
             for q in range(B):
                 sl = slice(q * nb, (q + 1) * nb)
@@ -380,7 +395,81 @@ def test_w6_idefics9b_widths_hooked_beam_generate_vs_oracle(nl, side):
             #  the two maxima scatters around that - measured 0.8 ... 1.54.  Parts (ii) and (iii), against fp32, stay as they are.)
             _wbar(nrec.logits[t][rows], r16.logits[t][rows], r32.logits[t][rows],
                   f"decode step {t} logits ({int(in_sync.sum())} questions in the same search state, {int(rows.sum())} beam rows)", rep,
-                  pair=2.0 if nl == IDEFICS_9B.num_layers else 1.5)
+                  pair=2.0 if nl == IDEFICS_9B.num_layers else 1.5, rel_floor=floor)
     finally:
         print("  W6 " + "\n  W6 ".join(rep))
     assert len(rep) >= 2, "no decode step could be compared"            # (prefill + at least one step in the same search state)
+
+
+def test_w6_idefics2_8b_widths_hooked_beam_generate_vs_oracle():
+    """The same for Idefics2-8B widths (Mistral 32q / 8kv x 128 through the GQA decode-attention launch and the cache-row table, I 14336,
+    the 32003-wide head, hook on the `.mlp` branch; 2 SigLIP layers, 2 connector blocks, 4 text layers), B = 8, one ragged image per
+    prompt, 3 beams x 5 tokens, left-padded like ref:inference.py's processor: ids against oracle/generate_ref.py (rows decided by more
+    than twice the oracle's noise must be identical), logits of the prefill and of every decode step in the same search state."""
+    from licv import generation as NG
+    from licv.idefics2_engine import Idefics2Engine, Idefics2Weights
+    torch.set_num_threads(max(torch.get_num_threads(), 8))      # (conftest.py caps the default at twice the cgroup quota)
+    nl = 4
+    arch = IDEFICS2_8B.with_(v_layers=2, r_depth=2, num_layers=nl)
+    sd = trained_like_(synth_idefics2_weights(arch, seed=981, dtype=torch.bfloat16, device=DEV), nl)
+    row_scale = torch.exp(torch.randn(arch.vocab_size, generator=torch.Generator().manual_seed(984)))
+    sd["lm_head.weight"] = (sd["lm_head.weight"].float() * row_scale.to(DEV)[:, None]).to(torch.bfloat16)
+    eng = Idefics2Engine(Idefics2Weights(sd, arch, DEV))
+    B, nb, S = 8, 3, 96
+    batch = synth_vqa_batch_idefics2(arch, B, S, 1, 98, 126, seed=982, min_len=88, dtype=torch.bfloat16, ragged=True, padding_side="left")
+    layers = list(range(nl))
+    icv = torch.randn(1, nl, arch.hidden_size, generator=torch.Generator().manual_seed(983)) * 0.05
+    hooks = dict(icv=icv, hook_layers=layers)
+    dev_batch = {k: v.to(DEV) for k, v in batch.items()}
+    model = NG._Idefics2Decoder(eng, dev_batch["pixel_values"], dev_batch["pixel_attention_mask"], B, S + 5, dict(icv=icv.to(DEV), hook_layers=layers),
+                                beams=nb)
+    nrec = _Recorder(model)
+    with torch.no_grad():
+        got = NG._decode(nrec, arch, dev_batch["input_ids"], dev_batch["attention_mask"], max_new_tokens=5, num_beams=nb, length_penalty=0.0,
+                         min_new_tokens=0).cpu()
+    plain = NG.generate_idefics2(eng, **dev_batch, icv=icv.to(DEV), hook_layers=layers, max_new_tokens=5, num_beams=nb, length_penalty=0.0).cpu()
+    assert torch.equal(got, plain), "the recorded search differs from licv.generation.generate_idefics2"
+    s16 = _cpu(sd, torch.bfloat16)
+    t0 = time.perf_counter()
+    ids16, r16 = _oracle_decode(s16, arch, batch, hooks, nb)
+    t_oracle = time.perf_counter() - t0
+    s32 = {k: v.float() for k, v in s16.items()}
+    b32 = {k: (v.float() if v.is_floating_point() else v) for k, v in batch.items()}
+    ids32, r32 = _oracle_decode(s32, arch, b32, hooks, nb)
+    del s32
+    pre16, pre32 = r16.logits[0][::nb], r32.logits[0][::nb]
+    wn = s16["lm_head.weight"].float().norm(dim=1)
+    envelope = ((pre16 - pre32) / wn[None]).pow(2).mean(dim=1, keepdim=True).sqrt() * wn[None] * 3 ** 0.5
+    decided = torch.tensor([_same_row(ids16, ids32, q) for q in range(B)])
+    for j in range(N_JITTER):
+        idsj, _ = _oracle_decode(s16, arch, batch, hooks, nb, noise=envelope * JITTER_SCALE, seed=990 + j, replay=r16)
+        decided &= torch.tensor([_same_row(ids16, idsj, q) for q in range(B)])
+    same = torch.tensor([_same_row(got, ids16, q) for q in range(B)])
+    same32 = torch.tensor([_same_row(got, ids32, q) for q in range(B)])
+    print(f"\n  W6 idefics2 {nl} layers, left-padded prompts, B = {B}, {nb} beams x 5 tokens: CPU oracle bf16 {t_oracle:.1f}s; rows identical to the "
+          f"bf16 oracle {int(same.sum())}/{B}, to the fp32 oracle {int(same32.sum())}/{B}; decided by more than {JITTER_SCALE:g} x the oracle's own "
+          f"noise {int(decided.sum())}/{B}; bf16 and fp32 oracles agree on {sum(_same_row(ids16, ids32, q) for q in range(B))}/{B}")
+    assert int(decided.sum()) > 0, "no row of this batch is decided by more than twice the oracle's own bf16 noise: the id check would be vacuous"
+    assert bool(same[decided].all()), f"rows decided by more than bf16 noise differ: {(~same & decided).nonzero().flatten().tolist()}"
+    rep = []
+    in_sync = torch.ones(B, dtype=torch.bool)
+    n_calls = min(len(nrec.logits), len(r16.logits), len(r32.logits))
+    try:
+        _wbar(nrec.logits[0], pre16, pre32, "idefics2 prefill logits (last prompt position, 32003 wide)", rep)
+        floor = _rel_spread(pre16, pre32)                # (as above: a late step's few rows under-sample the oracle's own noise)
+        for t in range(1, n_calls):
+            for q in range(B):
+                sl = slice(q * nb, (q + 1) * nb)
+                if in_sync[q]:
+                    ok = all(torch.equal(a.fed[t - 1][sl], nrec.fed[t - 1][sl]) for a in (r16, r32))
+                    ok = ok and all(len(a.order) >= t and torch.equal(a.order[t - 1][sl], nrec.order[t - 1][sl]) for a in (r16, r32))
+                    in_sync[q] = ok
+            if not bool(in_sync.any()):
+                break
+            rows = in_sync.repeat_interleave(nb)
+            _wbar(nrec.logits[t][rows], r16.logits[t][rows], r32.logits[t][rows],
+                  f"idefics2 decode step {t} logits ({int(in_sync.sum())} questions in the same search state, {int(rows.sum())} beam rows)", rep,
+                  rel_floor=floor)
+    finally:
+        print("  W6 " + "\n  W6 ".join(rep))
+    assert len(rep) >= 2, "no decode step could be compared"
