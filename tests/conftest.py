@@ -18,12 +18,20 @@ def _oracle_threads():
     """Threads for the CPU oracle: torch's default is one per HOST core (128 on the GPU boxes) while the job's cgroup grants 16 CPUs -
     measured there on a 800 x 4096 x 11008 linear: 128 threads 166 ms fp32 / 34 ms bf16, 32 threads 47 / 7.5 ms, 16 threads 55 / 11 ms.
     Twice the quota, never more than the affinity mask; None where no quota is set (torch's default stands)."""
-    try:
+    n = None
+    try:                                                    # cgroup v2
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota == "max":
-            return None
-        n = max(1, int(int(quota) / int(period)))
+        if quota != "max":
+            n = max(1, int(int(quota) / int(period)))
     except (OSError, ValueError):
+        try:                                                # cgroup v1
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0 and period > 0:
+                n = max(1, quota // period)
+        except (OSError, ValueError):
+            pass
+    if n is None:
         return None
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     return max(1, min(avail, 2 * n))
