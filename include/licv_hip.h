@@ -186,7 +186,8 @@ int licv_gemm_fp8(const void* Aq, int64_t lda, const float* a_scale, const void*
  * 128 x 128 kernel for everything smaller (M <= 32 with long K: licv_gemm_splitk).  1 = always the 128 x 128 kernel; 2 the round-1
  * single-barrier 256 x 256 kernel; 6 the round-1 ping-pong kernel; 8 persistent ping-pong; 20 flow wherever eligible; 21 pair kernel
  * (two K stages per phase); 22 lean ping-pong everywhere (23-27: its ordering / diagnostic builds); 30-37 four-wave kernel and its
- * timing builds; 40-42 four-wave kernel on 64-deep K tiles; 50 two workgroups per CU on 128 x 256 tiles.  All full-result variants are
+ * timing builds; 40-42 four-wave kernel on 64-deep K tiles; 50 two workgroups per CU on 128 x 256 tiles; 60 the four-wave flow64 kernel
+ * wherever eligible; 70 the 128-tile mid kernel at any M; 71 the 256 x 128 tall kernel wherever it can run (129-256 rows).  All full-result variants are
  * bit-identical (tests/test_ops_gpu.py).  Values that name a kernel of the lab library (2-8, 10-13, 21, 30-37, 50: csrc/lab/, built
  * into liblicv_hip_lab.so for tests and tools only) make licv_gemm_bf16 return LICV_E_UNSUPPORTED unless that library is loaded. */
 int licv_gemm_select(int which);
@@ -194,7 +195,11 @@ int licv_gemm_select(int which);
 int licv_lab_register(void* launch, void* knob, void* timestamps);
 /* Knobs: 0 per-XCD start stagger of the round-1 ping-pong kernel in percent (off); 1 tile-rows per XCD patch (0 = heuristic);
  * 2 = 0: never take the flow kernel in auto mode; 4 = 0: licv_gemm_splitk_plan always answers "one pass" (split-K off for every
- * caller, the native layer runner included: the batch-independence tests compare bit for bit). */
+ * caller, the native layer runner included: the batch-independence tests compare bit for bit); 5 forced split-K count of the 128-tile
+ * route (0 = the plan's choice); 6 fewest 256-tiles for the 256-tile kernels; 7 in-launch reduction of the skinny kernel; 8 = 0: fp8 GEMMs off the
+ * 128-deep MFMA; 9 timing-only ablation of the mid kernel (wrong results); 10 = 4: four K tiles in flight in the mid kernel; 11 non-temporal
+ * weight loads (bit 0 mid, bit 1 skinny); 12 = 0: wide outputs at 129-256 rows stay on the mid kernel instead of the tall kernel.  A/B timing
+ * and tests only: every setting gives the same results except knob 9. */
 int licv_gemm_experiment(int knob, int value);
 /* 1 if the flow kernel may be dispatched (its code objects use no scratch memory: its counted waits rely on that), else 0 */
 int licv_gemm_flow_available(void);

@@ -1659,7 +1659,7 @@ void gemm_bf16_mid_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __
 #define TALL_UNIT 16384
 #define TALL_KT (3 * TALL_UNIT)
 #define TALL_LDS (3 * TALL_KT)
-#define TALL_TK 0.55       // us per K tile of a lone workgroup (the split-K plan's constant; tools/tall_bench.py)
+#define TALL_TK 0.78       // us per K tile of a lone workgroup (the split-K plan's constant: 256 x 12288 x 4096 one pass 54.3 us, two splits 45.4; 22016: 59.9 / 84.7 - tools/tall_bench.py)
 template <int SPLITK>
 __global__ __launch_bounds__(512)
 void gemm_bf16_tall_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw,
