@@ -268,6 +268,49 @@ def test_w7_configs3_idefics2_8b_full_depth_one_shot_vs_oracle():
     print(f"  W7 positions whose argmax is decided by more than the reference's own bf16 noise: {int(sure.sum())} of {int(valid.sum())}")
 
 
+def test_w8_configs4_idefics2_8b_fp8_full_depth_vs_fp8_oracle():
+    """BASELINE.json configs[4] ("fp8 weights") at FULL depth: Idefics2-8B, 27 SigLIP + 32 Mistral layers, every text projection on e4m3
+    operands (per-row / per-channel amax / 448 scales), two 1-shot questions of 384 tokens (768 rows: above the engine's 512-row bar for
+    the fp8 path), hooks on all 32 `.mlp` branches.  No reference fp8 mode exists: the oracle restates the build's fp8 arithmetic
+    (oracle/idefics2_ref.py fp8_linear) and W2 pins every projection to it on identical inputs within one bf16 ulp.  Through 32
+    layers two runs whose inputs differ by bf16 noise decorrelate (e4m3 rounding is a step function), so the whole-model statement is
+    about the SIZE of the quantisation noise: the engine's logits are no further from the plain bf16 oracle than the fp8 oracle's own
+    logits are (x 1.25), and no further from the fp8 oracle than that same distance (two independent draws of the same noise:
+    sqrt(2) x it, bar 1.6 x)."""
+    from licv.idefics2_engine import Idefics2Engine, Idefics2Weights
+    torch.set_num_threads(max(torch.get_num_threads(), 8))      # (conftest.py caps the default at twice the cgroup quota)
+    arch = IDEFICS2_8B
+    sd = trained_like_(synth_idefics2_weights(arch, seed=931, dtype=torch.float32, device=DEV), arch.num_layers)
+    eng = Idefics2Engine(Idefics2Weights(sd, arch, DEV, fp8_text=True))
+    assert all(set(L.q8) == {"qkv_w", "o_w", "gu_w", "down_w"} for L in eng.w.text)
+    batch = synth_vqa_batch_idefics2(arch, 2, 384, 2, 378, 504, seed=932, min_len=300, dtype=torch.float32, ragged=True)
+    layers = list(range(arch.num_layers))
+    icv = torch.randn(1, arch.num_layers, arch.hidden_size, generator=torch.Generator().manual_seed(933)) * 0.05
+    lg = eng.forward(**{k: v.to(DEV) for k, v in batch.items()}, icv=icv.to(DEV), hook_layers=layers).float().cpu()
+    s = _cpu(sd, torch.bfloat16)
+    del sd, eng
+    torch.cuda.empty_cache()
+    kw = dict(batch)
+    kw["pixel_values"] = batch["pixel_values"].to(torch.bfloat16)
+    t0 = time.perf_counter()
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+        g16 = R2.forward(s, arch, **kw, icv=icv, hook_layers=layers).float()
+        t1 = time.perf_counter()
+        g8 = R2.forward(s, arch, **kw, icv=icv, hook_layers=layers, fp8_text=True).float()
+    t2 = time.perf_counter()
+    valid = batch["attention_mask"].bool()
+    rel = lambda a, b: float((a - b)[valid].norm() / b[valid].norm())
+    noise, hip_vs_bf16, hip_vs_fp8 = rel(g8, g16), rel(lg, g16), rel(lg, g8)
+    cos = torch.nn.functional.cosine_similarity(lg[valid], g16[valid], dim=-1)
+    cos8 = torch.nn.functional.cosine_similarity(g8[valid], g16[valid], dim=-1)
+    print(f"\n  W8 CPU oracle bf16 {t1 - t0:.1f}s, fp8 {t2 - t1:.1f}s; relative L2 of the logits (real positions): fp8 oracle vs bf16 oracle "
+          f"{noise:.3f} (the quantisation noise itself), engine vs bf16 oracle {hip_vs_bf16:.3f}, engine vs fp8 oracle {hip_vs_fp8:.3f}; "
+          f"min cosine vs the bf16 oracle: engine {float(cos.min()):.4f}, fp8 oracle {float(cos8.min()):.4f}")
+    assert hip_vs_bf16 <= 1.25 * noise + 1e-3, f"the engine's fp8 logits are {hip_vs_bf16:.3f} from the bf16 oracle; the fp8 oracle's own are {noise:.3f}"
+    assert hip_vs_fp8 <= 1.6 * noise + 1e-3, f"engine vs fp8 oracle {hip_vs_fp8:.3f} against the quantisation noise {noise:.3f}"
+    assert float(cos.min()) >= float(cos8.min()) - 0.02
+
+
 def test_w3_configs0_idefics9b_full_depth_one_shot_through_icv_module():
     """BASELINE.json configs[0]: "Idefics-9B 1-shot VQAv2, bs=1, CPU reference forward via icv_module (plumbing)"."""
     from icv_src.icv_module import VQAICVModule
