@@ -23,7 +23,7 @@ extern "C" {
 /* Bumped whenever an entry point is added, removed or changes its arguments; licv/_lib.py holds the same constant and refuses a
  * library that answers anything else.  1 = round 1; 2 = rounds 2-3 (fp8, split-K slices, runner, front-end, backward, image input);
  * 3 = round 4 (lab library split off; weight-streaming GEMM; beam scoring; decode-step fusion). */
-#define LICV_ABI_VERSION 3
+#define LICV_ABI_VERSION 4
 
 enum { LICV_BF16 = 0, LICV_F32 = 1 };
 enum { LICV_OK = 0, LICV_E_BADARG = -1, LICV_E_UNSUPPORTED = -2, LICV_E_HIP = -3 };
@@ -273,6 +273,10 @@ int licv_branch_grad(const float* dh, void* out_bf16, int64_t rows, int64_t dim,
  * dK/dV are written per QUERY head (n_heads*head_dim columns): with GQA reduce them with licv_head_group_sum */
 int licv_attn_bwd_small(const licv_attn_args* a, const void* dout_bf16, void* dq_bf16, int64_t dq_bs, int64_t dq_rs,
                         void* dk_bf16, void* dv_bf16, int64_t dkv_bs, int64_t dkv_rs, void* stream);
+/* A/B timing and tests of the backward kernels (results are bit-identical either way).  option 0 = 0: licv_attn_bwd_small keeps the
+ * head's Q / K / V / dO rows in global memory (default 1: staged in LDS where they fit beside P and dS); option 1 = 0: licv_rmsnorm_bwd
+ * on one wave per row at every row length (default 1: four waves per row from 1024 elements on). */
+int licv_backward_option(int option, int value);
 /* cross-entropy rows (the "hard" loss, ref:icv_src/icv_module.py:94-95,111-117; HF ForCausalLMLoss upcasts to fp32):
  * loss_rows[i] = logsumexp(logits[rows[i], :]) - logits[rows[i], labels[i]]  (may be NULL);
  * grad[(grad_rows ? grad_rows[i] : i), :] (+)= grad_coef * (softmax - onehot), bf16 (may be NULL). */

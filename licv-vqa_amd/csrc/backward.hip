@@ -8,6 +8,9 @@
 
 #define BW_WAVES 4
 
+static int g_attn_bwd_staged = 1;      // licv_backward_option 0
+static int g_rmsnorm_bwd_wide = 1;     // licv_backward_option 1
+
 __device__ __forceinline__ floatx4 ld4(const void* p, int dt, int64_t i) {
     if (dt == LICV_F32) return *reinterpret_cast<const floatx4*>(reinterpret_cast<const float*>(p) + i);
     const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(p) + i);
@@ -43,10 +46,75 @@ void rmsnorm_bwd_k(const void* __restrict__ x, int x_dt, const bf16_t* __restric
     const int64_t ro = row / inner, ri = row % inner;
     const int64_t xb = ro * ld_x + ri * dim, yb = ro * ld_dy + ri * dim, db = ro * ld_dx + ri * dim;
     floatx4 xv[NCH], gv[NCH];
-    float ss = 0.f;
+    // The two row statistics are formed in NG = 4 groups of NCH / 4 consecutive chunks (one group where NCH < 4), each summed over the
+    // wave, then added in group order: the order rmsnorm_bwd_wide_k (one wave per group) produces, so the two kernels agree bit for bit.
+    constexpr int NG = NCH >= 4 ? 4 : 1, PG = NCH / NG;
+    float sg[NG];
+#pragma unroll
+    for (int q = 0; q < NG; ++q) sg[q] = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int i = (c * 64 + lane) * 4;
+        if (i < dim) {
+            xv[c] = ld4(x, x_dt, xb + i);
+            const floatx4 d = ld4(dy, dy_dt, yb + i);
+            const floatx4 wv = ld4(w, LICV_BF16, i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { sg[c / PG] += xv[c][j] * xv[c][j]; const float gw = d[j] * wv[j]; gv[c][j] = round_g ? rbf(gw) : gw; }
+        }
+    }
+    float ss = wave_sum(sg[0]);
+#pragma unroll
+    for (int q = 1; q < NG; ++q) ss += wave_sum(sg[q]);
+    const float rs = rsqrtf(ss / (float)dim + eps);
+#pragma unroll
+    for (int q = 0; q < NG; ++q) sg[q] = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int i = (c * 64 + lane) * 4;
+        if (i < dim) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sg[c / PG] += gv[c][j] * xv[c][j] * rs;
+        }
+    }
+    float dot = wave_sum(sg[0]);
+#pragma unroll
+    for (int q = 1; q < NG; ++q) dot += wave_sum(sg[q]);
+    dot = dot / (float)dim;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int i = (c * 64 + lane) * 4;
+        if (i < dim) {
+            floatx4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = rs * (gv[c][j] - xv[c][j] * rs * dot);
+            if (accumulate) { const floatx4 a = ld4(dx, dx_dt, db + i);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] += a[j]; }
+            st4(dx, dx_dt, db + i, o);
+        }
+    }
+}
+
+// Four waves per row (NCH % 4 == 0: rows of 1024 elements and more), wave q on chunk group q: the student's 256 rows x 4096 were 64
+// workgroups of one-wave rows, sixteen dependent chunks each - 22 us per call, 81 calls per backward pass.  Same sums in the same
+// order as the one-wave kernel.
+template <int NCH>
+__global__ __launch_bounds__(256)
+void rmsnorm_bwd_wide_k(const void* __restrict__ x, int x_dt, const bf16_t* __restrict__ w, const void* __restrict__ dy, int dy_dt,
+                        void* __restrict__ dx, int dx_dt, int64_t rows, int dim, int64_t inner, int64_t ld_x, int64_t ld_dy,
+                        int64_t ld_dx, float eps, int accumulate, int round_g) {
+    __shared__ float red[2][4];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int64_t row = blockIdx.x;
+    const int64_t ro = row / inner, ri = row % inner;
+    const int64_t xb = ro * ld_x + ri * dim, yb = ro * ld_dy + ri * dim, db = ro * ld_dx + ri * dim;
+    constexpr int PG = NCH / 4;
+    floatx4 xv[PG], gv[PG];
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < PG; ++c) {
+        const int i = ((q * PG + c) * 64 + lane) * 4;
         if (i < dim) {
             xv[c] = ld4(x, x_dt, xb + i);
             const floatx4 d = ld4(dy, dy_dt, yb + i);
@@ -56,20 +124,26 @@ void rmsnorm_bwd_k(const void* __restrict__ x, int x_dt, const bf16_t* __restric
         }
     }
     ss = wave_sum(ss);
+    if (lane == 0) red[0][q] = ss;
+    __syncthreads();
+    ss = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
     const float rs = rsqrtf(ss / (float)dim + eps);
     float dot = 0.f;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        const int i = (c * 64 + lane) * 4;
+    for (int c = 0; c < PG; ++c) {
+        const int i = ((q * PG + c) * 64 + lane) * 4;
         if (i < dim) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) dot += gv[c][j] * xv[c][j] * rs;
         }
     }
-    dot = wave_sum(dot) / (float)dim;
+    dot = wave_sum(dot);
+    if (lane == 0) red[1][q] = dot;
+    __syncthreads();
+    dot = (((red[1][0] + red[1][1]) + red[1][2]) + red[1][3]) / (float)dim;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        const int i = (c * 64 + lane) * 4;
+    for (int c = 0; c < PG; ++c) {
+        const int i = ((q * PG + c) * 64 + lane) * 4;
         if (i < dim) {
             floatx4 o;
 #pragma unroll
@@ -136,38 +210,68 @@ struct AttnBwdP {
     int want_dkv;
 };
 
-__device__ __forceinline__ float dot8(const bf16_t* __restrict__ x, const bf16_t* __restrict__ y, int hd) {
-    float acc = 0.f;
-    for (int d = 0; d < hd; d += 8) {
-        const uint4 xv = *reinterpret_cast<const uint4*>(x + d), yv = *reinterpret_cast<const uint4*>(y + d);
-        const uint32_t xu[4] = {xv.x, xv.y, xv.z, xv.w}, yu[4] = {yv.x, yv.y, yv.z, yv.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            acc += __uint_as_float(xu[e] << 16) * __uint_as_float(yu[e] << 16);
-            acc += __uint_as_float(xu[e] & 0xffff0000u) * __uint_as_float(yu[e] & 0xffff0000u);
-        }
-    }
-    return acc;
-}
-
-// One workgroup per (batch, head); every phase spreads its (row, column) or (row, 8-channel chunk) items over all 256
-// lanes.  Q/K/V/dO stay in global memory (a few KiB per head, L1/L2 resident); P and dS (Sq x Sk fp32 each) live in LDS.
-__global__ __launch_bounds__(256)
+// One workgroup per (batch, head); every phase spreads its (row, column) or (row, 8-channel chunk) items over all its
+// lanes (1024 in the staged form: the phases are chains of dependent FMAs and LDS reads, and one wave per SIMD left each
+// latency exposed - 38 us with 256 lanes).  P and dS (Sq x Sk fp32 each) live in LDS.  STAGED (round 4): so do the head's Q, K, V and dO rows (rows of hd + 8 bf16, so
+// the 16-byte reads of 16 consecutive rows fall into 64 different banks) - the 32-token student's 1024 (query, key) pairs each walked
+// two 128-long dot products straight from global memory, dependent 16-byte loads one L2 round trip apiece: 67 us per layer for a
+// few MFLOP.  The arithmetic and its order are the same in both forms: bit-identical results (tests/test_backward_ops_gpu.py).
+// Not STAGED (the operands do not fit beside P and dS): Q / K / V / dO stay in global memory (L1 / L2 resident).
+template <bool STAGED>
+__global__ __launch_bounds__(1024)
 void attn_bwd_small_k(AttnBwdP a) {
-    extern __shared__ float bsm[];
-    float* P = bsm;                          // Sq x Sk
-    float* dS = bsm + a.Sq * a.Sk;           // Sq x Sk
+    extern __shared__ __attribute__((aligned(16))) float bsm[];
     const int head = blockIdx.x % a.nh, b = blockIdx.x / a.nh;
     const int kvh = head / (a.nh / a.nkv);
     const int coff = a.Sk - a.Sq;
-    const int hd = a.hd, Sq = a.Sq, Sk = a.Sk, tid = threadIdx.x;
+    const int hd = a.hd, Sq = a.Sq, Sk = a.Sk, tid = threadIdx.x, nthr = blockDim.x;
+    const int nch = hd >> 3;
+    const int npair = (Sq * Sk + 3) & ~3;     // (keeps the operand rows behind P and dS 16-byte aligned)
+    float* P = bsm;                          // Sq x Sk
+    float* dS = bsm + npair;                 // Sq x Sk
+    const int RS = hd + 8;
+    bf16_t* sQ = reinterpret_cast<bf16_t*>(bsm + 2 * npair);
+    bf16_t* sG = sQ + Sq * RS;
+    bf16_t* sK = sG + Sq * RS;
+    bf16_t* sV = sK + Sk * RS;
     const bf16_t* qb = a.q + (int64_t)b * a.q_bs + (int64_t)head * hd;
     const bf16_t* kb = a.k + (int64_t)b * a.kv_bs + (int64_t)kvh * hd;
     const bf16_t* vb = a.v + (int64_t)b * a.kv_bs + (int64_t)kvh * hd;
     const int64_t do_rs = (int64_t)a.nh * hd;
     const bf16_t* dob = a.dout + (int64_t)b * Sq * do_rs + (int64_t)head * hd;
+    if (STAGED) {
+        for (int idx = tid; idx < 2 * (Sq + Sk) * nch; idx += nthr) {
+            const int r = idx / nch, c = (idx - r * nch) * 8;
+            uint4 v;
+            bf16_t* dst;
+            if (r < Sq) { v = *reinterpret_cast<const uint4*>(qb + (int64_t)r * a.q_rs + c); dst = sQ + r * RS + c; }
+            else if (r < 2 * Sq) { v = *reinterpret_cast<const uint4*>(dob + (int64_t)(r - Sq) * do_rs + c); dst = sG + (r - Sq) * RS + c; }
+            else if (r < 2 * Sq + Sk) { v = *reinterpret_cast<const uint4*>(kb + (int64_t)(r - 2 * Sq) * a.kv_rs + c); dst = sK + (r - 2 * Sq) * RS + c; }
+            else { v = *reinterpret_cast<const uint4*>(vb + (int64_t)(r - 2 * Sq - Sk) * a.kv_rs + c); dst = sV + (r - 2 * Sq - Sk) * RS + c; }
+            *reinterpret_cast<uint4*>(dst) = v;
+        }
+        __syncthreads();
+    }
+    // 8 consecutive channels (16 bytes) of a row of Q / dO / K / V
+    auto q8 = [&](int i, int c) -> uint4 { return STAGED ? *reinterpret_cast<const uint4*>(sQ + i * RS + c) : *reinterpret_cast<const uint4*>(qb + (int64_t)i * a.q_rs + c); };
+    auto g8 = [&](int i, int c) -> uint4 { return STAGED ? *reinterpret_cast<const uint4*>(sG + i * RS + c) : *reinterpret_cast<const uint4*>(dob + (int64_t)i * do_rs + c); };
+    auto k8 = [&](int j, int c) -> uint4 { return STAGED ? *reinterpret_cast<const uint4*>(sK + j * RS + c) : *reinterpret_cast<const uint4*>(kb + (int64_t)j * a.kv_rs + c); };
+    auto v8 = [&](int j, int c) -> uint4 { return STAGED ? *reinterpret_cast<const uint4*>(sV + j * RS + c) : *reinterpret_cast<const uint4*>(vb + (int64_t)j * a.kv_rs + c); };
+    auto dot = [&](auto&& fx, int i, auto&& fy, int j) -> float {      // (the order of dot8)
+        float acc = 0.f;
+        for (int d = 0; d < hd; d += 8) {
+            const uint4 xv = fx(i, d), yv = fy(j, d);
+            const uint32_t xu[4] = {xv.x, xv.y, xv.z, xv.w}, yu[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc += __uint_as_float(xu[e] << 16) * __uint_as_float(yu[e] << 16);
+                acc += __uint_as_float(xu[e] & 0xffff0000u) * __uint_as_float(yu[e] & 0xffff0000u);
+            }
+        }
+        return acc;
+    };
     // phase 1: masked scores and dP = dO V^T
-    for (int idx = tid; idx < Sq * Sk; idx += 256) {
+    for (int idx = tid; idx < Sq * Sk; idx += nthr) {
         const int i = idx / Sk, j = idx - i * Sk;
         bool ok = true;
         if (a.mask_mode == 1) ok = (j <= i + coff) && (!a.key_valid || a.key_valid[(int64_t)b * Sk + j] != 0);
@@ -175,8 +279,8 @@ void attn_bwd_small_k(AttnBwdP a) {
         else if (a.mask_mode == 3) ok = a.img_mask[((int64_t)b * Sq + i) * a.n_img + j / a.img_len] != 0;
         float s = -INFINITY, dp = 0.f;
         if (ok) {
-            s = dot8(qb + (int64_t)i * a.q_rs, kb + (int64_t)j * a.kv_rs, hd) * a.scale;
-            dp = dot8(dob + (int64_t)i * do_rs, vb + (int64_t)j * a.kv_rs, hd);
+            s = dot(q8, i, k8, j) * a.scale;
+            dp = dot(g8, i, v8, j);
         }
         P[idx] = s;
         dS[idx] = dp;
@@ -184,7 +288,7 @@ void attn_bwd_small_k(AttnBwdP a) {
     __syncthreads();
     // phase 2: one wave per query row: softmax (probabilities rounded to bf16 like the forward), D = sum_j p dP, dS
     const int lane = tid & 63, wave = tid >> 6;
-    for (int i = wave; i < Sq; i += 4) {
+    for (int i = wave; i < Sq; i += (nthr >> 6)) {
         float mx = -INFINITY;
         for (int j = lane; j < Sk; j += 64) mx = fmaxf(mx, P[i * Sk + j]);
         mx = wave_max(mx);
@@ -208,14 +312,13 @@ void attn_bwd_small_k(AttnBwdP a) {
     }
     __syncthreads();
     // phase 3: dQ_i = sum_j dS_ij K_j, 8 channels per item
-    const int nch = hd >> 3;
-    for (int idx = tid; idx < Sq * nch; idx += 256) {
+    for (int idx = tid; idx < Sq * nch; idx += nthr) {
         const int i = idx / nch, c = (idx - i * nch) * 8;
         float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         for (int j = 0; j < Sk; ++j) {
             const float ds = dS[i * Sk + j];
             if (ds == 0.f) continue;
-            const uint4 kv = *reinterpret_cast<const uint4*>(kb + (int64_t)j * a.kv_rs + c);
+            const uint4 kv = k8(j, c);
             const uint32_t ku[4] = {kv.x, kv.y, kv.z, kv.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) { acc[2 * e] += ds * __uint_as_float(ku[e] << 16); acc[2 * e + 1] += ds * __uint_as_float(ku[e] & 0xffff0000u); }
@@ -227,14 +330,14 @@ void attn_bwd_small_k(AttnBwdP a) {
     }
     if (!a.want_dkv) return;
     // phase 4: dK_j = sum_i dS_ij Q_i ; dV_j = sum_i P_ij dO_i  (written per QUERY head; GQA groups are reduced by head_group_sum_k)
-    for (int idx = tid; idx < Sk * nch; idx += 256) {
+    for (int idx = tid; idx < Sk * nch; idx += nthr) {
         const int j = idx / nch, c = (idx - j * nch) * 8;
         float ak[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, av[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         for (int i = 0; i < Sq; ++i) {
             const float ds = dS[i * Sk + j], p = P[i * Sk + j];
             if (ds == 0.f && p == 0.f) continue;
-            const uint4 qv = *reinterpret_cast<const uint4*>(qb + (int64_t)i * a.q_rs + c);
-            const uint4 gv = *reinterpret_cast<const uint4*>(dob + (int64_t)i * do_rs + c);
+            const uint4 qv = q8(i, c);
+            const uint4 gv = g8(i, c);
             const uint32_t qu[4] = {qv.x, qv.y, qv.z, qv.w}, gu[4] = {gv.x, gv.y, gv.z, gv.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -322,8 +425,13 @@ extern "C" int licv_rmsnorm_bwd(const void* x, int x_dtype, const void* w_bf16, 
     const dim3 grid((unsigned)((rows + BW_WAVES - 1) / BW_WAVES)), block(64 * BW_WAVES);
     hipStream_t st = (hipStream_t)stream;
 #define L(NC) rmsnorm_bwd_k<NC><<<grid, block, 0, st>>>(x, x_dtype, (const bf16_t*)w_bf16, dy, dy_dtype, dx, dx_dtype, rows, (int)dim, inner, ld_x, ld_dy, ld_dx, eps, accumulate, round_g)
+#define LW(NC) rmsnorm_bwd_wide_k<NC><<<dim3((unsigned)rows), dim3(256), 0, st>>>(x, x_dtype, (const bf16_t*)w_bf16, dy, dy_dtype, dx, dx_dtype, rows, (int)dim, inner, ld_x, ld_dy, ld_dx, eps, accumulate, round_g)
+    if (g_rmsnorm_bwd_wide && nch >= 4) {
+        switch (nch) { case 4: LW(4); break; case 8: LW(8); break; default: LW(16); break; }
+    } else
     switch (nch) { case 1: L(1); break; case 2: L(2); break; case 4: L(4); break; case 8: L(8); break; default: L(16); break; }
 #undef L
+#undef LW
     LICV_LAUNCH_CHECK();
     return LICV_OK;
 }
@@ -343,6 +451,14 @@ extern "C" int licv_branch_grad(const float* dh, void* out_bf16, int64_t rows, i
     branch_grad_k<<<flat_grid(rows * dim), 256, 0, (hipStream_t)stream>>>(dh, (bf16_t*)out_bf16, rows, dim, scale, use_scale, row_gate);
     LICV_LAUNCH_CHECK();
     return LICV_OK;
+}
+
+// A/B timing and tests (results are bit-identical either way): option 0 = 0: attn_bwd_small keeps Q / K / V / dO in global memory;
+// option 1 = 0: rmsnorm_bwd on one wave per row at every row length
+extern "C" int licv_backward_option(int option, int value) {
+    if (option == 0) { g_attn_bwd_staged = value; return LICV_OK; }
+    if (option == 1) { g_rmsnorm_bwd_wide = value; return LICV_OK; }
+    return licv_set_error(LICV_E_BADARG, "backward_option: unknown option %d", option);
 }
 
 extern "C" int licv_attn_bwd_small(const licv_attn_args* x, const void* dout, void* dq, int64_t dq_bs, int64_t dq_rs,
@@ -368,10 +484,20 @@ extern "C" int licv_attn_bwd_small(const licv_attn_args* x, const void* dout, vo
     p.B = (int)x->B; p.Sq = (int)x->Sq; p.Sk = (int)x->Sk; p.nh = (int)x->n_heads; p.nkv = (int)x->n_kv_heads; p.hd = (int)x->head_dim;
     p.scale = x->scale; p.mask_mode = x->mask_mode; p.key_valid = x->key_valid; p.img_mask = x->img_mask;
     p.n_img = (int)x->n_img; p.img_len = (int)x->img_len; p.want_dkv = want;
-    const size_t lds = (size_t)2 * x->Sq * x->Sk * sizeof(float);
+    const size_t npair = ((size_t)x->Sq * x->Sk + 3) & ~(size_t)3;
+    const size_t lds = 2 * npair * sizeof(float);
+    // ... plus the head's Q, dO, K, V rows where they fit beside P and dS (knob: licv_backward_option 0 = 0 keeps them in global memory)
+    const size_t lds_staged = lds + 2 * (size_t)(x->Sq + x->Sk) * (x->head_dim + 8) * 2;
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)attn_bwd_small_k, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); attr = true; }
-    attn_bwd_small_k<<<(unsigned)(x->B * x->n_heads), 256, lds, (hipStream_t)stream>>>(p);
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)attn_bwd_small_k<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_small_k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    if (g_attn_bwd_staged && lds_staged <= 160 * 1024)
+        attn_bwd_small_k<true><<<(unsigned)(x->B * x->n_heads), g_attn_bwd_staged == 2 ? 256 : 1024, lds_staged, (hipStream_t)stream>>>(p);
+    else
+        attn_bwd_small_k<false><<<(unsigned)(x->B * x->n_heads), 256, lds, (hipStream_t)stream>>>(p);
     LICV_LAUNCH_CHECK();
     return LICV_OK;
 }

@@ -276,3 +276,59 @@ def test_attention_bwd_real_head_geometry_vs_autograd(nkv):
         assert err <= tol, f"{name}: {err:.3e} > {tol:.3e}"
         cos = F.cosine_similarity(g_.reshape(1, -1), r_.reshape(1, -1)).item()
         assert cos > 0.9999, f"{name}: cosine {cos}"
+
+
+# ------------------------------------------------------------------------------------------- round-4 forms of two backward kernels
+@pytest.mark.parametrize("shape", [(8, 32, 32, 32, 8, 128, 1), (2, 32, 64, 4, 4, 64, 2), (3, 5, 7, 6, 2, 80, 1), (1, 100, 100, 2, 2, 128, 1)],
+                         ids=["student_gqa", "perceiver_like_unmasked", "odd_sizes", "operands_do_not_fit_lds"])
+def test_attention_bwd_staged_operands_equal_global_operands_bitwise(shape):
+    """licv_attn_bwd_small with the head's Q / K / V / dO rows staged in LDS (licv_backward_option 0, the default where they fit) against
+    the same kernel reading them from global memory: same arithmetic in the same order, identical bits - causal + key padding, no
+    mask, odd sizes (a pair count that is not a multiple of 4, head dim 80), and a shape whose operands do not fit (falls back)."""
+    from licv import _lib
+    B, Sq, Sk, nh, nkv, hd, mode = shape
+    qd, kd = nh * hd, nkv * hd
+    q = torch.randn(B * Sq, qd, generator=g(41)).to(torch.bfloat16).to(DEV)
+    kv = torch.randn(B * Sk, 2 * kd, generator=g(42)).to(torch.bfloat16).to(DEV)
+    dout = (torch.randn(B * Sq, qd, generator=g(43)) * 0.05).to(torch.bfloat16).to(DEV)
+    key_valid = (torch.rand(B, Sk, generator=g(44)) > 0.2).to(torch.int32)
+    key_valid[:, 0] = 1
+    outs = []
+    try:
+        for staged in (0, 1):
+            _lib.check(_lib.lib().licv_backward_option(0, staged))
+            dq = torch.zeros_like(q)
+            dkv = torch.zeros((B * Sk, 2 * qd), dtype=torch.bfloat16, device=DEV)
+            ops().attention_bwd_small(q, kv, kv.view(-1)[kd:], dout, B, Sq, Sk, nh, nkv, hd, Sq * qd, qd, Sk * 2 * kd, 2 * kd, hd ** -0.5, mode,
+                                      dq, Sq * qd, qd, dk=dkv, dv=dkv.view(-1)[qd:], dkv_bs=Sk * 2 * qd, dkv_rs=2 * qd,
+                                      key_valid=key_valid.to(DEV))
+            outs.append((dq, dkv))
+    finally:
+        _lib.check(_lib.lib().licv_backward_option(0, 1))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert float(outs[1][0].float().abs().max()) > 0 and float(outs[1][1].float().abs().max()) > 0
+
+
+@pytest.mark.parametrize("dim", [1024, 1152, 4096])
+@pytest.mark.parametrize("x_dt", [torch.float32, torch.bfloat16])
+def test_rmsnorm_bwd_four_waves_per_row_equal_one_wave_per_row_bitwise(dim, x_dt):
+    """licv_rmsnorm_bwd on four waves per row (licv_backward_option 1, the default from 1024 elements on) against one wave per row:
+    both form the two row statistics in four chunk groups added in group order - identical bits, with and without accumulation."""
+    from licv import _lib
+    rows = 77
+    x = torch.randn(rows, dim, generator=g(45)).to(x_dt).to(DEV)
+    w = (1 + 0.1 * torch.randn(dim, generator=g(46))).to(torch.bfloat16).to(DEV)
+    dy = torch.randn(rows, dim, generator=g(47)).to(x_dt).to(DEV)
+    base = torch.randn(rows, dim, generator=g(48)).to(x_dt).to(DEV)
+    outs = []
+    try:
+        for wide in (0, 1):
+            _lib.check(_lib.lib().licv_backward_option(1, wide))
+            for acc in (False, True):
+                dx = base.clone()
+                ops().rmsnorm_bwd(x, w, dy, dx, 1e-6, accumulate=acc, flavour=1)
+                outs.append(dx)
+    finally:
+        _lib.check(_lib.lib().licv_backward_option(1, 1))
+    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[3])
+    assert not torch.equal(outs[0], outs[1])
