@@ -274,7 +274,8 @@ int licv_branch_grad(const float* dh, void* out_bf16, int64_t rows, int64_t dim,
 int licv_attn_bwd_small(const licv_attn_args* a, const void* dout_bf16, void* dq_bf16, int64_t dq_bs, int64_t dq_rs,
                         void* dk_bf16, void* dv_bf16, int64_t dkv_bs, int64_t dkv_rs, void* stream);
 /* A/B timing and tests of the backward kernels (results are bit-identical either way).  option 0 = 0: licv_attn_bwd_small keeps the
- * head's Q / K / V / dO rows in global memory (default 1: staged in LDS where they fit beside P and dS); option 1 = 0: licv_rmsnorm_bwd
+ * head's Q / K / V / dO rows in global memory (default 1: staged in LDS where they fit beside P and dS, 1024 lanes per (batch, head);
+ * 2: staged on 256 lanes, timing only); option 1 = 0: licv_rmsnorm_bwd
  * on one wave per row at every row length (default 1: four waves per row from 1024 elements on). */
 int licv_backward_option(int option, int value);
 /* cross-entropy rows (the "hard" loss, ref:icv_src/icv_module.py:94-95,111-117; HF ForCausalLMLoss upcasts to fp32):
