@@ -23,7 +23,7 @@ extern "C" {
 /* Bumped whenever an entry point is added, removed or changes its arguments; licv/_lib.py holds the same constant and refuses a
  * library that answers anything else.  1 = round 1; 2 = rounds 2-3 (fp8, split-K slices, runner, front-end, backward, image input);
  * 3 = round 4 (lab library split off; weight-streaming GEMM; beam scoring; decode-step fusion). */
-#define LICV_ABI_VERSION 4
+#define LICV_ABI_VERSION 5
 
 enum { LICV_BF16 = 0, LICV_F32 = 1 };
 enum { LICV_OK = 0, LICV_E_BADARG = -1, LICV_E_UNSUPPORTED = -2, LICV_E_HIP = -3 };
@@ -264,6 +264,12 @@ int licv_swiglu(const void* gu_bf16, void* out_bf16, int64_t rows, int64_t inter
 int licv_rmsnorm_bwd(const void* x, int x_dtype, const void* w_bf16, const void* dy, int dy_dtype, void* dx, int dx_dtype,
                      int64_t rows, int64_t dim, int64_t inner, int64_t ld_x, int64_t ld_dy, int64_t ld_dx, float eps,
                      int accumulate, int flavour, void* stream);
+/* The same with dy still in the fp32 split-K slices of the dgrad GEMM that produced it (licv_gemm_bf16_splitk_produce): dy[r, i] =
+ * bf16(sum over the slices, in slice order) - bit for bit what the finalize launch writes and licv_rmsnorm_bwd reads back; rows of
+ * >= 1024 elements, dy / x / dx dense (leading dimension = dim). */
+int licv_rmsnorm_bwd_ws(const void* x, int x_dtype, const void* w_bf16, const float* ws, int splits, int64_t slice_elems,
+                        int64_t row_stride, void* dx, int dx_dtype, int64_t rows, int64_t dim, float eps, int accumulate,
+                        int flavour, void* stream);
 /* SwiGLU backward on the unfused (rows, 2I) [gate | up] buffer */
 int licv_swiglu_bwd(const void* gu_bf16, const void* dact_bf16, void* dgu_bf16, int64_t rows, int64_t inter, void* stream);
 /* grad entering a residual branch: out = bf16(bf16(dh)*scale), rows with row_gate == 0 zeroed (row_gate may be NULL) */

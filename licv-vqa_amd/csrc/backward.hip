@@ -99,11 +99,14 @@ void rmsnorm_bwd_k(const void* __restrict__ x, int x_dt, const bf16_t* __restric
 // Four waves per row (NCH % 4 == 0: rows of 1024 elements and more), wave q on chunk group q: the student's 256 rows x 4096 were 64
 // workgroups of one-wave rows, sixteen dependent chunks each - 22 us per call, 81 calls per backward pass.  Same sums in the same
 // order as the one-wave kernel.
-template <int NCH>
+// WS: dy is still the fp32 split-K slices of the dgrad GEMM that produced it (licv_gemm_bf16_splitk_produce): element = bf16(sum of the
+// slices in slice order) - what the finalize launch would have written and this kernel read back; one launch less per norm.
+struct BwdWs { const float* ws; int splits; int64_t slice; int64_t stride; };
+template <int NCH, bool WS = false>
 __global__ __launch_bounds__(256)
 void rmsnorm_bwd_wide_k(const void* __restrict__ x, int x_dt, const bf16_t* __restrict__ w, const void* __restrict__ dy, int dy_dt,
                         void* __restrict__ dx, int dx_dt, int64_t rows, int dim, int64_t inner, int64_t ld_x, int64_t ld_dy,
-                        int64_t ld_dx, float eps, int accumulate, int round_g) {
+                        int64_t ld_dx, float eps, int accumulate, int round_g, BwdWs src = BwdWs{nullptr, 0, 0, 0}) {
     __shared__ float red[2][4];
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int64_t row = blockIdx.x;
@@ -117,7 +120,14 @@ void rmsnorm_bwd_wide_k(const void* __restrict__ x, int x_dt, const bf16_t* __re
         const int i = ((q * PG + c) * 64 + lane) * 4;
         if (i < dim) {
             xv[c] = ld4(x, x_dt, xb + i);
-            const floatx4 d = ld4(dy, dy_dt, yb + i);
+            floatx4 d;
+            if (WS) {
+                const float* p = src.ws + row * src.stride + i;
+                d = *reinterpret_cast<const floatx4*>(p);
+                for (int sp = 1; sp < src.splits; ++sp) d += *reinterpret_cast<const floatx4*>(p + (int64_t)sp * src.slice);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) d[j] = rbf(d[j]);
+            } else d = ld4(dy, dy_dt, yb + i);
             const floatx4 wv = ld4(w, LICV_BF16, i);
 #pragma unroll
             for (int j = 0; j < 4; ++j) { ss += xv[c][j] * xv[c][j]; const float gw = d[j] * wv[j]; gv[c][j] = round_g ? rbf(gw) : gw; }
@@ -431,6 +441,28 @@ extern "C" int licv_rmsnorm_bwd(const void* x, int x_dtype, const void* w_bf16, 
     } else
     switch (nch) { case 1: L(1); break; case 2: L(2); break; case 4: L(4); break; case 8: L(8); break; default: L(16); break; }
 #undef L
+#undef LW
+    LICV_LAUNCH_CHECK();
+    return LICV_OK;
+}
+
+extern "C" int licv_rmsnorm_bwd_ws(const void* x, int x_dtype, const void* w_bf16, const float* ws, int splits, int64_t slice_elems,
+                                   int64_t row_stride, void* dx, int dx_dtype, int64_t rows, int64_t dim, float eps, int accumulate,
+                                   int flavour, void* stream) {
+    LICV_CHECK_ARG(x && w_bf16 && ws && dx, "rmsnorm_bwd_ws: null pointer");
+    LICV_CHECK_ARG((x_dtype == LICV_BF16 || x_dtype == LICV_F32) && (dx_dtype == LICV_BF16 || dx_dtype == LICV_F32), "rmsnorm_bwd_ws: bad dtype");
+    LICV_CHECK_ARG(flavour == 0 || flavour == 1, "rmsnorm_bwd_ws: bad flavour %d", flavour);
+    LICV_CHECK_ARG(splits >= 1 && slice_elems > 0 && row_stride >= dim && row_stride % 4 == 0 && slice_elems % 4 == 0 && ((uintptr_t)ws & 15) == 0,
+                   "rmsnorm_bwd_ws: bad split-K workspace description");
+    LICV_CHECK_ARG(dim >= 1024 && dim % 4 == 0, "rmsnorm_bwd_ws: rows of %lld elements (needs >= 1024, a multiple of 4)", (long long)dim);
+    if (rows <= 0) return LICV_OK;
+    const int nch = nch_for(dim);
+    LICV_CHECK_ARG(nch >= 4 && nch <= 16, "rmsnorm_bwd_ws: row length %lld unsupported", (long long)dim);
+    const int round_g = (flavour == 1 && x_dtype == LICV_F32) ? 0 : 1;
+    hipStream_t st = (hipStream_t)stream;
+    const BwdWs src{ws, splits, slice_elems, row_stride};
+#define LW(NC) rmsnorm_bwd_wide_k<NC, true><<<dim3((unsigned)rows), dim3(256), 0, st>>>(x, x_dtype, (const bf16_t*)w_bf16, nullptr, LICV_BF16, dx, dx_dtype, rows, (int)dim, 1, dim, dim, dim, eps, accumulate, round_g, src)
+    switch (nch) { case 4: LW(4); break; case 8: LW(8); break; default: LW(16); break; }
 #undef LW
     LICV_LAUNCH_CHECK();
     return LICV_OK;

@@ -18,7 +18,7 @@ LAB_PATH = Path(os.environ.get("LICV_HIP_LAB_LIB", _HERE / "liblicv_hip_lab.so")
 LAB_HEADER = _HERE.parents[1] / "include" / "licv_hip_lab.h"
 
 LICV_BF16, LICV_F32 = 0, 1
-ABI_VERSION = 4          # == LICV_ABI_VERSION of include/licv_hip.h this binding was written against (check_exports compares both)
+ABI_VERSION = 5          # == LICV_ABI_VERSION of include/licv_hip.h this binding was written against (check_exports compares both)
 
 _lib = None
 _lab = None
@@ -139,6 +139,7 @@ def lib() -> C.CDLL:
             "licv_tile_rows": [P, P, I64, I64, I64, P],
             "licv_swiglu": [P, P, I64, I64, P],
             "licv_rmsnorm_bwd": [P, I, P, P, I, P, I, I64, I64, I64, I64, I64, I64, F, I, I, P],
+            "licv_rmsnorm_bwd_ws": [P, I, P, P, I, I64, I64, P, I, I64, I64, F, I, I, P],
             "licv_swiglu_bwd": [P, P, P, I64, I64, P],
             "licv_branch_grad": [P, P, I64, I64, F, I, P, P],
             "licv_attn_bwd_small": [C.POINTER(AttnArgs), P, P, I64, I64, P, P, I64, I64, P],

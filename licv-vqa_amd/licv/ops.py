@@ -577,6 +577,22 @@ def rmsnorm_bwd(x: torch.Tensor, w: torch.Tensor, dy: torch.Tensor, dx: torch.Te
     return dx
 
 
+def rmsnorm_bwd_from(x: torch.Tensor, w: torch.Tensor, a: torch.Tensor, wt: torch.Tensor, dx: torch.Tensor, eps: float, accumulate: bool,
+                     flavour: int = 0):
+    """rmsnorm_bwd(x, w, dy = a @ wt.T, dx, ...) with the dgrad GEMM and the norm's backward fused at the launch level: where the plan
+    splits K (the 256-row student always does) only the producer half of the GEMM runs and the norm kernel sums the slices itself -
+    bit for bit rmsnorm_bwd(x, w, linear(a, wt), ...), one launch and one bf16 round trip of dy less."""
+    dim = x.shape[-1]
+    sl = linear_produce(a, wt) if (dim >= 1024 and x.is_contiguous() and dx.is_contiguous()) else None
+    if sl is None:
+        return rmsnorm_bwd(x, w, linear(a, wt), dx, eps, accumulate, flavour=flavour)
+    rows = x.numel() // dim
+    assert sl.rows == rows and sl.cols == dim
+    check(_lib.lib().licv_rmsnorm_bwd_ws(_p(x), _dt(x), _p(w), *sl.args(), _p(dx), _dt(dx), rows, dim, float(eps), 1 if accumulate else 0,
+                                         flavour, _stream(x)))
+    return dx
+
+
 def swiglu_bwd(gu: torch.Tensor, dact: torch.Tensor) -> torch.Tensor:
     rows, two_i = gu.shape
     out = torch.empty_like(gu)

@@ -167,8 +167,7 @@ class StudentPass:
             d_out = ops.branch_grad(dh)
             d_act = ops.linear(d_out, T["down_T"])
             d_gu = ops.swiglu_bwd(rec["gu"], d_act)
-            d_x = ops.linear(d_gu, T["gu_T"])
-            ops.rmsnorm_bwd(rec["h_mid"], D.post_ln, d_x, dh, a.rms_eps, accumulate=True)
+            ops.rmsnorm_bwd_from(rec["h_mid"], D.post_ln, d_gu, T["gu_T"], dh, a.rms_eps, accumulate=True)
             # attention branch
             d_o = ops.branch_grad(dh)
             d_attn = ops.linear(d_o, T["o_T"])
@@ -178,8 +177,7 @@ class StudentPass:
                                     S * 3 * H, 3 * H, hd ** -0.5, 1, dqkv, S * 3 * H, 3 * H, dk=dqkv.view(-1)[H:], dv=dqkv.view(-1)[2 * H:],
                                     dkv_bs=S * 3 * H, dkv_rs=3 * H, key_valid=st["key_valid"])
             ops.rotary_(dqkv, w.cos, tw.neg_sin, st["pos"], M, nh, hd, 3 * H, H, 2)                 # inverse rotation
-            d_x = ops.linear(dqkv, T["qkv_T"])
-            ops.rmsnorm_bwd(rec["h_in"], D.in_ln, d_x, dh, a.rms_eps, accumulate=True)
+            ops.rmsnorm_bwd_from(rec["h_in"], D.in_ln, dqkv, T["qkv_T"], dh, a.rms_eps, accumulate=True)
             if "x" in rec:
                 x = rec["x"]
                 j = l // a.cross_layer_interval
@@ -187,8 +185,7 @@ class StudentPass:
                 d_out = ops.branch_grad(dh, scale=X.gate_dense)
                 d_act = ops.linear(d_out, TX["down_T"])
                 d_gu = ops.swiglu_bwd(x["gu"], d_act)
-                d_x = ops.linear(d_gu, TX["gu_T"])
-                ops.rmsnorm_bwd(x["h_mid"], X.post_ln, d_x, dh, a.rms_eps, accumulate=True)
+                ops.rmsnorm_bwd_from(x["h_mid"], X.post_ln, d_gu, TX["gu_T"], dh, a.rms_eps, accumulate=True)
                 d_o = ops.branch_grad(dh, scale=X.gate_attn, row_gate=st["gate"])
                 d_attn = ops.linear(d_o, TX["o_T"])
                 dq = torch.empty((M, H), dtype=torch.bfloat16, device=dev)
@@ -200,8 +197,7 @@ class StudentPass:
                     ops.rmsnorm_bwd(x["q_pre"], X.qn_w, dq, dq_pre, a.rms_eps, accumulate=False, inner=nh, ld_x=H, ld_dy=H, ld_dx=H,
                                     rows=M * nh, dim=hd)
                     dq = dq_pre
-                d_x = ops.linear(dq, TX["q_T"])
-                ops.rmsnorm_bwd(x["h_in"], X.in_ln, d_x, dh, a.rms_eps, accumulate=True)
+                ops.rmsnorm_bwd_from(x["h_in"], X.in_ln, dq, TX["q_T"], dh, a.rms_eps, accumulate=True)
         return grad_v
 
 
@@ -306,8 +302,7 @@ class StudentPass2:
                 d_out = ops.branch_grad(dh)
             d_act = ops.linear(d_out, T["down_T"])
             d_gu = ops.swiglu_bwd(rec["gu"], d_act)
-            d_x = ops.linear(d_gu, T["gu_T"])
-            ops.rmsnorm_bwd(rec["h_mid"], L.post_ln, d_x, dh, a.rms_eps, accumulate=True, flavour=1)
+            ops.rmsnorm_bwd_from(rec["h_mid"], L.post_ln, d_gu, T["gu_T"], dh, a.rms_eps, accumulate=True, flavour=1)
             # attention branch (GQA): dK / dV per query head, then the group sum = backward of repeat_kv
             d_attn = ops.linear(ops.branch_grad(dh), T["o_T"])
             qkv = rec["qkv"]
@@ -319,6 +314,5 @@ class StudentPass2:
             ops.head_group_sum(dkv_heads, dqkv.view(-1)[qd:], M, nkv, rep, hd, 2 * qd, ldq)
             ops.head_group_sum(dkv_heads.view(-1)[qd:], dqkv.view(-1)[qd + kd:], M, nkv, rep, hd, 2 * qd, ldq)
             ops.rotary_(dqkv, w.cos, tw.neg_sin, st["pos"], M, nh + nkv, hd, ldq, 0, 1)      # inverse rotation of dQ and dK
-            d_x = ops.linear(dqkv, T["qkv_T"])
-            ops.rmsnorm_bwd(rec["h_in"], L.in_ln, d_x, dh, a.rms_eps, accumulate=True, flavour=1)
+            ops.rmsnorm_bwd_from(rec["h_in"], L.in_ln, dqkv, T["qkv_T"], dh, a.rms_eps, accumulate=True, flavour=1)
         return grad_v

@@ -332,3 +332,24 @@ def test_rmsnorm_bwd_four_waves_per_row_equal_one_wave_per_row_bitwise(dim, x_dt
         _lib.check(_lib.lib().licv_backward_option(1, 1))
     assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[3])
     assert not torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("x_dt,flavour", [(torch.float32, 1), (torch.float32, 0), (torch.bfloat16, 0)])
+@pytest.mark.parametrize("K", [11008, 22016, 12288])
+def test_rmsnorm_bwd_fed_by_split_k_slices_equals_gemm_then_norm_bitwise(K, x_dt, flavour):
+    """ops.rmsnorm_bwd_from: the dgrad GEMM's producer half + licv_rmsnorm_bwd_ws (the norm's backward sums the fp32 slices itself) against
+    linear() + rmsnorm_bwd() - the three dgrad shapes of the 256-row student (d gu . [gate|up], d act . down at Idefics2's width, dqkv . qkv),
+    both norm flavours, fp32 and bf16 streams, accumulating into a non-zero dx."""
+    M, H = 256, 4096
+    a = (torch.randn(M, K, generator=g(51)) * 0.05).to(torch.bfloat16).to(DEV)
+    wt = (torch.randn(H, K, generator=g(52)) * K ** -0.5).to(torch.bfloat16).to(DEV)
+    x = torch.randn(M, H, generator=g(53)).to(x_dt).to(DEV)
+    w = (1 + 0.1 * torch.randn(H, generator=g(54))).to(torch.bfloat16).to(DEV)
+    base = torch.randn(M, H, generator=g(55)).to(x_dt).to(DEV)
+    o = ops()
+    assert o.linear_produce(a, wt) is not None, "the plan must split this shape"
+    for acc in (True, False):
+        d1, d2 = base.clone(), base.clone()
+        o.rmsnorm_bwd(x, w, o.linear(a, wt), d1, 1e-6, accumulate=acc, flavour=flavour)
+        o.rmsnorm_bwd_from(x, w, a, wt, d2, 1e-6, accumulate=acc, flavour=flavour)
+        assert torch.equal(d1, d2), (K, x_dt, flavour, acc)
