@@ -23,13 +23,21 @@ extern "C" {
 /* Bumped whenever an entry point is added, removed or changes its arguments; licv/_lib.py holds the same constant and refuses a
  * library that answers anything else.  1 = round 1; 2 = rounds 2-3 (fp8, split-K slices, runner, front-end, backward, image input);
  * 3 = round 4 (lab library split off; weight-streaming GEMM; beam scoring; decode-step fusion). */
-#define LICV_ABI_VERSION 5
+#define LICV_ABI_VERSION 6
 
 enum { LICV_BF16 = 0, LICV_F32 = 1 };
 enum { LICV_OK = 0, LICV_E_BADARG = -1, LICV_E_UNSUPPORTED = -2, LICV_E_HIP = -3 };
 
 int         licv_version(void);
 const char* licv_last_error(void);
+
+/* The one collective of the path (replaces the gradient all-reduce Lightning DDP / DeepSpeed ZeRO-2 run for the
+ * reference, ref:config/trainer/ddp.yaml:5, ref:config/trainer/zero2.yaml:5): in-place sum (average != 0: mean) of n fp32 values - the
+ * gradients of icv and alpha, 131 k floats - over the ranks of `nccl_comm`, an ncclComm_t of the RCCL ALREADY loaded and initialised in
+ * the calling process, enqueued on `stream`.  The library opens no communicator and does not link RCCL: ncclAllReduce is looked up
+ * (dlsym) at the first call; LICV_E_UNSUPPORTED when the process has no RCCL.  (The Python host keeps torch.distributed.all_reduce,
+ * which owns its communicator: licv/trainer.py.) */
+int licv_allreduce_small(void* nccl_comm, float* data, int64_t n, int average, void* stream);
 
 /* ---- the hook: ref:icv_src/icv_model/icv_intervention.py:61-86 (intervention_function) ----
  * out[r,:] = (h[r,:]+v) / ||h[r,:]+v|| * ||h[r,:]||, fp32 maths, fp32 output (torch promotion of a

@@ -18,7 +18,7 @@ LAB_PATH = Path(os.environ.get("LICV_HIP_LAB_LIB", _HERE / "liblicv_hip_lab.so")
 LAB_HEADER = _HERE.parents[1] / "include" / "licv_hip_lab.h"
 
 LICV_BF16, LICV_F32 = 0, 1
-ABI_VERSION = 5          # == LICV_ABI_VERSION of include/licv_hip.h this binding was written against (check_exports compares both)
+ABI_VERSION = 6          # == LICV_ABI_VERSION of include/licv_hip.h this binding was written against (check_exports compares both)
 
 _lib = None
 _lab = None
@@ -98,6 +98,7 @@ def lib() -> C.CDLL:
             "licv_add_rmsnorm_fwd": [P, I, P, P, I, F, P, P, I64, I64, F, I, P],
             "licv_runner_option": [I, I],
             "licv_backward_option": [I, I],
+            "licv_allreduce_small": [P, P, I64, I, P],
             "licv_scatter_rows": [P, P, P, I64, I64, P],
             "licv_ce_rows": [P, I, P, P, I64, I64, I64, P, F, P, P, I64, P, I, P],
             "licv_head_group_sum": [P, P, I64, I64, I64, I64, I64, I64, P],
